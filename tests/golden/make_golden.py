@@ -1,0 +1,266 @@
+"""
+Generate golden vectors for the GP hot path by IMPORTING the reference
+(C-bowman/inference-tools, mounted read-only at /root/reference) and running
+it on the seeded synthetic inputs of `workloads.py`.
+
+Run in the build container only:   python tests/golden/make_golden.py [case ...]
+
+The reference's source never travels: this script only imports it (with
+PYTHONDONTWRITEBYTECODE so nothing is written into the reference tree), and the
+outputs are stored as small .npz fixtures beside this file.  On a machine
+without /root/reference (the GPU box) the script exits with a message.
+
+Cases
+  t32        the reference's own GP test data (tests/gp/test_GpRegressor.py:36-42), SE and RQ,
+             full matrices + every public method of the path
+  cfg1       BASELINE config 1: SE, N=512, d=2
+  rq256      RQ, N=256, d=16 (config-3 shape at a size the reference classes can hold)
+  cfg4       BASELINE config 4: SE, N=4096, d=4, 1000 EI candidates
+  cfg2       BASELINE config 2: SE, N=8192, d=8 (needs ~16 GB RSS, several minutes)
+  fail       a theta for which numpy.linalg.cholesky raises (pins the -1e50 path)
+"""
+import os
+import sys
+import types
+import warnings
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+
+REF = "/root/reference"
+if not os.path.isdir(os.path.join(REF, "inference")):
+    print("reference tree not present - golden vectors can only be generated in the build container")
+    sys.exit(0)
+
+# `import inference` needs setuptools_scm (inference/__init__.py:3-8), which is absent:
+# pre-register a bare package pointing at the reference source instead.
+pkg = types.ModuleType("inference")
+pkg.__path__ = [os.path.join(REF, "inference")]
+sys.modules["inference"] = pkg
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+
+import numpy as np  # noqa: E402
+from inference.gp import (  # noqa: E402
+    GpRegressor,
+    SquaredExponential,
+    RationalQuadratic,
+    WhiteNoise,
+    ExpectedImprovement,
+    UpperConfidenceBound,
+    MaxVariance,
+)
+import workloads as wl  # noqa: E402
+
+IDX64 = None
+
+
+def idx64(n):
+    return np.unique(np.linspace(0, n - 1, 64).astype(int))
+
+
+def kernel_cls(kid):
+    return SquaredExponential if kid == wl.SE else RationalQuadratic
+
+
+def common_outputs(gp, thetas, pts, out, prefix="", full=False, grads=True):
+    n = gp.n_points
+    ii = idx64(n)
+    out[prefix + "hp_bounds"] = np.array(gp.hp_bounds, dtype=float)
+    out[prefix + "labels"] = np.array(gp.hyperpar_labels)
+    out[prefix + "str"] = np.array(str(gp))
+    out[prefix + "thetas"] = thetas
+    out[prefix + "lml"] = np.array([gp.marginal_likelihood(t) for t in thetas])
+    if grads:
+        res = [gp.marginal_likelihood_gradient(t) for t in thetas]
+        out[prefix + "lml_g_val"] = np.array([r[0] for r in res])
+        out[prefix + "lml_g_grad"] = np.array([r[1] for r in res])
+    # fitted state at thetas[0]
+    gp.set_hyperparameters(thetas[0])
+    out[prefix + "alpha_norm"] = np.linalg.norm(gp.alpha)
+    out[prefix + "alpha_idx"] = ii
+    out[prefix + "alpha_sub"] = gp.alpha[ii]
+    out[prefix + "diagL_sub"] = np.diagonal(gp.L)[ii]
+    out[prefix + "logdet"] = np.log(np.diagonal(gp.L)).sum()
+    mu, sig = gp(pts)
+    out[prefix + "pts"] = pts
+    out[prefix + "mu"] = mu
+    out[prefix + "sig"] = sig
+    pm, pc = gp.build_posterior(pts[:16])
+    out[prefix + "post_mu"] = pm
+    out[prefix + "post_cov"] = pc
+    if full:
+        out[prefix + "K_xx"] = gp.K_xx
+        out[prefix + "L"] = gp.L
+        out[prefix + "alpha"] = gp.alpha
+
+
+def case_t32():
+    """The reference's own test data: tests/gp/test_GpRegressor.py:36-42."""
+    out = {}
+    n = 32
+    rng = np.random.default_rng(1)
+    points = rng.uniform(low=0.0, high=2.0, size=(n, 2))
+    values = np.sin(points[:, 0]) * np.cos(points[:, 1]) + rng.normal(scale=0.1, size=n)
+    errors = np.full(n, fill_value=0.1)
+    out["x"], out["y"], out["y_err"] = points, values, errors
+    qrng = np.random.default_rng(99)
+    pts = qrng.uniform(0.0, 2.0, size=(24, 2))
+
+    # thetas as in test_marginal_likelihood_gradient (tests/gp/test_GpRegressor.py:65-69)
+    trng = np.random.default_rng(123)
+    th_se = trng.uniform(low=[-0.3, -1.5, 0.1, 0.1], high=[0.3, 0.5, 1.5, 1.5], size=[8, 4])
+    th_rq = trng.uniform(
+        low=[-0.3, -1.5, -1.0, 0.1, 0.1], high=[0.3, 0.5, 3.0, 1.5, 1.5], size=[8, 5]
+    )
+    for name, kid, th in (("se_", wl.SE, th_se), ("rq_", wl.RQ, th_rq)):
+        gp = GpRegressor(points, values, y_err=errors, hyperpars=th[0], kernel=kernel_cls(kid))
+        common_outputs(gp, th, pts, out, prefix=name, full=True)
+        # kernel-level outputs
+        K, dK = gp.cov.covariance_and_gradients(th[1][1:])
+        out[name + "cov_K"] = K
+        out[name + "cov_dK"] = np.array(dK)
+        out[name + "cov_cross"] = gp.cov(pts, points, th[1][1:])
+        # LOO trio (regression.py:451-526)
+        gp.set_hyperparameters(th[0])
+        lm, ls = gp.loo_predictions()
+        out[name + "loo_mu"], out[name + "loo_sig"] = lm, ls
+        out[name + "loo"] = np.array([gp.loo_likelihood(t) for t in th])
+        res = [gp.loo_likelihood_gradient(t) for t in th]
+        out[name + "loo_g_val"] = np.array([r[0] for r in res])
+        out[name + "loo_g_grad"] = np.array([r[1] for r in res])
+    # SE-only spatial gradients (RQ raises NotImplementedError: covariance.py:38-44)
+    gp = GpRegressor(points, values, y_err=errors, hyperpars=th_se[0])
+    g_mu, g_cov = gp.gradient(pts[:16])
+    s_mu, s_var = gp.spatial_derivatives(pts[:16])
+    out["se_grad_mu"], out["se_grad_cov"] = g_mu, g_cov
+    out["se_sd_mu"], out["se_sd_var"] = s_mu, s_var
+    # acquisition functions on the fitted SE GP (acquisition.py:44-232)
+    for nm, acq in (("ei", ExpectedImprovement()), ("ucb", UpperConfidenceBound()), ("mv", MaxVariance())):
+        acq.update_gp(gp)
+        out[f"se_{nm}_call"] = np.array([acq(p) for p in pts])
+        out[f"se_{nm}_opt"] = np.array([acq.opt_func(p) for p in pts])
+        r = [acq.opt_func_gradient(p) for p in pts]
+        out[f"se_{nm}_optg_val"] = np.array([float(np.squeeze(a)) for a, _ in r])
+        out[f"se_{nm}_optg_grad"] = np.array([b for _, b in r])
+        out[f"se_{nm}_conv"] = np.array([acq.convergence_metric(p) for p in pts[:4]])
+    # composite kernel SE + WhiteNoise (covariance.py:47-105,108-178)
+    thc = np.array([0.1, -0.4, 0.3, 0.6, -2.0])
+    gpc = GpRegressor(points, values, y_err=errors, hyperpars=thc, kernel=SquaredExponential() + WhiteNoise())
+    out["sewn_theta"] = thc
+    out["sewn_labels"] = np.array(gpc.hyperpar_labels)
+    out["sewn_hp_bounds"] = np.array(gpc.hp_bounds, dtype=float)
+    out["sewn_lml"] = gpc.marginal_likelihood(thc)
+    v, g = gpc.marginal_likelihood_gradient(thc)
+    out["sewn_lml_g_val"], out["sewn_lml_g_grad"] = v, g
+    out["sewn_alpha"] = gpc.alpha
+    m, s = gpc(pts)
+    out["sewn_mu"], out["sewn_sig"] = m, s
+    # 1-D data (regression.py:110-112 reshape path) as in tests/gp/test_GpRegressor.py:97-117
+    rng1 = np.random.default_rng(42)
+    N, S = 10, 1.1
+    x1 = np.linspace(0, 10, N)
+    y1 = 0.3 * x1 + 0.02 * x1**3 + 5.0 + rng1.normal(size=N) * S
+    e1 = np.zeros(N) + S
+    th1 = np.array([y1.mean(), np.log(y1.std()), np.log(2.0)])
+    gp1 = GpRegressor(x1, y1, y_err=e1, hyperpars=th1)
+    sx = np.linspace(0, 10, 30)
+    out["d1_x"], out["d1_y"], out["d1_err"], out["d1_theta"], out["d1_pts"] = x1, y1, e1, th1, sx
+    out["d1_mu"], out["d1_sig"] = gp1(sx)
+    out["d1_grad_mu"], out["d1_grad_cov"] = gp1.gradient(sx)
+    out["d1_sd_mu"], out["d1_sd_var"] = gp1.spatial_derivatives(sx)
+    out["d1_hp_bounds"] = np.array(gp1.hp_bounds, dtype=float)
+    return out
+
+
+def case_synthetic(cfg, kid, n, d, n_theta, m, grads=True):
+    out = {}
+    x, y, y_err = wl.synthetic_dataset(cfg, n, d)
+    thetas = wl.theta_set(kid, y, d, n_theta)
+    pts = wl.query_points(cfg, m, d)
+    gp = GpRegressor(x, y, y_err=y_err, hyperpars=thetas[0], kernel=kernel_cls(kid))
+    common_outputs(gp, thetas, pts, out, grads=grads)
+    out["meta"] = np.array([cfg, kid, n, d])
+    return out, gp
+
+
+def case_cfg1():
+    out, gp = case_synthetic(1, wl.SE, 512, 2, 8, 64)
+    return out
+
+
+def case_rq256():
+    out, gp = case_synthetic(3, wl.RQ, 256, 16, 8, 64)
+    return out
+
+
+def case_cfg4():
+    out, gp = case_synthetic(4, wl.SE, 4096, 4, 2, 64, grads=True)
+    # 1000 EI candidates (acquisition.py:76-125)
+    cand = wl.query_points(4004, 1000, 4)
+    ei = ExpectedImprovement()
+    ei.update_gp(gp)
+    out["cand"] = cand
+    out["ei_call"] = np.array([ei(p) for p in cand])
+    out["ei_opt"] = np.array([ei.opt_func(p) for p in cand])
+    r = [ei.opt_func_gradient(p) for p in cand[:200]]
+    out["ei_optg_val"] = np.array([float(np.squeeze(a)) for a, _ in r])
+    out["ei_optg_grad"] = np.array([b for _, b in r])
+    out["mu_max"] = ei.mu_max
+    # force the Z < -3 branch: same GP, a y_max far above the data
+    ei.mu_max = gp.y.max() + 2.0
+    out["ei_far_mu_max"] = ei.mu_max
+    out["ei_far_call"] = np.array([ei(p) for p in cand[:200]])
+    out["ei_far_opt"] = np.array([ei.opt_func(p) for p in cand[:200]])
+    r = [ei.opt_func_gradient(p) for p in cand[:200]]
+    out["ei_far_optg_val"] = np.array([float(np.squeeze(a)) for a, _ in r])
+    out["ei_far_optg_grad"] = np.array([b for _, b in r])
+    return out
+
+
+def case_cfg2():
+    out, gp = case_synthetic(2, wl.SE, 8192, 8, 2, 64, grads=False)
+    return out
+
+
+def case_fail():
+    """Inputs for which numpy.linalg.cholesky raises LinAlgError, so that
+    marginal_likelihood returns -1e50 (regression.py:540-542):
+    a symmetric but indefinite y_cov (regression.py:262-293 accepts it unchecked),
+    (an overflowing amplitude is NOT such a case: cholesky returns non-finite values and
+    scipy's solve_triangular then raises ValueError)."""
+    out = {}
+    rng = np.random.default_rng(3)
+    x = rng.uniform(0, 1, (48, 2))
+    y = np.sin(3 * x[:, 0]) + x[:, 1]
+    th0 = np.array([y.mean(), 0.0, 0.0, 0.0])
+    y_cov = np.diag(np.where(np.arange(48) % 7 == 3, -1.5, 0.01))
+    gp = GpRegressor(x, y, y_cov=y_cov, hyperpars=np.array([y.mean(), 2.0, -3.0, -3.0]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        v_cov = gp.marginal_likelihood(th0)
+        v_ok = gp.marginal_likelihood(np.array([y.mean(), 2.0, -3.0, -3.0]))
+    assert v_cov == -1e50 and v_ok != -1e50
+    out["x"], out["y"], out["y_cov"] = x, y, y_cov
+    out["theta_bad"], out["theta_ok"] = th0, np.array([y.mean(), 2.0, -3.0, -3.0])
+    out["lml_bad"], out["lml_ok"] = v_cov, v_ok
+    return out
+
+
+CASES = {
+    "t32": case_t32,
+    "cfg1": case_cfg1,
+    "rq256": case_rq256,
+    "cfg4": case_cfg4,
+    "cfg2": case_cfg2,
+    "fail": case_fail,
+}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or ["t32", "cfg1", "rq256", "fail"]
+    for nm in names:
+        res = CASES[nm]()
+        path = os.path.join(HERE, f"{nm}.npz")
+        np.savez_compressed(path, **res)
+        print(f"wrote {path}: {len(res)} arrays, {os.path.getsize(path)/1024:.1f} KiB")

@@ -1,0 +1,155 @@
+"""
+Pins the CPU oracle (oracle/gp_oracle.py) against golden vectors produced by
+the imported reference (tests/golden/make_golden.py).  CPU only.
+
+Tolerances: the oracle uses the same LAPACK entry points as the reference, so
+agreement is at the oracle noise floor (different BLAS blocking / thread counts
+between the two call sequences): rtol 1e-11 scaled by the quantity's magnitude.
+"""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as orc
+import workloads as wl
+
+
+def close(a, b, rtol=1e-11, scale=None):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    s = np.abs(b).max() if scale is None else scale
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.abs(a - b).max() <= rtol * max(s, 1e-300), np.abs(a - b).max() / max(s, 1e-300)
+
+
+@pytest.mark.parametrize("name,kid", [("se_", orc.SE), ("rq_", orc.RQ)])
+def test_t32_all_methods(golden, name, kid):
+    g = golden("t32")
+    x, y, e = g["x"], g["y"], g["y_err"]
+    th = g[name + "thetas"]
+    gp = orc.OracleGp(x, y, e, kernel=kid, hyperpars=th[0])
+    # bit-exact K (same ops, same order) — covariance.py:247-255 / 343-348
+    assert np.array_equal(gp.K_xx, g[name + "K_xx"])
+    close(gp.L, g[name + "L"])
+    close(gp.alpha, g[name + "alpha"])
+    close(np.array(gp.hp_bounds), g[name + "hp_bounds"], rtol=1e-13)
+    close([gp.marginal_likelihood(t) for t in th], g[name + "lml"])
+    res = [gp.marginal_likelihood_gradient(t) for t in th]
+    close([r[0] for r in res], g[name + "lml_g_val"])
+    close([r[1] for r in res], g[name + "lml_g_grad"], rtol=1e-10)
+    mu, sig = gp(g[name + "pts"])
+    close(mu, g[name + "mu"])
+    close(sig, g[name + "sig"])
+    pm, pc = gp.build_posterior(g[name + "pts"][:16])
+    close(pm, g[name + "post_mu"])
+    close(pc, g[name + "post_cov"])
+    K, dK = orc.kernel_build_and_grads(kid, x, th[1][1:])
+    assert np.array_equal(K, g[name + "cov_K"])
+    close(np.array(dK), g[name + "cov_dK"], rtol=1e-14)
+    assert np.array_equal(orc.kernel_cross(kid, g[name + "pts"], x, th[1][1:]), g[name + "cov_cross"])
+    lm, ls = gp.loo_predictions()
+    close(lm, g[name + "loo_mu"])
+    close(ls, g[name + "loo_sig"])
+    close([gp.loo_likelihood(t) for t in th], g[name + "loo"])
+    res = [gp.loo_likelihood_gradient(t) for t in th]
+    close([r[0] for r in res], g[name + "loo_g_val"])
+    close([r[1] for r in res], g[name + "loo_g_grad"], rtol=1e-10)
+
+
+def test_t32_spatial_gradients_and_acquisition(golden):
+    g = golden("t32")
+    gp = orc.OracleGp(g["x"], g["y"], g["y_err"], kernel=orc.SE, hyperpars=g["se_thetas"][0])
+    pts = g["se_pts"]
+    gm, gc = gp.gradient(pts[:16])
+    close(gm, g["se_grad_mu"])
+    close(gc, g["se_grad_cov"])
+    sm, sv = gp.spatial_derivatives(pts[:16])
+    close(sm, g["se_sd_mu"])
+    close(sv, g["se_sd_var"])
+    mu, sig = gp(pts)
+    mu_max = g["y"].max()
+    close(orc.ei_value(mu, sig, mu_max), g["se_ei_call"])
+    close(-orc.ei_log(mu, sig, mu_max), g["se_ei_opt"])
+    sm, sv = gp.spatial_derivatives(pts)
+    val, grad = orc.ei_opt_func_gradient(mu, sig, sm, sv, mu_max)
+    close(val, g["se_ei_optg_val"])
+    close(grad, g["se_ei_optg_grad"], rtol=1e-10)
+    # UCB (acquisition.py:168-189, kappa = 2) and MaxVariance (acquisition.py:212-229)
+    close(mu + 2.0 * sig, g["se_ucb_call"])
+    close(-(dmu := sm) - 0.5 * 2.0 * sv / sig[:, None], g["se_ucb_optg_grad"], rtol=1e-10)
+    close(sig**2, g["se_mv_call"])
+    close(-sv, g["se_mv_optg_grad"], rtol=1e-10)
+
+
+def test_t32_white_noise_composite(golden):
+    g = golden("t32")
+    th = g["sewn_theta"]
+    gp = orc.OracleGp(g["x"], g["y"], g["y_err"], kernel=orc.SE, hyperpars=th, white_noise=True)
+    close(np.array(gp.hp_bounds), g["sewn_hp_bounds"], rtol=1e-13)
+    close(gp.marginal_likelihood(th), g["sewn_lml"])
+    v, gr = gp.marginal_likelihood_gradient(th)
+    close(v, g["sewn_lml_g_val"])
+    close(gr, g["sewn_lml_g_grad"], rtol=1e-10)
+    close(gp.alpha, g["sewn_alpha"])
+    mu, sig = gp(g["se_pts"])
+    close(mu, g["sewn_mu"])
+    close(sig, g["sewn_sig"])
+
+
+def test_t32_one_dimensional(golden):
+    g = golden("t32")
+    gp = orc.OracleGp(g["d1_x"], g["d1_y"], g["d1_err"], kernel=orc.SE, hyperpars=g["d1_theta"])
+    close(np.array(gp.hp_bounds), g["d1_hp_bounds"], rtol=1e-13)
+    mu, sig = gp(g["d1_pts"])
+    close(mu, g["d1_mu"])
+    close(sig, g["d1_sig"])
+    gm, gc = gp.gradient(g["d1_pts"])
+    close(gm, g["d1_grad_mu"])
+    close(gc, g["d1_grad_cov"])
+    sm, sv = gp.spatial_derivatives(g["d1_pts"])
+    close(sm, g["d1_sd_mu"])
+    close(sv, g["d1_sd_var"])
+
+
+@pytest.mark.parametrize("case", ["cfg1", "rq256", "cfg4", "cfg2"])
+def test_synthetic_configs(golden, case):
+    g = golden(case)
+    cfg, kid, n, d = [int(v) for v in g["meta"]]
+    if n > 4096:
+        pytest.skip("cfg2-size oracle run is exercised by the GPU parity test and bench, not the CPU suite")
+    x, y, e = wl.synthetic_dataset(cfg, n, d)
+    th = g["thetas"]
+    assert np.array_equal(th, wl.theta_set(kid, y, d, len(th)))
+    gp = orc.OracleGp(x, y, e, kernel=kid, hyperpars=th[0])
+    close(np.array(gp.hp_bounds), g["hp_bounds"], rtol=1e-12)
+    n_lml = len(th) if n <= 1024 else 1
+    close([gp.marginal_likelihood(t) for t in th[:n_lml]], g["lml"][:n_lml])
+    if "lml_g_val" in g and n <= 1024:
+        res = [gp.marginal_likelihood_gradient(t) for t in th[:2]]
+        close([r[0] for r in res], g["lml_g_val"][:2])
+        close([r[1] for r in res], g["lml_g_grad"][:2], rtol=1e-9)
+    close(np.linalg.norm(gp.alpha), g["alpha_norm"])
+    close(gp.alpha[g["alpha_idx"]], g["alpha_sub"], rtol=1e-10)
+    close(np.diagonal(gp.L)[g["alpha_idx"]], g["diagL_sub"])
+    close(np.log(np.diagonal(gp.L)).sum(), g["logdet"])
+    mu, sig = gp(g["pts"])
+    close(mu, g["mu"], rtol=1e-10)
+    close(sig, g["sig"], rtol=1e-10)
+    pm, pc = gp.build_posterior(g["pts"][:16])
+    close(pm, g["post_mu"], rtol=1e-10)
+    close(pc, g["post_cov"], rtol=1e-10)
+    if "ei_call" in g:
+        m2, s2 = gp(g["cand"])
+        close(orc.ei_value(m2, s2, float(g["mu_max"])), g["ei_call"], rtol=1e-9)
+        close(-orc.ei_log(m2, s2, float(g["mu_max"])), g["ei_opt"], rtol=1e-9)
+        far = float(g["ei_far_mu_max"])
+        close(-orc.ei_log(m2[:200], s2[:200], far), g["ei_far_opt"], rtol=1e-9)
+        sm, sv = gp.spatial_derivatives(g["cand"][:200])
+        val, grad = orc.ei_opt_func_gradient(m2[:200], s2[:200], sm, sv, far)
+        close(val, g["ei_far_optg_val"], rtol=1e-9)
+        close(grad, g["ei_far_optg_grad"], rtol=1e-8)
+
+
+def test_cholesky_failure_sentinel(golden):
+    g = golden("fail")
+    gp = orc.OracleGp(g["x"], g["y"], y_cov=g["y_cov"], kernel=orc.SE)
+    assert gp.marginal_likelihood(g["theta_bad"]) == -1e50 == float(g["lml_bad"])
+    close(gp.marginal_likelihood(g["theta_ok"]), g["lml_ok"])
