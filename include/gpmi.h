@@ -1,0 +1,188 @@
+/*
+ * gpmi.h — C-ABI of the MI355X-native Gaussian-process regression hot path.
+ *
+ * Drop-in boundary for the `inference.gp` path of C-bowman/inference-tools
+ * (reference @ 2025-06-14).  The reference is pure Python and has NO FFI of its
+ * own; each entry point below therefore cites the
+ * reference *Python* function it replaces (file:line relative to the reference
+ * root).  The Python host package `inference_amd` binds these through ctypes
+ * (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain C: opaque handle, raw pointers, 64-bit sizes; no torch / numpy types.
+ *   - all arithmetic is IEEE fp64; matrices are row-major (NumPy C order).
+ *   - pointers named *_host are host memory owned by the caller; the library
+ *     owns every device buffer behind the handle.  Pointers named *_dev in the
+ *     `gpmi_dev_*` block are device pointers (tests / micro-benchmarks).
+ *   - every function returns an int status: 0 = ok, <0 = error
+ *     (GPMI_ERR_*; text via gpmi_last_error).  Numerical failure of the
+ *     Cholesky factorisation is NOT an error status: it is reported LAPACK-style
+ *     through `info` (0 = ok, k>0 = leading minor of order k is not positive
+ *     definite / not finite), which the host maps to the reference's
+ *     `LinAlgError` handling (regression.py:536-542).
+ *   - calls on one handle are serialised on the handle's HIP stream; several
+ *     handles may be used concurrently from different threads / on different
+ *     devices.  No callbacks into the caller.
+ */
+#ifndef GPMI_H
+#define GPMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPMI_VERSION 100
+
+/* covariance kernels (covariance.py:181-279 SquaredExponential, 282-368 RationalQuadratic) */
+#define GPMI_KERNEL_SE 0 /* theta = [ln a, ln l_1..ln l_d]            n_theta = d+1 */
+#define GPMI_KERNEL_RQ 1 /* theta = [ln a, ln kappa, ln l_1..ln l_d]  n_theta = d+2 */
+
+#define GPMI_OK 0
+#define GPMI_ERR_ARG (-1)     /* bad argument / call order */
+#define GPMI_ERR_HIP (-2)     /* HIP runtime error */
+#define GPMI_ERR_NOMEM (-3)   /* device allocation failed */
+#define GPMI_ERR_NODEVICE (-4)/* no usable gfx950 device */
+
+typedef struct gpmi_ctx gpmi_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------ */
+int gpmi_version(void);
+/* number of visible HIP devices (does not create a context) */
+int gpmi_device_count(int* count);
+/* create a handle bound to `device` (own stream + workspaces) */
+int gpmi_create(int device, gpmi_ctx** ctx);
+int gpmi_destroy(gpmi_ctx* ctx);
+/* text of the last error on this handle (ctx may be NULL: last create error) */
+const char* gpmi_last_error(const gpmi_ctx* ctx);
+/* block until all work queued on the handle's stream has finished */
+int gpmi_sync(gpmi_ctx* ctx);
+
+/* ---- data -------------------------------------------------------------------------
+ * Replaces GpRegressor.__init__ storing x, y and sig (regression.py:94-133, 246-322) and
+ * CovarianceFunction.pass_spatial_data (covariance.py:212-226, 309-321): only x (n x d),
+ * y (n) and the data-error covariance are uploaded — the N x N x d tensors of the
+ * reference are never formed.
+ *   noise_var_host : n values y_err**2 (regression.py:320) or NULL for zeros (regression.py:322)
+ *   y_cov_host     : dense n x n y-covariance (regression.py:262-293) or NULL; replaces noise_var
+ */
+int gpmi_set_data(gpmi_ctx* ctx, const double* x_host, const double* y_host,
+                  const double* noise_var_host, const double* y_cov_host, int64_t n, int64_t d);
+
+/* ---- fit ---------------------------------------------------------------------------
+ * Replaces GpRegressor.set_hyperparameters (regression.py:218-244):
+ *   K_xx = K(theta) + extra_diag*I + sig ; L = chol(K_xx) ; alpha = L^-T L^-1 (y - mu)
+ *   theta_host  : covariance hyper-parameters (log space), n_theta values
+ *   extra_diag  : variance added to the diagonal by a `+ WhiteNoise()` component
+ *                 (covariance.py:163-169), 0 otherwise
+ *   mu_host     : the mean vector MeanFunction.build_mean(theta_mean) (mean.py:47-48), n values
+ *   alpha_host  : out, n values          logdet_host : out, sum_i ln L_ii
+ * The factor stays resident on the device for predict / posterior / gradients.
+ */
+int gpmi_fit(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_theta, double extra_diag,
+             const double* mu_host, double* alpha_host, double* logdet_host, int* info);
+
+/* ---- log-marginal likelihood ------------------------------------------------------
+ * Replaces GpRegressor.marginal_likelihood (regression.py:528-542):
+ *   lml = -1/2 |L^-1 (y-mu)|^2 - sum ln L_ii      (no -(n/2) ln 2 pi term, as the reference)
+ * Uses a scratch matrix: the fitted state of gpmi_fit is not disturbed.
+ * If info != 0 the value written is -1e50 (regression.py:540-542 sentinel; the host warns).
+ */
+int gpmi_lml(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_theta, double extra_diag,
+             const double* mu_host, double* lml_host, int* info);
+
+/* T independent evaluations of gpmi_lml (hyper-parameter grid / DE population / PT chains):
+ *   thetas_host : T x n_theta      extra_diag_host : T values or NULL
+ *   mus_host    : T x n mean vectors, or NULL with mu_const_host : T constants (ConstantMean)
+ *   lml_host    : T out            info_host : T out
+ * Evaluations are spread over the handle's worker streams (gpmi_set_streams). */
+int gpmi_lml_batch(gpmi_ctx* ctx, int kernel, int64_t T, const double* thetas_host, int n_theta,
+                   const double* extra_diag_host, const double* mus_host,
+                   const double* mu_const_host, double* lml_host, int* info_host);
+/* number of concurrent worker streams (each with its own n x n scratch) used by gpmi_lml_batch */
+int gpmi_set_streams(gpmi_ctx* ctx, int n_streams);
+
+/* Replaces GpRegressor.marginal_likelihood_gradient (regression.py:544-567):
+ *   grad_theta_host : n_theta values  1/2 sum (alpha alpha^T - K^-1) o dK/dtheta_j
+ *                     (dK_j recomputed from x on the fly: covariance.py:268-276, 350-365)
+ *   trace_q_host    : sum_i (alpha_i^2 - K^-1_ii)  (= d/d extra_diag * 2; WhiteNoise gradient,
+ *                     covariance.py:171-175) or NULL
+ *   alpha_host      : n values K^-1 (y-mu) for the mean-parameter gradients (regression.py:563)
+ * No sentinel here: info != 0 is returned to the host, which raises like the reference
+ * (regression.py:555 has no LinAlgError guard). */
+int gpmi_lml_grad(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_theta,
+                  double extra_diag, const double* mu_host, double* lml_host,
+                  double* grad_theta_host, double* trace_q_host, double* alpha_host, int* info);
+
+/* ---- prediction (needs a prior gpmi_fit) --------------------------------------------
+ * Replaces the per-point loop of GpRegressor.__call__ (regression.py:188-216) by one batched
+ * cross-covariance + triangular solve:
+ *   mu_host[m]  = k(q_m, x) . alpha            (the host adds MeanFunction(q), regression.py:212)
+ *   var_host[m] = a^2 - |L^-1 k(q_m, x)|^2     (the host takes sqrt(abs(.)), regression.py:216)
+ */
+int gpmi_predict(gpmi_ctx* ctx, const double* pts_host, int64_t m, double* mu_host,
+                 double* var_host);
+/* Replaces GpRegressor.build_posterior (regression.py:421-449): mu (m) and
+ * Sigma = K_qq - Q^T Q (m x m), Q = L^-1 K_qx^T.  cov_host may be NULL (mean_only). */
+int gpmi_posterior(gpmi_ctx* ctx, const double* pts_host, int64_t m, double* mu_host,
+                   double* cov_host);
+/* Replaces GpRegressor.spatial_derivatives (regression.py:387-419), SE kernel only
+ * (RationalQuadratic has no gradient_terms: covariance.py:38-44): dmu (m x d), dvar (m x d). */
+int gpmi_spatial_derivatives(gpmi_ctx* ctx, const double* pts_host, int64_t m, double* dmu_host,
+                             double* dvar_host);
+/* Replaces GpRegressor.gradient (regression.py:351-385), SE only: mean (m x d) and covariance
+ * (m x d x d) of the gradient of the regression estimate. */
+int gpmi_gradient(gpmi_ctx* ctx, const double* pts_host, int64_t m, double* gmu_host,
+                  double* gcov_host);
+
+/* ---- covariance plugin surface -----------------------------------------------------
+ * Replaces CovarianceFunction.build_covariance (covariance.py:247-255, 343-348): the n x n matrix
+ * a^2 (C + 1e-12 I) + extra_diag I, plus the data-error covariance when with_noise != 0. */
+int gpmi_covariance(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_theta,
+                    double extra_diag, int with_noise, double* K_host);
+/* Replaces CovarianceFunction.__call__(u, v = x, theta) (covariance.py:240-245, 335-341):
+ * the m x n cross-covariance between pts and the stored x, no jitter. */
+int gpmi_cross_covariance(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_theta,
+                          const double* pts_host, int64_t m, double* out_host);
+
+/* ---- lazy attribute downloads (GpRegressor.K_xx / .L, regression.py:239-241) ------- */
+int gpmi_get_K(gpmi_ctx* ctx, double* K_host); /* n x n, rebuilt from the fitted theta */
+int gpmi_get_L(gpmi_ctx* ctx, double* L_host); /* n x n lower factor, upper triangle zero */
+
+/* ---- leave-one-out (regression.py:451-526) ------------------------------------------ */
+/* diag(K^-1) of the fitted model: var = 1/diag, mu = y - alpha*var on the host (regression.py:460-466) */
+int gpmi_loo_diag(gpmi_ctx* ctx, double* ikdiag_host);
+
+/* ---- instrumentation ---------------------------------------------------------------
+ * HIP-event timing on the handle's own stream (torch.cuda.Event would not see it). */
+int gpmi_timer_start(gpmi_ctx* ctx);
+int gpmi_timer_stop(gpmi_ctx* ctx, float* ms);
+/* per-kernel-class accounting: when enabled every launch of the class is bracketed by events */
+#define GPMI_PROF_KBUILD 0  /* covariance build            (HBM-write bound) */
+#define GPMI_PROF_SYRK 1    /* potrf trailing SYRK/GEMM    (fp64 MFMA bound) */
+#define GPMI_PROF_PANEL 2   /* potrf diagonal block + panel TRSM (latency bound) */
+#define GPMI_PROF_SOLVE 3   /* triangular solves / reductions */
+#define GPMI_PROF_NCLASS 4
+int gpmi_profile_enable(gpmi_ctx* ctx, int on);
+/* accumulated since the last reset: launches, total ms, algorithmic flops and bytes */
+int gpmi_profile_read(gpmi_ctx* ctx, int klass, int64_t* launches, double* ms, double* flops,
+                      double* bytes);
+int gpmi_profile_reset(gpmi_ctx* ctx);
+
+/* ---- device-pointer entry points (kernel tests / micro-benchmarks) -------------------
+ * Matrices are row-major with leading dimension ld (multiple of 128); n multiple of 128. */
+int gpmi_dev_alloc(gpmi_ctx* ctx, int64_t bytes, void** ptr_dev);
+int gpmi_dev_free(gpmi_ctx* ctx, void* ptr_dev);
+int gpmi_dev_upload(gpmi_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes);
+int gpmi_dev_download(gpmi_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
+/* in-place lower Cholesky of the n x n matrix at A_dev (upper triangle untouched) */
+int gpmi_dev_potrf(gpmi_ctx* ctx, double* A_dev, int64_t n, int64_t ld, int* info);
+/* C (m x n, lower tiles only if lower != 0) -= A (m x k) * B (n x k)^T */
+int gpmi_dev_gemm_nt(gpmi_ctx* ctx, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
+                     const double* B_dev, int64_t ldb, int64_t m, int64_t n, int64_t k, int lower);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPMI_H */

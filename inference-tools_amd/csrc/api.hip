@@ -1,0 +1,694 @@
+// C-ABI of libgpmi (see include/gpmi.h): handle management, host<->device plumbing and the
+// orchestration of the GP hot path (covariance build -> Cholesky -> solves -> reductions).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "gpmi_internal.h"
+
+namespace {
+
+thread_local std::string g_create_err;
+
+#define HIPCHK(ctx, expr)                                                                   \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                      \
+      return (e__ == hipErrorOutOfMemory) ? GPMI_ERR_NOMEM : GPMI_ERR_HIP;                  \
+    }                                                                                       \
+  } while (0)
+
+#define ARGCHK(ctx, cond, msg) \
+  do {                         \
+    if (!(cond)) {             \
+      (ctx)->err = (msg);      \
+      return GPMI_ERR_ARG;     \
+    }                          \
+  } while (0)
+
+constexpr int RED_SLOTS = 8192;  // per-lane result slots for batched evaluations
+
+int lane_alloc(gpmi_ctx* c, Lane& L) {
+  HIPCHK(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+  const int64_t nt = c->np / GPMI_NB;
+  HIPCHK(c, hipMalloc(&L.A, sizeof(double) * c->np * c->ld));
+  HIPCHK(c, hipMalloc(&L.invD, sizeof(double) * nt * GPMI_NB * GPMI_NB));
+  HIPCHK(c, hipMalloc(&L.vec, sizeof(double) * 4 * c->np));
+  HIPCHK(c, hipMalloc(&L.red, sizeof(double) * 2 * RED_SLOTS));
+  HIPCHK(c, hipMalloc(&L.info, sizeof(int) * RED_SLOTS));
+  HIPCHK(c, hipHostMalloc(&L.h_red, sizeof(double) * 2 * RED_SLOTS));
+  HIPCHK(c, hipHostMalloc(&L.h_info, sizeof(int) * RED_SLOTS));
+  return GPMI_OK;
+}
+
+void lane_free(Lane& L) {
+  if (L.stream) (void)hipStreamSynchronize(L.stream);
+  if (L.A) (void)hipFree(L.A);
+  if (L.invD) (void)hipFree(L.invD);
+  if (L.vec) (void)hipFree(L.vec);
+  if (L.red) (void)hipFree(L.red);
+  if (L.info) (void)hipFree(L.info);
+  if (L.h_red) (void)hipHostFree(L.h_red);
+  if (L.h_info) (void)hipHostFree(L.h_info);
+  if (L.stream) (void)hipStreamDestroy(L.stream);
+  L = Lane();
+}
+
+int ensure_lanes(gpmi_ctx* c, size_t count) {
+  while (c->lanes.size() < count) {
+    c->lanes.emplace_back();
+    int rc = lane_alloc(c, c->lanes.back());
+    if (rc != GPMI_OK) {
+      lane_free(c->lanes.back());
+      c->lanes.pop_back();
+      return rc;
+    }
+  }
+  return GPMI_OK;
+}
+
+void free_data(gpmi_ctx* c) {
+  for (auto& L : c->lanes) lane_free(L);
+  c->lanes.clear();
+  auto fr = [](double*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  };
+  fr(c->x);
+  fr(c->y);
+  fr(c->noise);
+  fr(c->ycov);
+  fr(c->alpha);
+  fr(c->Q);
+  fr(c->Q2);
+  fr(c->pts);
+  fr(c->pvec);
+  c->mq_cap = 0;
+  c->fitted = false;
+  c->n = c->d = c->np = c->ld = 0;
+}
+
+int make_params(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra,
+                KParams& p) {
+  ARGCHK(c, c->n > 0, "gpmi_set_data has not been called");
+  ARGCHK(c, kernel == GPMI_KERNEL_SE || kernel == GPMI_KERNEL_RQ, "unknown kernel id");
+  const int off = (kernel == GPMI_KERNEL_SE) ? 1 : 2;
+  ARGCHK(c, n_theta == c->d + off, "n_theta does not match the kernel and the data dimension");
+  ARGCHK(c, theta != nullptr, "theta is NULL");
+  std::memset(&p, 0, sizeof(p));
+  p.kernel = kernel;
+  p.d = (int)c->d;
+  const double a = std::exp(theta[0]);
+  p.a2 = a * a;                                             // (a**2), covariance.py:255
+  p.kappa = (kernel == GPMI_KERNEL_RQ) ? std::exp(theta[1]) : 1.0;
+  p.extra_diag = extra;
+  for (int k = 0; k < p.d; ++k) {
+    const double l = std::exp(theta[off + k]);
+    p.inv_l2[k] = 1.0 / (l * l);
+  }
+  return GPMI_OK;
+}
+
+int set_device(gpmi_ctx* c) {
+  HIPCHK(c, hipSetDevice(c->device));
+  return GPMI_OK;
+}
+
+// K(theta) + sig into lane.A (lower tiles), factorise, forward-solve the residual, reduce.
+// Leaves: lane.A = L, lane.invD, vec[0:np] = v = L^-1 (y - mu), red[2*slot..] = {v.v, sum ln L_ii},
+// info[slot].  `mu_dev` may be null (then mu_const is used).
+int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const double* mu_dev,
+                               double mu_const, int slot) {
+  hipStream_t s = L.stream;
+  HIPCHK(c, hipMemsetAsync(L.info + slot, 0, sizeof(int), s));
+  {
+    ProfScope ps(c, s, GPMI_PROF_KBUILD, 0.0, 4.0 * c->np * c->np);
+    launch_kbuild_square(s, p, c->x, c->n, c->np, c->noise, L.A, c->ld, true);
+  }
+  if (c->ycov) launch_add_full(s, L.A, c->ld, c->ycov, c->n);
+  potrf_lower(c, s, L.A, c->np, c->ld, L.invD, L.info + slot);
+  launch_residual(s, c->y, mu_dev, mu_const, L.vec, c->n, c->np);
+  trsv_forward(c, s, L.A, c->np, c->ld, L.invD, L.vec);
+  launch_lml_reduce(s, L.vec, L.A, c->ld, c->np, L.red + 2 * slot);
+  HIPCHK(c, hipGetLastError());
+  return GPMI_OK;
+}
+
+int ensure_query_ws(gpmi_ctx* c, int64_t mp) {
+  if (mp <= c->mq_cap) return GPMI_OK;
+  auto fr = [](double*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  };
+  fr(c->Q);
+  fr(c->Q2);
+  fr(c->pts);
+  fr(c->pvec);
+  c->mq_cap = 0;
+  HIPCHK(c, hipMalloc(&c->Q, sizeof(double) * mp * c->ld));
+  HIPCHK(c, hipMalloc(&c->pts, sizeof(double) * mp * c->d));
+  HIPCHK(c, hipMalloc(&c->pvec, sizeof(double) * mp * (2 + 2 * c->d)));
+  c->mq_cap = mp;
+  return GPMI_OK;
+}
+
+}  // namespace
+
+// ---- instrumentation scope ----------------------------------------------------------
+ProfScope::ProfScope(gpmi_ctx* ctx, hipStream_t st, int klass, double flops, double bytes)
+    : c(ctx), s(st), slot(nullptr) {
+  if (!c->prof) return;
+  if (c->prof_used == c->prof_slots.size()) {
+    ProfSlot ns{};
+    if (hipEventCreate(&ns.e0) != hipSuccess || hipEventCreate(&ns.e1) != hipSuccess) return;
+    c->prof_slots.push_back(ns);
+  }
+  slot = &c->prof_slots[c->prof_used++];
+  slot->klass = klass;
+  slot->flops = flops;
+  slot->bytes = bytes;
+  (void)hipEventRecord(slot->e0, s);
+}
+ProfScope::~ProfScope() {
+  if (slot) (void)hipEventRecord(slot->e1, s);
+}
+
+extern "C" {
+
+int gpmi_version(void) { return GPMI_VERSION; }
+
+int gpmi_device_count(int* count) {
+  if (!count) return GPMI_ERR_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    *count = 0;
+    return GPMI_ERR_NODEVICE;
+  }
+  *count = n;
+  return GPMI_OK;
+}
+
+int gpmi_create(int device, gpmi_ctx** out) {
+  if (!out) return GPMI_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    g_create_err = "no HIP device visible";
+    return GPMI_ERR_NODEVICE;
+  }
+  if (device < 0 || device >= n) {
+    g_create_err = "device index out of range";
+    return GPMI_ERR_ARG;
+  }
+  gpmi_ctx* c = new gpmi_ctx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipEventCreate(&c->t0) != hipSuccess ||
+      hipEventCreate(&c->t1) != hipSuccess) {
+    g_create_err = "cannot initialise the device";
+    delete c;
+    return GPMI_ERR_HIP;
+  }
+  *out = c;
+  return GPMI_OK;
+}
+
+int gpmi_destroy(gpmi_ctx* c) {
+  if (!c) return GPMI_OK;
+  (void)hipSetDevice(c->device);
+  free_data(c);
+  for (auto& sl : c->prof_slots) {
+    (void)hipEventDestroy(sl.e0);
+    (void)hipEventDestroy(sl.e1);
+  }
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->t0) (void)hipEventDestroy(c->t0);
+  if (c->t1) (void)hipEventDestroy(c->t1);
+  delete c;
+  return GPMI_OK;
+}
+
+const char* gpmi_last_error(const gpmi_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int gpmi_sync(gpmi_ctx* c) {
+  if (!c) return GPMI_ERR_ARG;
+  if (set_device(c)) return GPMI_ERR_HIP;
+  for (auto& L : c->lanes) HIPCHK(c, hipStreamSynchronize(L.stream));
+  return GPMI_OK;
+}
+
+int gpmi_set_data(gpmi_ctx* c, const double* x, const double* y, const double* noise_var,
+                  const double* y_cov, int64_t n, int64_t d) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, x && y && n > 0 && d > 0, "x, y must be non-NULL and n, d positive");
+  ARGCHK(c, d <= GPMI_MAX_D, "more spatial dimensions than GPMI_MAX_D (64)");
+  if (int rc = set_device(c)) return rc;
+  free_data(c);
+  c->n = n;
+  c->d = d;
+  c->np = round_up(n, GPMI_NB);
+  c->ld = c->np + 32;  // keep rows 256-byte aligned but off a power-of-two pitch
+  HIPCHK(c, hipMalloc(&c->x, sizeof(double) * c->np * d));
+  HIPCHK(c, hipMalloc(&c->y, sizeof(double) * c->np));
+  HIPCHK(c, hipMalloc(&c->noise, sizeof(double) * c->np));
+  HIPCHK(c, hipMalloc(&c->alpha, sizeof(double) * c->np));
+  HIPCHK(c, hipMemset(c->x, 0, sizeof(double) * c->np * d));
+  HIPCHK(c, hipMemset(c->y, 0, sizeof(double) * c->np));
+  HIPCHK(c, hipMemset(c->noise, 0, sizeof(double) * c->np));
+  HIPCHK(c, hipMemcpy(c->x, x, sizeof(double) * n * d, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->y, y, sizeof(double) * n, hipMemcpyHostToDevice));
+  if (y_cov) {
+    HIPCHK(c, hipMalloc(&c->ycov, sizeof(double) * n * n));
+    HIPCHK(c, hipMemcpy(c->ycov, y_cov, sizeof(double) * n * n, hipMemcpyHostToDevice));
+  } else if (noise_var) {
+    HIPCHK(c, hipMemcpy(c->noise, noise_var, sizeof(double) * n, hipMemcpyHostToDevice));
+  }
+  return ensure_lanes(c, 1);
+}
+
+int gpmi_set_streams(gpmi_ctx* c, int n_streams) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->n > 0, "gpmi_set_data has not been called");
+  ARGCHK(c, n_streams >= 1 && n_streams <= 256, "n_streams out of range");
+  if (int rc = set_device(c)) return rc;
+  while ((int)c->lanes.size() > 1 + n_streams) {
+    lane_free(c->lanes.back());
+    c->lanes.pop_back();
+  }
+  return ensure_lanes(c, 1 + (size_t)n_streams);
+}
+
+int gpmi_fit(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,
+             const double* mu, double* alpha_out, double* logdet_out, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  KParams p;
+  if (int rc = make_params(c, kernel, theta, n_theta, extra_diag, p)) return rc;
+  ARGCHK(c, mu != nullptr, "mu is NULL");
+  if (int rc = set_device(c)) return rc;
+  Lane& L = c->lanes[0];
+  hipStream_t s = L.stream;
+  double* mu_dev = L.vec + 3 * c->np;
+  HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
+  if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
+  // alpha = L^-T v
+  HIPCHK(c, hipMemcpyAsync(c->alpha, L.vec, sizeof(double) * c->np, hipMemcpyDeviceToDevice, s));
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, c->alpha);
+  HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (alpha_out)
+    HIPCHK(c, hipMemcpyAsync(alpha_out, c->alpha, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  if (logdet_out) *logdet_out = L.h_red[1];
+  if (info) *info = L.h_info[0];
+  c->fit_params = p;
+  c->fitted = (L.h_info[0] == 0);
+  return GPMI_OK;
+}
+
+int gpmi_lml(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,
+             const double* mu, double* lml, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, mu != nullptr && lml != nullptr, "mu / lml is NULL");
+  int inf = 0;
+  int rc = gpmi_lml_batch(c, kernel, 1, theta, n_theta, &extra_diag, mu, nullptr, lml, &inf);
+  if (info) *info = inf;
+  return rc;
+}
+
+int gpmi_lml_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int n_theta,
+                   const double* extra, const double* mus, const double* mu_const, double* lml,
+                   int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, T >= 1 && T <= RED_SLOTS, "T out of range");
+  ARGCHK(c, thetas && lml, "thetas / lml is NULL");
+  ARGCHK(c, mus || mu_const, "one of mus / mu_const is required");
+  if (int rc = set_device(c)) return rc;
+  if (c->lanes.size() < 2)
+    if (int rc = ensure_lanes(c, 2)) return rc;
+  const int S = (int)c->lanes.size() - 1;
+  std::vector<KParams> ps((size_t)T);
+  for (int64_t t = 0; t < T; ++t)
+    if (int rc = make_params(c, kernel, thetas + t * n_theta, n_theta, extra ? extra[t] : 0.0,
+                             ps[(size_t)t]))
+      return rc;
+  std::vector<int> slot_of((size_t)T);
+  std::vector<int> used((size_t)S, 0);
+  for (int64_t t = 0; t < T; ++t) {
+    const int li = (int)(t % S);
+    Lane& L = c->lanes[1 + li];
+    const int slot = used[li]++;
+    slot_of[(size_t)t] = slot;
+    double* mu_dev = nullptr;
+    if (mus) {
+      mu_dev = L.vec + 3 * c->np;
+      HIPCHK(c, hipMemcpyAsync(mu_dev, mus + t * c->n, sizeof(double) * c->n,
+                               hipMemcpyHostToDevice, L.stream));
+    }
+    if (int rc = enqueue_factor_and_forward(c, L, ps[(size_t)t], mu_dev,
+                                            mu_const ? mu_const[t] : 0.0, slot))
+      return rc;
+  }
+  for (int li = 0; li < S; ++li) {
+    if (!used[li]) continue;
+    Lane& L = c->lanes[1 + li];
+    HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double) * used[li], hipMemcpyDeviceToHost,
+                             L.stream));
+    HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int) * used[li], hipMemcpyDeviceToHost,
+                             L.stream));
+  }
+  for (int li = 0; li < S; ++li)
+    if (used[li]) HIPCHK(c, hipStreamSynchronize(c->lanes[1 + li].stream));
+  for (int64_t t = 0; t < T; ++t) {
+    Lane& L = c->lanes[1 + (int)(t % S)];
+    const int slot = slot_of[(size_t)t];
+    const int inf = L.h_info[slot];
+    // -1/2 v.v - sum ln L_ii (regression.py:539); sentinel on failure (regression.py:540-542)
+    lml[t] = (inf == 0) ? (-0.5 * L.h_red[2 * slot] - L.h_red[2 * slot + 1]) : -1e50;
+    if (info) info[t] = inf;
+  }
+  return GPMI_OK;
+}
+
+int gpmi_lml_grad(gpmi_ctx* c, int, const double*, int, double, const double*, double*, double*,
+                  double*, double*, int*) {
+  if (!c) return GPMI_ERR_ARG;
+  c->err = "gpmi_lml_grad: not implemented yet";
+  return GPMI_ERR_ARG;
+}
+
+int gpmi_predict(gpmi_ctx* c, const double* pts, int64_t m, double* mu_out, double* var_out) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->fitted, "gpmi_predict needs a successful gpmi_fit");
+  ARGCHK(c, pts && m > 0, "pts is NULL or m <= 0");
+  if (int rc = set_device(c)) return rc;
+  Lane& L = c->lanes[0];
+  hipStream_t s = L.stream;
+  const int64_t chunk = 2048;
+  KParams p = c->fit_params;
+  for (int64_t m0 = 0; m0 < m; m0 += chunk) {
+    const int64_t mc = (m - m0 < chunk) ? m - m0 : chunk;
+    const int64_t mp = round_up(mc, GPMI_NB);
+    if (int rc = ensure_query_ws(c, mp)) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->pts, pts + m0 * c->d, sizeof(double) * mc * c->d,
+                             hipMemcpyHostToDevice, s));
+    {
+      ProfScope ps(c, s, GPMI_PROF_KBUILD, 0.0, 8.0 * mp * c->np);
+      launch_kbuild_cross(s, p, c->pts, mc, mp, c->x, c->n, c->np, c->Q, c->ld);
+    }
+    double* mu_dev = c->pvec;
+    double* var_dev = c->pvec + mp;
+    if (mu_out) launch_rows_dot(s, c->Q, c->ld, mp, c->np, c->alpha, mu_dev);
+    if (var_out) {
+      trsm_rows_forward(c, s, L.A, c->np, c->ld, L.invD, c->Q, mp);
+      launch_rows_sumsq(s, c->Q, c->ld, mp, c->np, p.a2, var_dev);  // K_qq[0,0] = a^2 (regression.py:210)
+    }
+    HIPCHK(c, hipGetLastError());
+    if (mu_out)
+      HIPCHK(c, hipMemcpyAsync(mu_out + m0, mu_dev, sizeof(double) * mc, hipMemcpyDeviceToHost, s));
+    if (var_out)
+      HIPCHK(c, hipMemcpyAsync(var_out + m0, var_dev, sizeof(double) * mc, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+  }
+  return GPMI_OK;
+}
+
+int gpmi_posterior(gpmi_ctx* c, const double* pts, int64_t m, double* mu_out, double* cov_out) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->fitted, "gpmi_posterior needs a successful gpmi_fit");
+  ARGCHK(c, pts && m > 0, "pts is NULL or m <= 0");
+  if (int rc = set_device(c)) return rc;
+  Lane& L = c->lanes[0];
+  hipStream_t s = L.stream;
+  KParams p = c->fit_params;
+  const int64_t mp = round_up(m, GPMI_NB);
+  if (int rc = ensure_query_ws(c, mp)) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->pts, pts, sizeof(double) * m * c->d, hipMemcpyHostToDevice, s));
+  launch_kbuild_cross(s, p, c->pts, m, mp, c->x, c->n, c->np, c->Q, c->ld);
+  double* mu_dev = c->pvec;
+  launch_rows_dot(s, c->Q, c->ld, mp, c->np, c->alpha, mu_dev);
+  if (mu_out) HIPCHK(c, hipMemcpyAsync(mu_out, mu_dev, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+  if (cov_out) {
+    double* Kqq = nullptr;
+    const int64_t ldq = mp + 32;
+    HIPCHK(c, hipMalloc(&Kqq, sizeof(double) * mp * ldq));
+    trsm_rows_forward(c, s, L.A, c->np, c->ld, L.invD, c->Q, mp);
+    launch_kbuild_cross(s, p, c->pts, m, mp, c->pts, m, mp, Kqq, ldq);  // no jitter (regression.py:441)
+    // Sigma = K_qq - Q^T Q with Q = L^-1 K_qx^T, i.e. rows of c->Q dotted pairwise
+    launch_gemm_nt(s, TILES_RECT, OP_SUB, Kqq, ldq, c->Q, c->ld, c->Q, c->ld, (int)(mp / GPMI_NB),
+                   (int)(mp / GPMI_NB), (int)c->np);
+    hipError_t e = hipMemcpy2DAsync(cov_out, sizeof(double) * m, Kqq, sizeof(double) * ldq,
+                                    sizeof(double) * m, m, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(Kqq);
+    HIPCHK(c, e);
+  }
+  HIPCHK(c, hipStreamSynchronize(s));
+  return GPMI_OK;
+}
+
+int gpmi_spatial_derivatives(gpmi_ctx* c, const double*, int64_t, double*, double*) {
+  if (!c) return GPMI_ERR_ARG;
+  c->err = "gpmi_spatial_derivatives: not implemented yet";
+  return GPMI_ERR_ARG;
+}
+
+int gpmi_gradient(gpmi_ctx* c, const double*, int64_t, double*, double*) {
+  if (!c) return GPMI_ERR_ARG;
+  c->err = "gpmi_gradient: not implemented yet";
+  return GPMI_ERR_ARG;
+}
+
+int gpmi_loo_diag(gpmi_ctx* c, double*) {
+  if (!c) return GPMI_ERR_ARG;
+  c->err = "gpmi_loo_diag: not implemented yet";
+  return GPMI_ERR_ARG;
+}
+
+int gpmi_covariance(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,
+                    int with_noise, double* K_host) {
+  if (!c) return GPMI_ERR_ARG;
+  KParams p;
+  if (int rc = make_params(c, kernel, theta, n_theta, extra_diag, p)) return rc;
+  ARGCHK(c, K_host != nullptr, "K_host is NULL");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = ensure_lanes(c, 2)) return rc;
+  Lane& L = c->lanes[1];
+  double* noise = c->noise;
+  double* zeros = nullptr;
+  if (!with_noise) {
+    HIPCHK(c, hipMalloc(&zeros, sizeof(double) * c->np));
+    HIPCHK(c, hipMemsetAsync(zeros, 0, sizeof(double) * c->np, L.stream));
+    noise = zeros;
+  }
+  launch_kbuild_square(L.stream, p, c->x, c->n, c->np, noise, L.A, c->ld, false);
+  if (with_noise && c->ycov) launch_add_full(L.stream, L.A, c->ld, c->ycov, c->n);
+  hipError_t e = hipMemcpy2DAsync(K_host, sizeof(double) * c->n, L.A, sizeof(double) * c->ld,
+                                  sizeof(double) * c->n, c->n, hipMemcpyDeviceToHost, L.stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(L.stream);
+  if (zeros) (void)hipFree(zeros);
+  HIPCHK(c, e);
+  return GPMI_OK;
+}
+
+int gpmi_cross_covariance(gpmi_ctx* c, int kernel, const double* theta, int n_theta,
+                          const double* pts, int64_t m, double* out) {
+  if (!c) return GPMI_ERR_ARG;
+  KParams p;
+  if (int rc = make_params(c, kernel, theta, n_theta, 0.0, p)) return rc;
+  ARGCHK(c, pts && out && m > 0, "pts / out is NULL or m <= 0");
+  if (int rc = set_device(c)) return rc;
+  hipStream_t s = c->lanes[0].stream;
+  const int64_t chunk = 2048;
+  for (int64_t m0 = 0; m0 < m; m0 += chunk) {
+    const int64_t mc = (m - m0 < chunk) ? m - m0 : chunk;
+    const int64_t mp = round_up(mc, GPMI_NB);
+    if (int rc = ensure_query_ws(c, mp)) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->pts, pts + m0 * c->d, sizeof(double) * mc * c->d,
+                             hipMemcpyHostToDevice, s));
+    launch_kbuild_cross(s, p, c->pts, mc, mp, c->x, c->n, c->np, c->Q, c->ld);
+    HIPCHK(c, hipMemcpy2DAsync(out + m0 * c->n, sizeof(double) * c->n, c->Q, sizeof(double) * c->ld,
+                               sizeof(double) * c->n, mc, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+  }
+  return GPMI_OK;
+}
+
+int gpmi_get_K(gpmi_ctx* c, double* K_host) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->fitted && K_host, "gpmi_get_K needs a successful gpmi_fit");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = ensure_lanes(c, 2)) return rc;
+  Lane& L = c->lanes[1];
+  launch_kbuild_square(L.stream, c->fit_params, c->x, c->n, c->np, c->noise, L.A, c->ld, false);
+  if (c->ycov) launch_add_full(L.stream, L.A, c->ld, c->ycov, c->n);
+  HIPCHK(c, hipMemcpy2DAsync(K_host, sizeof(double) * c->n, L.A, sizeof(double) * c->ld,
+                             sizeof(double) * c->n, c->n, hipMemcpyDeviceToHost, L.stream));
+  HIPCHK(c, hipStreamSynchronize(L.stream));
+  return GPMI_OK;
+}
+
+int gpmi_get_L(gpmi_ctx* c, double* L_host) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->fitted && L_host, "gpmi_get_L needs a successful gpmi_fit");
+  if (int rc = set_device(c)) return rc;
+  Lane& L = c->lanes[0];
+  HIPCHK(c, hipMemcpy2DAsync(L_host, sizeof(double) * c->n, L.A, sizeof(double) * c->ld,
+                             sizeof(double) * c->n, c->n, hipMemcpyDeviceToHost, L.stream));
+  HIPCHK(c, hipStreamSynchronize(L.stream));
+  for (int64_t i = 0; i < c->n; ++i)
+    for (int64_t j = i + 1; j < c->n; ++j) L_host[i * c->n + j] = 0.0;  // numpy returns the upper triangle zeroed
+  return GPMI_OK;
+}
+
+// ---- instrumentation ------------------------------------------------------------------
+int gpmi_timer_start(gpmi_ctx* c) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, !c->lanes.empty(), "gpmi_set_data has not been called");
+  if (int rc = gpmi_sync(c)) return rc;
+  HIPCHK(c, hipEventRecord(c->t0, c->lanes[0].stream));
+  return GPMI_OK;
+}
+
+int gpmi_timer_stop(gpmi_ctx* c, float* ms) {
+  if (!c || !ms) return GPMI_ERR_ARG;
+  ARGCHK(c, !c->lanes.empty(), "gpmi_set_data has not been called");
+  if (int rc = set_device(c)) return rc;
+  // the stop event is recorded on lane 0 after every other lane has drained into it
+  for (size_t i = 1; i < c->lanes.size(); ++i) {
+    hipEvent_t ev;
+    HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(ev, c->lanes[i].stream));
+    HIPCHK(c, hipStreamWaitEvent(c->lanes[0].stream, ev, 0));
+    HIPCHK(c, hipEventDestroy(ev));
+  }
+  HIPCHK(c, hipEventRecord(c->t1, c->lanes[0].stream));
+  HIPCHK(c, hipEventSynchronize(c->t1));
+  HIPCHK(c, hipEventElapsedTime(ms, c->t0, c->t1));
+  return GPMI_OK;
+}
+
+int gpmi_profile_enable(gpmi_ctx* c, int on) {
+  if (!c) return GPMI_ERR_ARG;
+  c->prof = on != 0;
+  return GPMI_OK;
+}
+
+static int profile_collect(gpmi_ctx* c) {
+  if (int rc = gpmi_sync(c)) return rc;
+  for (size_t i = 0; i < c->prof_used; ++i) {
+    ProfSlot& sl = c->prof_slots[i];
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, sl.e0, sl.e1) != hipSuccess) continue;
+    c->prof_ms[sl.klass] += ms;
+    c->prof_flops[sl.klass] += sl.flops;
+    c->prof_bytes[sl.klass] += sl.bytes;
+    c->prof_launches[sl.klass] += 1;
+  }
+  c->prof_used = 0;
+  return GPMI_OK;
+}
+
+int gpmi_profile_read(gpmi_ctx* c, int klass, int64_t* launches, double* ms, double* flops,
+                      double* bytes) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, klass >= 0 && klass < GPMI_PROF_NCLASS, "bad profile class");
+  if (int rc = profile_collect(c)) return rc;
+  if (launches) *launches = c->prof_launches[klass];
+  if (ms) *ms = c->prof_ms[klass];
+  if (flops) *flops = c->prof_flops[klass];
+  if (bytes) *bytes = c->prof_bytes[klass];
+  return GPMI_OK;
+}
+
+int gpmi_profile_reset(gpmi_ctx* c) {
+  if (!c) return GPMI_ERR_ARG;
+  if (int rc = profile_collect(c)) return rc;
+  for (int k = 0; k < GPMI_PROF_NCLASS; ++k) {
+    c->prof_ms[k] = c->prof_flops[k] = c->prof_bytes[k] = 0.0;
+    c->prof_launches[k] = 0;
+  }
+  return GPMI_OK;
+}
+
+// ---- device-pointer entry points ---------------------------------------------------------
+int gpmi_dev_alloc(gpmi_ctx* c, int64_t bytes, void** ptr) {
+  if (!c || !ptr) return GPMI_ERR_ARG;
+  if (int rc = set_device(c)) return rc;
+  HIPCHK(c, hipMalloc(ptr, (size_t)bytes));
+  return GPMI_OK;
+}
+int gpmi_dev_free(gpmi_ctx* c, void* ptr) {
+  if (!c) return GPMI_ERR_ARG;
+  if (int rc = set_device(c)) return rc;
+  HIPCHK(c, hipFree(ptr));
+  return GPMI_OK;
+}
+int gpmi_dev_upload(gpmi_ctx* c, void* dst, const void* src, int64_t bytes) {
+  if (!c) return GPMI_ERR_ARG;
+  if (int rc = set_device(c)) return rc;
+  HIPCHK(c, hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+  return GPMI_OK;
+}
+int gpmi_dev_download(gpmi_ctx* c, void* dst, const void* src, int64_t bytes) {
+  if (!c) return GPMI_ERR_ARG;
+  if (int rc = set_device(c)) return rc;
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+  return GPMI_OK;
+}
+
+static int dev_stream(gpmi_ctx* c, hipStream_t* s) {
+  if (c->lanes.empty()) {
+    // a bare handle (no data yet): give it a stream-only lane
+    c->lanes.emplace_back();
+    HIPCHK(c, hipStreamCreateWithFlags(&c->lanes[0].stream, hipStreamNonBlocking));
+  }
+  *s = c->lanes[0].stream;
+  return GPMI_OK;
+}
+
+int gpmi_dev_potrf(gpmi_ctx* c, double* A, int64_t n, int64_t ld, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, A && n > 0 && n % GPMI_NB == 0 && ld >= n && ld % 2 == 0, "bad matrix shape");
+  if (int rc = set_device(c)) return rc;
+  hipStream_t s;
+  if (int rc = dev_stream(c, &s)) return rc;
+  double* invD = nullptr;
+  int* dinfo = nullptr;
+  HIPCHK(c, hipMalloc(&invD, sizeof(double) * (n / GPMI_NB) * GPMI_NB * GPMI_NB));
+  HIPCHK(c, hipMalloc(&dinfo, sizeof(int)));
+  HIPCHK(c, hipMemsetAsync(dinfo, 0, sizeof(int), s));
+  potrf_lower(c, s, A, n, ld, invD, dinfo);
+  int h = 0;
+  hipError_t e = hipMemcpyAsync(&h, dinfo, sizeof(int), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(invD);
+  (void)hipFree(dinfo);
+  HIPCHK(c, e);
+  if (info) *info = h;
+  return GPMI_OK;
+}
+
+int gpmi_dev_gemm_nt(gpmi_ctx* c, double* C, int64_t ldc, const double* A, int64_t lda,
+                     const double* B, int64_t ldb, int64_t m, int64_t n, int64_t k, int lower) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, m % GPMI_NB == 0 && n % GPMI_NB == 0 && k % 16 == 0 && m > 0 && n > 0 && k > 0,
+         "m, n must be multiples of 128 and k of 16");
+  if (int rc = set_device(c)) return rc;
+  hipStream_t s;
+  if (int rc = dev_stream(c, &s)) return rc;
+  {
+    const double tiles = lower ? (double)(n / GPMI_NB) * (n / GPMI_NB + 1) / 2.0 +
+                                     (double)(m / GPMI_NB - n / GPMI_NB) * (n / GPMI_NB)
+                               : (double)(m / GPMI_NB) * (n / GPMI_NB);
+    ProfScope ps(c, s, GPMI_PROF_SYRK, tiles * 2.0 * GPMI_NB * GPMI_NB * k,
+                 tiles * 16.0 * GPMI_NB * GPMI_NB);
+    launch_gemm_nt(s, lower ? TILES_LOWER : TILES_RECT, OP_SUB, C, ldc, A, lda, B, ldb,
+                   (int)(m / GPMI_NB), (int)(n / GPMI_NB), (int)k);
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(s));
+  return GPMI_OK;
+}
+
+}  // extern "C"

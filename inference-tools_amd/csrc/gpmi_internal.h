@@ -1,0 +1,135 @@
+// Internal declarations shared by the HIP translation units of libgpmi.
+// Public C-ABI: include/gpmi.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "gpmi.h"
+
+constexpr int GPMI_NB = 128;     // tile / inner block size: every device matrix dimension is a multiple
+constexpr int GPMI_MAX_D = 64;   // max spatial dimensions handled by the covariance kernels
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// Hyper-parameters of one covariance evaluation, passed by value as a kernel argument.
+struct KParams {
+  int kernel;                 // GPMI_KERNEL_SE / GPMI_KERNEL_RQ
+  int d;                      // spatial dimensions
+  double a2;                  // exp(theta0)^2
+  double kappa;               // RQ: exp(theta1)
+  double extra_diag;          // WhiteNoise variance added to the diagonal
+  double inv_l2[GPMI_MAX_D];  // 1 / l_k^2
+};
+
+struct ProfSlot {
+  hipEvent_t e0, e1;
+  int klass;
+  double flops, bytes;
+};
+
+// One independent evaluation lane: a stream with its own n x n scratch matrix and vectors.
+struct Lane {
+  hipStream_t stream = nullptr;
+  double* A = nullptr;      // np x ld scratch (K then L)
+  double* invD = nullptr;   // (np/128) x 128 x 128 inverses of the diagonal blocks
+  double* vec = nullptr;    // 4 x np work vectors
+  double* red = nullptr;    // small reduction outputs (device)
+  int* info = nullptr;      // device info word
+  double* h_red = nullptr;  // pinned host mirror of red
+  int* h_info = nullptr;    // pinned host mirror of info
+};
+
+struct gpmi_ctx {
+  int device = 0;
+  std::string err;
+  // data
+  int64_t n = 0, d = 0, np = 0, ld = 0;
+  double* x = nullptr;      // np x d (rows >= n are zero)
+  double* y = nullptr;      // np
+  double* noise = nullptr;  // np diagonal data variances (zero padded)
+  double* ycov = nullptr;   // n x n dense y covariance or nullptr
+  // fitted state lives in lanes[0]
+  std::vector<Lane> lanes;
+  bool fitted = false;
+  KParams fit_params{};
+  double* alpha = nullptr;  // np (device) — fitted alpha
+  // prediction workspace
+  double* Q = nullptr;      // mq_cap x ld
+  double* Q2 = nullptr;     // second panel (spatial derivatives)
+  int64_t mq_cap = 0;
+  double* pts = nullptr;    // mq_cap x d
+  double* pvec = nullptr;   // vectors of length mq_cap * (2 + 2 d)
+  // host staging (pinned)
+  double* h_stage = nullptr;
+  int64_t h_stage_bytes = 0;
+  // instrumentation
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  bool prof = false;
+  std::vector<ProfSlot> prof_slots;
+  size_t prof_used = 0;
+  double prof_ms[GPMI_PROF_NCLASS] = {0, 0, 0, 0};
+  double prof_flops[GPMI_PROF_NCLASS] = {0, 0, 0, 0};
+  double prof_bytes[GPMI_PROF_NCLASS] = {0, 0, 0, 0};
+  int64_t prof_launches[GPMI_PROF_NCLASS] = {0, 0, 0, 0};
+};
+
+// instrumentation helpers (api.hip)
+struct ProfScope {
+  gpmi_ctx* c;
+  hipStream_t s;
+  ProfSlot* slot;
+  ProfScope(gpmi_ctx* ctx, hipStream_t st, int klass, double flops, double bytes);
+  ~ProfScope();
+};
+
+// ---- kernel launchers -------------------------------------------------------------
+// kbuild.hip
+// square covariance of the np x np padded problem (identity in the padding), lower tiles only if lower_only
+void launch_kbuild_square(hipStream_t s, const KParams& p, const double* x, int64_t n, int64_t np,
+                          const double* noise, double* A, int64_t ld, bool lower_only);
+// cross covariance U (mp x d, mu valid rows) vs V (np x d, n valid rows): out mp x ld, zeros in padding
+void launch_kbuild_cross(hipStream_t s, const KParams& p, const double* U, int64_t mu, int64_t mp,
+                         const double* V, int64_t n, int64_t np, double* out, int64_t ld);
+void launch_add_full(hipStream_t s, double* A, int64_t ld, const double* Y, int64_t n);
+
+// gemm_f64.hip  (all dims multiples of 128, k multiple of 16)
+enum GemmTiles { TILES_RECT = 0, TILES_LOWER = 1 };
+enum GemmOp { OP_SUB = 0, OP_ASSIGN = 1 };
+// C(ntr*128 x ntc*128) op= A(rows x k) * B(cols x k)^T ; TILES_LOWER visits tiles ti >= tj only
+void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc,
+                    const double* A, int64_t lda, const double* B, int64_t ldb, int ntr, int ntc,
+                    int k);
+
+// potrf.hip
+void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0);
+// blocked right-looking Cholesky, in place, lower; invD receives the inverses of the diagonal blocks
+void potrf_lower(gpmi_ctx* c, hipStream_t s, double* A, int64_t np, int64_t ld, double* invD,
+                 int* info);
+
+// solve.hip
+// forward substitution  L v = r  (in place on r), single right-hand side
+void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
+                  const double* invD, double* r);
+// backward substitution  L^T a = v  (in place)
+void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
+                   const double* invD, double* r);
+// Q (mp x np, row-major, ld) <- Q L^-T   (forward solve of mp right-hand sides stored as rows)
+void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
+                       const double* invD, double* Q, int64_t mp);
+// r = y - mu (padded with zeros)
+void launch_residual(hipStream_t s, const double* y, const double* mu, double mu_const, double* r,
+                     int64_t n, int64_t np);
+// red[0] = sum v^2, red[1] = sum log diag(L)
+void launch_lml_reduce(hipStream_t s, const double* v, const double* L, int64_t ld, int64_t np,
+                       double* red);
+// out[m] = sum_n Q[m][n] * a[n]
+void launch_rows_dot(hipStream_t s, const double* Q, int64_t ld, int64_t mp, int64_t np,
+                     const double* a, double* out);
+// out[m] = base - sum_n Q[m][n]^2
+void launch_rows_sumsq(hipStream_t s, const double* Q, int64_t ld, int64_t mp, int64_t np,
+                       double base, double* out);

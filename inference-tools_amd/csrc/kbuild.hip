@@ -1,0 +1,117 @@
+// Covariance-matrix build for SquaredExponential / RationalQuadratic on gfx950.
+//
+// Replaces the reference's N x N x d broadcast tensors (covariance.py:218-219, 254, 315-316, 347)
+// by a tiled kernel: a workgroup stages the two 64-point panels in LDS (transposed, [dim][point]) and
+// every thread produces a 4 x 4 block of K, written as 32-byte row segments (16 threads -> 512
+// contiguous bytes per row).  HBM-write bound: 8 bytes per element, x is read once per tile from L2.
+#include "gpmi_internal.h"
+
+namespace {
+
+constexpr int KT = 64;  // output tile edge
+
+__device__ inline double kfun(const KParams& p, double s) {
+  // s = sum_k 0.5 * dx_k^2 / l_k^2  (>= 0)
+  if (p.kernel == GPMI_KERNEL_SE) return exp(-s);              // covariance.py:254
+  return pow(1.0 + s / p.kappa, -p.kappa);                      // covariance.py:348
+}
+
+// SQUARE: U == V, jitter + noise on the diagonal, identity in the padding (rows/cols >= n).
+template <bool SQUARE>
+__global__ __launch_bounds__(256) void kbuild_kernel(KParams p, const double* __restrict__ U,
+                                                     int64_t nu, const double* __restrict__ V,
+                                                     int64_t nv, const double* __restrict__ noise,
+                                                     double* __restrict__ out, int64_t ld,
+                                                     int lower_only) {
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (SQUARE && lower_only && tj > ti) return;
+  __shared__ double su[GPMI_MAX_D * KT];
+  __shared__ double sv[GPMI_MAX_D * KT];
+  const int tid = threadIdx.x;
+  const int d = p.d;
+  const int64_t i0 = (int64_t)ti * KT, j0 = (int64_t)tj * KT;
+  // stage panels transposed: s[k][pt]
+  for (int idx = tid; idx < KT * d; idx += 256) {
+    int pt = idx / d, k = idx - pt * d;
+    int64_t gi = i0 + pt, gj = j0 + pt;
+    su[k * KT + pt] = (gi < nu) ? U[gi * d + k] : 0.0;
+    sv[k * KT + pt] = (gj < nv) ? V[gj * d + k] : 0.0;
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  double s[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[r][c] = 0.0;
+  for (int k = 0; k < d; ++k) {
+    const double il2 = p.inv_l2[k];
+    double ur[4], vc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ur[r] = su[k * KT + ty * 4 + r];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vc[c] = sv[k * KT + tx * 4 + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double dx = ur[r] - vc[c];
+        s[r][c] = fma(0.5 * dx * dx, il2, s[r][c]);  // distances_k / l_k^2 accumulated (covariance.py:254)
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t gi = i0 + ty * 4 + r;
+    double v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int64_t gj = j0 + tx * 4 + c;
+      double val;
+      if (gi < nu && gj < nv) {
+        double cfun = kfun(p, s[r][c]);
+        if (SQUARE && gi == gj) {
+          // a^2 (C + 1e-12) + WhiteNoise + sig   (covariance.py:254-255, 163-169; regression.py:239)
+          val = p.a2 * (cfun + 1e-12);
+          val += p.extra_diag;
+          val += noise[gi];
+        } else {
+          val = p.a2 * cfun;
+        }
+      } else {
+        val = (SQUARE && gi == gj) ? 1.0 : 0.0;  // padding: identity keeps the factorisation trivial
+      }
+      v[c] = val;
+    }
+    double* dst = out + gi * ld + j0 + tx * 4;
+    *reinterpret_cast<d2_t*>(dst) = d2_t{v[0], v[1]};
+    *reinterpret_cast<d2_t*>(dst + 2) = d2_t{v[2], v[3]};
+  }
+}
+
+__global__ void add_full_kernel(double* __restrict__ A, int64_t ld, const double* __restrict__ Y,
+                                int64_t n) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t i = blockIdx.y;
+  if (j < n) A[i * ld + j] += Y[i * n + j];
+}
+
+}  // namespace
+
+void launch_kbuild_square(hipStream_t s, const KParams& p, const double* x, int64_t n, int64_t np,
+                          const double* noise, double* A, int64_t ld, bool lower_only) {
+  dim3 grid((unsigned)(np / KT), (unsigned)(np / KT));
+  hipLaunchKernelGGL(kbuild_kernel<true>, grid, dim3(256), 0, s, p, x, n, x, n, noise, A, ld,
+                     lower_only ? 1 : 0);
+}
+
+void launch_kbuild_cross(hipStream_t s, const KParams& p, const double* U, int64_t mu, int64_t mp,
+                         const double* V, int64_t n, int64_t np, double* out, int64_t ld) {
+  dim3 grid((unsigned)(np / KT), (unsigned)(mp / KT));
+  hipLaunchKernelGGL(kbuild_kernel<false>, grid, dim3(256), 0, s, p, U, mu, V, n, nullptr, out, ld,
+                     0);
+}
+
+void launch_add_full(hipStream_t s, double* A, int64_t ld, const double* Y, int64_t n) {
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
+  hipLaunchKernelGGL(add_full_kernel, grid, dim3(256), 0, s, A, ld, Y, n);
+}

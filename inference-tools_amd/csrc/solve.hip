@@ -1,0 +1,228 @@
+// Triangular solves and reductions of the GP path (gfx950).
+//
+// Replaces scipy.linalg.solve_triangular at regression.py:213, 242-244, 410, 447, 538 and the
+// reductions of regression.py:214, 539.  All solves use the inverted 128 x 128 diagonal blocks
+// produced by potrf_diag, so every step is a matrix-vector / matrix-matrix product:
+//   single right-hand side  -> HBM-bound GEMV sweeps (L is read exactly once per solve)
+//   many right-hand sides    -> the fp64 MFMA GEMM (right-hand sides stored as rows, "NT" form)
+#include "gpmi_internal.h"
+
+namespace {
+
+constexpr int NB = GPMI_NB;
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// out[0:128] = invD (128 x 128, lower) * r[0:128]        (one workgroup, one wave per row)
+__global__ __launch_bounds__(256) void diag_apply_kernel(const double* __restrict__ invD,
+                                                         double* __restrict__ r) {
+  __shared__ double rin[NB];
+  __shared__ double rout[NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < NB) rin[tid] = r[tid];
+  __syncthreads();
+  for (int row = wave; row < NB; row += 4) {
+    double s = invD[row * NB + lane] * rin[lane] + invD[row * NB + 64 + lane] * rin[64 + lane];
+    s = wave_sum(s);
+    if (lane == 0) rout[row] = s;
+  }
+  __syncthreads();
+  if (tid < NB) r[tid] = rout[tid];
+}
+
+// out[c] = sum_i invD[i][c] * r[i]   (transposed apply, thread per column)
+__global__ __launch_bounds__(128) void diag_apply_t_kernel(const double* __restrict__ invD,
+                                                           double* __restrict__ r) {
+  __shared__ double rin[NB];
+  const int c = threadIdx.x;
+  rin[c] = r[c];
+  __syncthreads();
+  double s = 0.0;
+  for (int i = 0; i < NB; ++i) s = fma(invD[i * NB + c], rin[i], s);  // zero above the diagonal
+  r[c] = s;
+}
+
+// forward sweep: r[i] -= sum_c Lpanel[i][c] * v[c]  for `rows` rows below the block (wave per row)
+__global__ __launch_bounds__(256) void gemv_panel_kernel(const double* __restrict__ Lp, int64_t ld,
+                                                         const double* __restrict__ v,
+                                                         double* __restrict__ r, int64_t rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  const double v0 = v[lane], v1 = v[64 + lane];
+  for (int64_t row = wave; row < rows; row += nw) {
+    const double* p = Lp + row * ld;
+    double s = wave_sum(p[lane] * v0 + p[64 + lane] * v1);
+    if (lane == 0) r[row] -= s;
+  }
+}
+
+// backward sweep: r[j] -= sum_i Lrow[i][j] * a[i]  for `cols` columns left of the block (thread per column)
+__global__ __launch_bounds__(256) void gemv_rowblock_t_kernel(const double* __restrict__ Lr,
+                                                              int64_t ld,
+                                                              const double* __restrict__ a,
+                                                              double* __restrict__ r, int64_t cols) {
+  __shared__ double as[NB];
+  if (threadIdx.x < NB) as[threadIdx.x] = a[threadIdx.x];
+  __syncthreads();
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= cols) return;
+  double s = 0.0;
+#pragma unroll 8
+  for (int i = 0; i < NB; ++i) s = fma(Lr[(int64_t)i * ld + j], as[i], s);
+  r[j] -= s;
+}
+
+__global__ void residual_kernel(const double* __restrict__ y, const double* __restrict__ mu,
+                                double mu_const, double* __restrict__ r, int64_t n, int64_t np) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  r[i] = (i < n) ? y[i] - (mu ? mu[i] : mu_const) : 0.0;
+}
+
+// deterministic two-value reduction: red[0] = sum v^2, red[1] = sum ln L_ii  (fixed tree order)
+__global__ __launch_bounds__(1024) void lml_reduce_kernel(const double* __restrict__ v,
+                                                          const double* __restrict__ L, int64_t ld,
+                                                          int64_t np, double* __restrict__ red) {
+  __shared__ double s0[16], s1[16];
+  double a = 0.0, b = 0.0;
+  for (int64_t i = threadIdx.x; i < np; i += 1024) {
+    const double vi = v[i];
+    a = fma(vi, vi, a);
+    b += log(L[i * ld + i]);
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    s0[wave] = a;
+    s1[wave] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ta = 0.0, tb = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      ta += s0[w];
+      tb += s1[w];
+    }
+    red[0] = ta;
+    red[1] = tb;
+  }
+}
+
+// one wave per row: out[m] = sum_n Q[m][n] * a[n]
+__global__ __launch_bounds__(256) void rows_dot_kernel(const double* __restrict__ Q, int64_t ld,
+                                                       int64_t mp, int64_t np,
+                                                       const double* __restrict__ a,
+                                                       double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= mp) return;
+  const double* q = Q + row * ld;
+  double s = 0.0;
+  for (int64_t j = lane * 2; j < np; j += 128) {
+    const d2_t qv = *reinterpret_cast<const d2_t*>(q + j);
+    const d2_t av = *reinterpret_cast<const d2_t*>(a + j);
+    s = fma(qv[0], av[0], s);
+    s = fma(qv[1], av[1], s);
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+
+__global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restrict__ Q, int64_t ld,
+                                                         int64_t mp, int64_t np, double base,
+                                                         double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= mp) return;
+  const double* q = Q + row * ld;
+  double s = 0.0;
+  for (int64_t j = lane * 2; j < np; j += 128) {
+    const d2_t qv = *reinterpret_cast<const d2_t*>(q + j);
+    s = fma(qv[0], qv[0], s);
+    s = fma(qv[1], qv[1], s);
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = base - s;
+}
+
+}  // namespace
+
+void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
+                  const double* invD, double* r) {
+  const int nt = (int)(np / NB);
+  ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)np * np, 4.0 * np * np);
+  for (int k = 0; k < nt; ++k) {
+    hipLaunchKernelGGL(diag_apply_kernel, dim3(1), dim3(256), 0, s, invD + (int64_t)k * NB * NB,
+                       r + (int64_t)k * NB);
+    const int64_t rows = np - (int64_t)(k + 1) * NB;
+    if (rows > 0) {
+      int64_t blocks = (rows + 3) / 4;
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(gemv_panel_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                         L + (int64_t)(k + 1) * NB * ld + (int64_t)k * NB, ld, r + (int64_t)k * NB,
+                         r + (int64_t)(k + 1) * NB, rows);
+    }
+  }
+}
+
+void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
+                   const double* invD, double* r) {
+  const int nt = (int)(np / NB);
+  ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)np * np, 4.0 * np * np);
+  for (int k = nt - 1; k >= 0; --k) {
+    hipLaunchKernelGGL(diag_apply_t_kernel, dim3(1), dim3(128), 0, s, invD + (int64_t)k * NB * NB,
+                       r + (int64_t)k * NB);
+    const int64_t cols = (int64_t)k * NB;
+    if (cols > 0) {
+      hipLaunchKernelGGL(gemv_rowblock_t_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0,
+                         s, L + (int64_t)k * NB * ld, ld, r + (int64_t)k * NB, r, cols);
+    }
+  }
+}
+
+void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
+                       const double* invD, double* Q, int64_t mp) {
+  const int nt = (int)(np / NB), mt = (int)(mp / NB);
+  ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)mp * np * np, 4.0 * np * np);
+  for (int k = 0; k < nt; ++k) {
+    double* Qk = Q + (int64_t)k * NB;
+    // Q[:, k] <- Q[:, k] * invD_k^T   (in place, one tile column)
+    launch_gemm_nt(s, TILES_RECT, OP_ASSIGN, Qk, ld, Qk, ld, invD + (int64_t)k * NB * NB, NB, mt, 1,
+                   NB);
+    const int rem = nt - k - 1;
+    if (rem > 0) {
+      // Q[:, k+1:] -= Q[:, k] * L[k+1:, k]^T
+      launch_gemm_nt(s, TILES_RECT, OP_SUB, Qk + NB, ld, Qk, ld,
+                     L + (int64_t)(k + 1) * NB * ld + (int64_t)k * NB, ld, mt, rem, NB);
+    }
+  }
+}
+
+void launch_residual(hipStream_t s, const double* y, const double* mu, double mu_const, double* r,
+                     int64_t n, int64_t np) {
+  hipLaunchKernelGGL(residual_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, y, mu,
+                     mu_const, r, n, np);
+}
+
+void launch_lml_reduce(hipStream_t s, const double* v, const double* L, int64_t ld, int64_t np,
+                       double* red) {
+  hipLaunchKernelGGL(lml_reduce_kernel, dim3(1), dim3(1024), 0, s, v, L, ld, np, red);
+}
+
+void launch_rows_dot(hipStream_t s, const double* Q, int64_t ld, int64_t mp, int64_t np,
+                     const double* a, double* out) {
+  hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)((mp + 3) / 4)), dim3(256), 0, s, Q, ld, mp, np,
+                     a, out);
+}
+
+void launch_rows_sumsq(hipStream_t s, const double* Q, int64_t ld, int64_t mp, int64_t np,
+                       double base, double* out) {
+  hipLaunchKernelGGL(rows_sumsq_kernel, dim3((unsigned)((mp + 3) / 4)), dim3(256), 0, s, Q, ld, mp,
+                     np, base, out);
+}

@@ -1,0 +1,158 @@
+"""
+NumPy-facing wrapper around one gpmi handle: uploads the data once and exposes
+the device operations of the GP hot path with ndarray arguments / results.
+Used by `inference_amd.gp.regression.GpRegressor` and the covariance classes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from inference_amd import _lib
+from inference_amd._lib import as_f64, dptr
+
+
+class GpEngine:
+    def __init__(self, x, y, noise_var=None, y_cov=None, device=None):
+        self.h = _lib.Handle(device)
+        self.x = as_f64(x)
+        self.y = as_f64(y)
+        self.n, self.d = self.x.shape
+        nv = None if noise_var is None else as_f64(noise_var)
+        yc = None if y_cov is None else as_f64(y_cov)
+        self.h.call("gpmi_set_data", dptr(self.x), dptr(self.y), dptr(nv), dptr(yc), self.n, self.d)
+
+    # -- fit / likelihood -----------------------------------------------------------
+    def fit(self, kernel, theta_cov, extra_diag, mu):
+        theta = as_f64(theta_cov)
+        mu = as_f64(mu)
+        alpha = np.empty(self.n)
+        logdet = C.c_double(0.0)
+        info = C.c_int(0)
+        self.h.call("gpmi_fit", kernel, dptr(theta), theta.size, float(extra_diag), dptr(mu),
+                    dptr(alpha), C.byref(logdet), C.byref(info))
+        return alpha, logdet.value, info.value
+
+    def lml(self, kernel, theta_cov, extra_diag, mu):
+        theta = as_f64(theta_cov)
+        mu = as_f64(mu)
+        out = C.c_double(0.0)
+        info = C.c_int(0)
+        self.h.call("gpmi_lml", kernel, dptr(theta), theta.size, float(extra_diag), dptr(mu),
+                    C.byref(out), C.byref(info))
+        return out.value, info.value
+
+    def lml_batch(self, kernel, thetas_cov, extra_diag=None, mus=None, mu_const=None):
+        thetas = as_f64(thetas_cov)
+        T, nt = thetas.shape
+        ex = None if extra_diag is None else as_f64(extra_diag)
+        mus = None if mus is None else as_f64(mus)
+        mc = None if mu_const is None else as_f64(mu_const)
+        out = np.empty(T)
+        info = np.zeros(T, dtype=np.int32)
+        self.h.call("gpmi_lml_batch", kernel, T, dptr(thetas), nt, dptr(ex), dptr(mus), dptr(mc),
+                    dptr(out), info.ctypes.data_as(C.POINTER(C.c_int)))
+        return out, info
+
+    def set_streams(self, n):
+        self.h.call("gpmi_set_streams", int(n))
+
+    def lml_grad(self, kernel, theta_cov, extra_diag, mu):
+        theta = as_f64(theta_cov)
+        mu = as_f64(mu)
+        lml = C.c_double(0.0)
+        trq = C.c_double(0.0)
+        info = C.c_int(0)
+        grad = np.empty(theta.size)
+        alpha = np.empty(self.n)
+        self.h.call("gpmi_lml_grad", kernel, dptr(theta), theta.size, float(extra_diag), dptr(mu),
+                    C.byref(lml), dptr(grad), C.byref(trq), dptr(alpha), C.byref(info))
+        return lml.value, grad, trq.value, alpha, info.value
+
+    # -- prediction -------------------------------------------------------------------
+    def predict(self, pts, want_var=True):
+        p = as_f64(pts)
+        m = p.shape[0]
+        mu = np.empty(m)
+        var = np.empty(m) if want_var else None
+        self.h.call("gpmi_predict", dptr(p), m, dptr(mu), dptr(var))
+        return mu, var
+
+    def posterior(self, pts, mean_only=False):
+        p = as_f64(pts)
+        m = p.shape[0]
+        mu = np.empty(m)
+        cov = None if mean_only else np.empty((m, m))
+        self.h.call("gpmi_posterior", dptr(p), m, dptr(mu), dptr(cov))
+        return mu, cov
+
+    def spatial_derivatives(self, pts):
+        p = as_f64(pts)
+        m = p.shape[0]
+        dmu = np.empty((m, self.d))
+        dvar = np.empty((m, self.d))
+        self.h.call("gpmi_spatial_derivatives", dptr(p), m, dptr(dmu), dptr(dvar))
+        return dmu, dvar
+
+    def gradient(self, pts):
+        p = as_f64(pts)
+        m = p.shape[0]
+        gmu = np.empty((m, self.d))
+        gcov = np.empty((m, self.d, self.d))
+        self.h.call("gpmi_gradient", dptr(p), m, dptr(gmu), dptr(gcov))
+        return gmu, gcov
+
+    def covariance(self, kernel, theta_cov, extra_diag=0.0, with_noise=False):
+        theta = as_f64(theta_cov)
+        K = np.empty((self.n, self.n))
+        self.h.call("gpmi_covariance", kernel, dptr(theta), theta.size, float(extra_diag),
+                    int(bool(with_noise)), dptr(K))
+        return K
+
+    def cross_covariance(self, kernel, theta_cov, pts):
+        theta = as_f64(theta_cov)
+        p = as_f64(pts)
+        out = np.empty((p.shape[0], self.n))
+        self.h.call("gpmi_cross_covariance", kernel, dptr(theta), theta.size, dptr(p), p.shape[0], dptr(out))
+        return out
+
+    def get_K(self):
+        K = np.empty((self.n, self.n))
+        self.h.call("gpmi_get_K", dptr(K))
+        return K
+
+    def get_L(self):
+        L = np.empty((self.n, self.n))
+        self.h.call("gpmi_get_L", dptr(L))
+        return L
+
+    def loo_diag(self):
+        out = np.empty(self.n)
+        self.h.call("gpmi_loo_diag", dptr(out))
+        return out
+
+    # -- instrumentation ----------------------------------------------------------------
+    def timer_start(self):
+        self.h.call("gpmi_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float(0.0)
+        self.h.call("gpmi_timer_stop", C.byref(ms))
+        return ms.value
+
+    def profile_enable(self, on=True):
+        self.h.call("gpmi_profile_enable", int(bool(on)))
+
+    def profile_reset(self):
+        self.h.call("gpmi_profile_reset")
+
+    def profile_read(self, klass):
+        n = C.c_int64(0)
+        ms, fl, by = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+        self.h.call("gpmi_profile_read", klass, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))
+        return {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
+
+    def sync(self):
+        self.h.call("gpmi_sync")
+
+    def close(self):
+        self.h.close()

@@ -1,0 +1,137 @@
+"""
+ctypes binding of libgpmi.so (C-ABI declared in include/gpmi.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C
+inference-tools_amd/csrc` into `inference_amd/lib/libgpmi.so`.  Nothing here
+falls back to a CPU implementation: a missing library or device raises
+`GpmiUnavailable`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgpmi.so")
+
+KERNEL_SE = 0
+KERNEL_RQ = 1
+PROF_KBUILD, PROF_SYRK, PROF_PANEL, PROF_SOLVE = 0, 1, 2, 3
+
+
+class GpmiUnavailable(RuntimeError):
+    """libgpmi.so (the HIP extension) or an MI355X device is missing."""
+
+
+class GpmiError(RuntimeError):
+    """A gpmi_* call returned a non-zero status."""
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+# name -> (restype, argtypes); mirrors include/gpmi.h one to one
+SIGNATURES = {
+    "gpmi_version": (C.c_int, []),
+    "gpmi_device_count": (C.c_int, [_ip]),
+    "gpmi_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "gpmi_destroy": (C.c_int, [_vp]),
+    "gpmi_last_error": (C.c_char_p, [_vp]),
+    "gpmi_sync": (C.c_int, [_vp]),
+    "gpmi_set_data": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _i64, _i64]),
+    "gpmi_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _ip]),
+    "gpmi_lml": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _ip]),
+    "gpmi_lml_batch": (C.c_int, [_vp, C.c_int, _i64, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_set_streams": (C.c_int, [_vp, C.c_int]),
+    "gpmi_lml_grad": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_predict": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
+    "gpmi_posterior": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
+    "gpmi_spatial_derivatives": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
+    "gpmi_gradient": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
+    "gpmi_covariance": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, C.c_int, _dp]),
+    "gpmi_cross_covariance": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _i64, _dp]),
+    "gpmi_get_K": (C.c_int, [_vp, _dp]),
+    "gpmi_get_L": (C.c_int, [_vp, _dp]),
+    "gpmi_loo_diag": (C.c_int, [_vp, _dp]),
+    "gpmi_timer_start": (C.c_int, [_vp]),
+    "gpmi_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "gpmi_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "gpmi_profile_read": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), _dp, _dp, _dp]),
+    "gpmi_profile_reset": (C.c_int, [_vp]),
+    "gpmi_dev_alloc": (C.c_int, [_vp, _i64, C.POINTER(_vp)]),
+    "gpmi_dev_free": (C.c_int, [_vp, _vp]),
+    "gpmi_dev_upload": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "gpmi_dev_download": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "gpmi_dev_potrf": (C.c_int, [_vp, _vp, _i64, _i64, _ip]),
+    "gpmi_dev_gemm_nt": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libgpmi.so and declare every prototype.  Raises GpmiUnavailable if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GpmiUnavailable(
+                f"{LIB_PATH} not found - build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C inference-tools_amd/csrc)"
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = header / library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def dptr(a):
+    """double* view of a C-contiguous float64 array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_dp)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Handle:
+    """Owns one gpmi_ctx (one device, one set of streams / workspaces)."""
+
+    def __init__(self, device=None):
+        lib = load()
+        if device is None:
+            device = int(os.environ.get("GPMI_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            cnt = C.c_int(0)
+            lib.gpmi_device_count(C.byref(cnt))
+            if cnt.value > 0:
+                device %= cnt.value
+        self.lib = lib
+        self.device = device
+        self.ctx = _vp()
+        rc = lib.gpmi_create(device, C.byref(self.ctx))
+        if rc != 0:
+            msg = lib.gpmi_last_error(None).decode()
+            raise GpmiUnavailable(f"gpmi_create(device={device}) failed with status {rc}: {msg}")
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, name)(self.ctx, *args)
+        if rc != 0:
+            raise GpmiError(f"{name} failed with status {rc}: {self.lib.gpmi_last_error(self.ctx).decode()}")
+
+    def close(self):
+        if self.ctx:
+            self.lib.gpmi_destroy(self.ctx)
+            self.ctx = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

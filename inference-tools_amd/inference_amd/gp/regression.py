@@ -1,0 +1,451 @@
+"""
+`GpRegressor` — drop-in for `inference.gp.GpRegressor` (reference:
+inference/gp/regression.py:16-612) whose covariance build, Cholesky
+factorisation / solves and log-marginal-likelihood evaluations run on an MI355X
+through the C-ABI of include/gpmi.h.
+
+Same constructor signature, attribute names (`x, y, sig, cov, mean, hp_bounds,
+hyperpars, K_xx, L, alpha, mu, ...`), return shapes, warnings and errors as the
+reference.  Differences in mechanism only:
+  * prediction is one batched device call instead of a Python loop over points
+    (regression.py:208-214);
+  * `K_xx`, `L` and `sig` are materialised lazily on first access (N^2 download);
+  * hyper-parameter layout, the LML without the 2 pi constant, the -1e50
+    sentinel, `sqrt(abs(var))` and the `.squeeze()`d gradient outputs are kept.
+"""
+from copy import copy
+from inspect import isclass
+from warnings import warn
+
+import numpy as np
+from numpy import array, ndarray, sqrt, zeros
+from numpy.linalg import LinAlgError
+from numpy.random import random
+from scipy.optimize import differential_evolution, fmin_l_bfgs_b
+
+from inference_amd._engine import GpEngine
+from inference_amd.gp.covariance import CovarianceFunction, SquaredExponential, device_plan
+from inference_amd.gp.mean import ConstantMean, MeanFunction
+
+
+class GpRegressor:
+    """
+    Gaussian-process regression in one or more dimensions (see the reference's
+    docstring, regression.py:17-77, for the modelling description).
+
+    :param x: (N, d) array (or array-like) of point coordinates; 1-D input means d = 1.
+    :param y: (N,) array of values.
+    :param y_err: (N,) standard deviations of the values (Gaussian errors).
+    :param y_cov: (N, N) covariance of the values, alternative to ``y_err``.
+    :param hyperpars: hyper-parameter vector ``[mean params | covariance params]``;
+        when omitted it is found by maximising the marginal likelihood (or the
+        leave-one-out likelihood if ``cross_val``).
+    :param kernel: covariance class or instance (``SquaredExponential``,
+        ``RationalQuadratic``, optionally ``+ WhiteNoise()``).
+    :param mean: mean-function class or instance.
+    :param bool cross_val: select hyper-parameters by LOO cross-validation.
+    :param str optimizer: ``"bfgs"`` (multi-start L-BFGS-B) or ``"diffev"``.
+    :param int n_processes: kept for signature compatibility; the starts are
+        evaluated on the device one after another.
+    :param int n_starts: number of L-BFGS-B starting positions.
+    :param device: (extension) HIP device index; default ``LOCAL_RANK`` / 0.
+    """
+
+    def __init__(
+        self,
+        x: ndarray,
+        y: ndarray,
+        y_err: ndarray = None,
+        y_cov: ndarray = None,
+        hyperpars: ndarray = None,
+        kernel: CovarianceFunction = SquaredExponential,
+        mean: MeanFunction = ConstantMean,
+        cross_val: bool = False,
+        optimizer: str = "bfgs",
+        n_processes: int = 1,
+        n_starts: int = None,
+        device: int = None,
+    ):
+        self.x = x if isinstance(x, ndarray) else array(x)
+        self.y = y if isinstance(y, ndarray) else array(y)
+        self.y = self.y.squeeze()
+
+        if self.y.ndim != 1:
+            raise ValueError(
+                f"""\n
+                \r[ GpRegressor error ]
+                \r>> 'y' argument must be a 1D array, but instead has shape {self.y.shape}
+                """
+            )
+
+        self.n_points = self.y.size
+        if self.x.ndim == 2:
+            self.n_dimensions = self.x.shape[1]
+        elif self.x.ndim <= 1:
+            self.n_dimensions = 1
+            self.x = self.x.reshape([self.x.size, self.n_dimensions])
+        else:
+            raise ValueError(
+                f"""\n
+                \r[ GpRegressor Error ]
+                \r>> 'x' argument must be a 2D array, but instead has
+                \r>> {self.x.ndim} dimensions and shape {self.x.shape}.
+                """
+            )
+
+        if self.x.shape[0] != self.n_points:
+            raise ValueError(
+                f"""\n
+                \r[ GpRegressor Error ]
+                \r>> The first dimension of the 'x' array must be equal in size
+                \r>> to the 'y' array.
+                \r>> 'x' has shape {self.x.shape}, but 'y' has size {self.y.size}.
+                """
+            )
+
+        # data-error covariance: kept as a variance vector or the dense matrix the user gave
+        self._noise_var, self._y_cov = self.check_error_data(y_err, y_cov)
+
+        self.cov = kernel() if isclass(kernel) else kernel
+        self.mean = mean() if isclass(mean) else mean
+
+        self.cov.pass_spatial_data(self.x)
+        self.mean.pass_spatial_data(self.x)
+        if self.cov.bounds is None:
+            self.cov.estimate_hyperpar_bounds(self.y)
+        if self.mean.bounds is None:
+            self.mean.estimate_hyperpar_bounds(self.y)
+        self.hp_bounds = copy(self.mean.bounds)
+        self.hp_bounds.extend(copy(self.cov.bounds))
+        self.n_hyperpars = len(self.hp_bounds)
+        self.mean_slice = slice(0, self.mean.n_params)
+        self.cov_slice = slice(self.mean.n_params, self.n_hyperpars)
+        self.hyperpar_labels = [*self.mean.hyperpar_labels, *self.cov.hyperpar_labels]
+
+        plan = device_plan(self.cov)
+        if plan is None:
+            raise NotImplementedError(
+                f"""\n
+                \r[ GpRegressor error ]
+                \r>> The covariance function {type(self.cov)} has no MI355X device kernel.
+                \r>> Supported: SquaredExponential, RationalQuadratic, each optionally + WhiteNoise().
+                """
+            )
+        self._kernel_id, self._stat, self._stat_slice, self._wn_index = plan
+        self._device = device
+        self._engine = None
+        self._K_cache = None
+        self._L_cache = None
+
+        if cross_val:
+            self.model_selector = self.loo_likelihood
+            self.model_selector_gradient = self.loo_likelihood_gradient
+        else:
+            self.model_selector = self.marginal_likelihood
+            self.model_selector_gradient = self.marginal_likelihood_gradient
+
+        if hyperpars is None:
+            if optimizer not in ["bfgs", "diffev"]:
+                optimizer = "bfgs"
+                warn(
+                    """
+                    An invalid option was passed to the 'optimizer' keyword argument.
+                    The default option 'bfgs' was used instead.
+                    Valid options are 'bfgs' and 'diffev'.
+                    """
+                )
+            if optimizer == "diffev":
+                hyperpars = self.differential_evo()
+            else:
+                hyperpars = self.multistart_bfgs(n_processes=n_processes, starts=n_starts)
+
+        self.set_hyperparameters(hyperpars)
+
+    # ---------------------------------------------------------------------------------
+    # device plumbing
+    # ---------------------------------------------------------------------------------
+    @property
+    def engine(self) -> GpEngine:
+        if self._engine is None:
+            self._engine = GpEngine(
+                self.x, self.y, noise_var=self._noise_var, y_cov=self._y_cov, device=self._device
+            )
+        return self._engine
+
+    def __getstate__(self):
+        # device handles do not pickle (the reference pickles the regressor into worker
+        # processes, regression.py:600-601); drop them and re-attach lazily
+        state = self.__dict__.copy()
+        state["_engine"] = None
+        state["_K_cache"] = None
+        state["_L_cache"] = None
+        return state
+
+    def _split_cov_theta(self, theta_cov):
+        """(stationary-kernel parameters, WhiteNoise variance) of a covariance parameter vector."""
+        theta_cov = np.asarray(theta_cov, dtype=float)
+        extra = 0.0
+        if self._wn_index is not None:
+            extra = float(np.exp(2 * theta_cov[self._wn_index]))  # covariance.py:168
+        return np.ascontiguousarray(theta_cov[self._stat_slice]), extra
+
+    @property
+    def sig(self) -> ndarray:
+        """Dense data-error covariance as in the reference (regression.py:320-322)."""
+        if self._y_cov is not None:
+            return self._y_cov
+        if self._noise_var is not None:
+            return np.diag(self._noise_var)
+        return zeros([self.n_points, self.n_points])
+
+    @property
+    def K_xx(self) -> ndarray:
+        if self._K_cache is None:
+            self._K_cache = self.engine.get_K()
+        return self._K_cache
+
+    @property
+    def L(self) -> ndarray:
+        if self._L_cache is None:
+            self._L_cache = self.engine.get_L()
+        return self._L_cache
+
+    # ---------------------------------------------------------------------------------
+    # public API (reference: regression.py:188-567)
+    # ---------------------------------------------------------------------------------
+    def __call__(self, points: ndarray):
+        """Mean and standard deviation of the regression estimate at `points`
+        (regression.py:188-216), evaluated as one batched device call."""
+        p = self.process_points(points)
+        mu, var = self.engine.predict(p)
+        mean_q = array([self.mean(q, self.mean_hyperpars) for q in p[:, None, :]])
+        return mu + mean_q, sqrt(abs(var))
+
+    def set_hyperparameters(self, hyperpars: ndarray):
+        """Update the hyper-parameters and re-fit (regression.py:218-244)."""
+        if len(hyperpars) != self.n_hyperpars:
+            raise ValueError(
+                f"""\n
+                [ GpRegressor error ]
+                >> An incorrect number of hyper-parameter values were passed via the
+                >> 'hyperpars' keyword argument:
+                >> There are {self.n_hyperpars} hyper-parameters but {len(hyperpars)} values were given.
+                """
+            )
+        self.hyperpars = hyperpars
+        self.mean_hyperpars = self.hyperpars[self.mean_slice]
+        self.cov_hyperpars = self.hyperpars[self.cov_slice]
+        self.mu = self.mean.build_mean(self.mean_hyperpars)
+        theta_stat, extra = self._split_cov_theta(self.cov_hyperpars)
+        self._K_cache = None
+        self._L_cache = None
+        alpha, logdet, info = self.engine.fit(self._kernel_id, theta_stat, extra, self.mu)
+        if info != 0:
+            raise LinAlgError("Matrix is not positive definite")  # numpy.linalg.cholesky, regression.py:241
+        self.alpha = alpha
+        self._logdet = logdet
+
+    def check_error_data(self, y_err, y_cov):
+        """Validation of regression.py:246-322; returns (variance vector | None, dense matrix | None)."""
+        if y_cov is not None:
+            if type(y_cov) in (list, tuple):
+                y_cov = array(y_cov).squeeze()
+            elif type(y_cov) is not ndarray:
+                raise TypeError(
+                    f"""\n
+                    [ GpRegressor error ]
+                    >> The 'y_cov' keyword argument should be given as a numpy array:
+                    >> Expected type {ndarray} but type {type(y_cov)} was given.
+                    """
+                )
+            if y_cov.shape != (self.n_points, self.n_points):
+                raise ValueError(
+                    """\n
+                    [ GpRegressor error ]
+                    >> The 'y_cov' keyword argument was passed an array with an incorrect
+                    >> shape. 'y_cov' must be a 2D array of shape (N,N), where 'N' is the
+                    >> number of given y-data values.
+                    """
+                )
+            if not (y_cov == y_cov.T).all():
+                raise ValueError(
+                    """\n
+                    [ GpRegressor error ]
+                    >> The covariance matrix passed to the 'y_cov' keyword argument
+                    >> is not symmetric.
+                    """
+                )
+            if y_err is not None:
+                warn(
+                    """\n
+                    [ GpRegressor warning ]
+                    >> Only one of the 'y_err' and 'y_cov' keyword arguments should
+                    >> be specified. Only the input to 'y_cov' will be used - the
+                    >> input to 'y_err' will be ignored.
+                    """
+                )
+            return None, np.ascontiguousarray(y_cov, dtype=float)
+
+        if y_err is not None:
+            if type(y_err) in (list, tuple):
+                y_err = array(y_err).squeeze()
+            elif type(y_err) is not ndarray:
+                raise TypeError(
+                    f"""\n
+                    [ GpRegressor error ]
+                    >> The 'y_err' keyword argument should be given as a numpy array:
+                    >> Expected type {ndarray} but type {type(y_err)} was given.
+                    """
+                )
+            if y_err.shape != (self.n_points,):
+                raise ValueError(
+                    """\n
+                    [ GpRegressor error ]
+                    >> The 'y_err' keyword argument was passed an array with an
+                    >> incorrect shape. 'y_err' must be a 1D array of length 'N',
+                    >> where 'N' is the number of given y-data values.
+                    """
+                )
+            return np.asarray(y_err, dtype=float) ** 2, None
+        return None, None
+
+    def process_points(self, points: ndarray) -> ndarray:
+        """Shape handling of regression.py:324-349."""
+        x = points if isinstance(points, ndarray) else array(points)
+        if x.ndim <= 1 and self.n_dimensions == 1:
+            x = x.reshape([x.size, 1])
+        elif x.ndim == 1 and x.size == self.n_dimensions:
+            x = x.reshape([1, x.size])
+        elif x.ndim > 2:
+            raise ValueError(
+                f"""\n
+                [ GpRegressor error ]
+                >> 'points' argument must be a 2D array, but given array
+                >> has {x.ndim} dimensions and shape {x.shape}.
+                """
+            )
+        if x.shape[1] != self.n_dimensions:
+            raise ValueError(
+                f"""\n
+                [ GpRegressor error ]
+                >> The second dimension of the 'points' array must have size
+                >> equal to the number of dimensions of the input data.
+                >> The input data have {self.n_dimensions} dimensions but 'points' has shape {x.shape}.
+                """
+            )
+        return x
+
+    def _require_gradient_terms(self):
+        if self._kernel_id != 0:
+            # RationalQuadratic has no gradient_terms (covariance.py:38-44): same error as the reference
+            self._stat.gradient_terms(None, None, None)
+
+    def gradient(self, points: ndarray):
+        """Mean and covariance of the gradient of the estimate (regression.py:351-385)."""
+        self._require_gradient_terms()
+        p = self.process_points(points)
+        gmu, gcov = self.engine.gradient(p)
+        return gmu.squeeze(), gcov.squeeze()
+
+    def spatial_derivatives(self, points: ndarray):
+        """Gradients of the predictive mean and variance (regression.py:387-419)."""
+        self._require_gradient_terms()
+        p = self.process_points(points)
+        dmu, dvar = self.engine.spatial_derivatives(p)
+        return dmu.squeeze(), dvar.squeeze()
+
+    def build_posterior(self, points: ndarray, mean_only=False):
+        """Posterior mean vector and covariance matrix (regression.py:421-449)."""
+        v = self.process_points(points)
+        mu, sigma = self.engine.posterior(v, mean_only=mean_only)
+        mu = mu + array([self.mean(p, self.mean_hyperpars) for p in v])
+        if mean_only:
+            return mu
+        return mu, sigma
+
+    def loo_predictions(self):
+        """Leave-one-out predictions, R&W eq. 5.12 (regression.py:451-466)."""
+        var = 1.0 / self.engine.loo_diag()
+        return self.y - self.alpha * var, sqrt(var)
+
+    def loo_likelihood(self, theta: ndarray) -> float:
+        raise NotImplementedError("loo_likelihood: device path not built yet")
+
+    def loo_likelihood_gradient(self, theta: ndarray):
+        raise NotImplementedError("loo_likelihood_gradient: device path not built yet")
+
+    def marginal_likelihood(self, theta: ndarray) -> float:
+        """Log-marginal likelihood, R&W eq. 5.8 without the 2 pi constant (regression.py:528-542)."""
+        theta = np.asarray(theta, dtype=float)
+        theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
+        mu = self.mean.build_mean(theta[self.mean_slice])
+        value, info = self.engine.lml(self._kernel_id, theta_stat, extra, mu)
+        if info != 0:
+            warn("Cholesky decomposition failure in marginal_likelihood")
+            return -1e50
+        return float(value)
+
+    def marginal_likelihood_batch(self, thetas: ndarray) -> ndarray:
+        """(extension) `marginal_likelihood` for T hyper-parameter vectors at once, spread over
+        the device's worker streams — the unit the grid sweep / PT driver shards over GPUs."""
+        thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
+        split = [self._split_cov_theta(t[self.cov_slice]) for t in thetas]
+        th = np.array([s[0] for s in split])
+        ex = np.array([s[1] for s in split])
+        if isinstance(self.mean, ConstantMean):
+            vals, info = self.engine.lml_batch(self._kernel_id, th, ex, mu_const=thetas[:, 0])
+        else:
+            mus = np.array([self.mean.build_mean(t[self.mean_slice]) for t in thetas])
+            vals, info = self.engine.lml_batch(self._kernel_id, th, ex, mus=mus)
+        if (info != 0).any():
+            warn("Cholesky decomposition failure in marginal_likelihood")
+        return vals
+
+    def marginal_likelihood_gradient(self, theta: ndarray):
+        """LML and its gradient, R&W eqs. 5.8-5.9 (regression.py:544-567)."""
+        theta = np.asarray(theta, dtype=float)
+        theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
+        mu, grad_mu = self.mean.mean_and_gradients(theta[self.mean_slice])
+        lml, g_stat, trace_q, alpha, info = self.engine.lml_grad(self._kernel_id, theta_stat, extra, mu)
+        if info != 0:
+            raise LinAlgError("Matrix is not positive definite")  # regression.py:555 has no guard
+        grad = zeros(self.n_hyperpars)
+        grad[self.mean_slice] = array([(alpha * dmu).sum() for dmu in grad_mu])
+        g_cov = zeros(self.cov.n_params)
+        g_cov[self._stat_slice] = g_stat
+        if self._wn_index is not None:
+            g_cov[self._wn_index] = extra * trace_q  # 1/2 sum Q o (2 sigma^2 I), covariance.py:171-175
+        grad[self.cov_slice] = g_cov
+        return lml, grad
+
+    # ---------------------------------------------------------------------------------
+    # hyper-parameter search (regression.py:569-605): SciPy drivers on the host, every
+    # objective evaluation on the device
+    # ---------------------------------------------------------------------------------
+    def differential_evo(self) -> ndarray:
+        opt_result = differential_evolution(func=lambda t: -self.model_selector(t), bounds=self.hp_bounds)
+        return opt_result.x
+
+    def bfgs_cost_func(self, theta: ndarray):
+        y, grad_y = self.model_selector_gradient(theta)
+        return -y, -grad_y
+
+    def launch_bfgs(self, x0: ndarray):
+        return fmin_l_bfgs_b(func=self.bfgs_cost_func, x0=x0, approx_grad=False, bounds=self.hp_bounds)
+
+    def multistart_bfgs(self, starts: int = None, n_processes: int = 1):
+        if starts is None:
+            starts = int(2 * sqrt(len(self.hp_bounds))) + 1
+        lwr, upr = [array([k[i] for k in self.hp_bounds]) for i in [0, 1]]
+        # random starts from the legacy global RNG plus the bounds centre (regression.py:589-594)
+        starting_positions = [lwr + (upr - lwr) * random(size=len(self.hp_bounds)) for _ in range(starts - 1)]
+        starting_positions.append(0.5 * (lwr + upr))
+        results = [self.launch_bfgs(x0) for x0 in starting_positions]
+        return sorted(results, key=lambda r: r[1])[0][0]
+
+    def __str__(self):
+        pad = max(len(label) for label in self.hyperpar_labels) + 2
+        lines = ["\n[ GpRegressor hyperparameters ]\n"]
+        for label, val in zip(self.hyperpar_labels, self.hyperpars):
+            lines.append(f"{label:>{pad}} = {val:.4}\n")
+        return "".join(lines)
