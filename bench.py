@@ -1,0 +1,191 @@
+"""
+bench.py — headline benchmark of the GP hot path on MI355X.
+
+Metric (BASELINE.json): GpRegressor fit+predict wall-time and GFLOP/s at N=16384, d=8.
+One "step" = one fit at fixed hyper-parameters (covariance build -> blocked Cholesky -> alpha solves,
+reference regression.py:218-244) followed by a batched predict of M=1024 points (regression.py:188-216)
+on the synthetic data of workloads.py, x / y / y_err already resident in HBM.
+value = (N^3/3 + M N^2) FLOP per step * steps * n_gpus / wall  in GFLOP/s (whole job).
+
+N GPUs: one process per GPU (torch.distributed, backend nccl = RCCL), each rank runs the same step
+at its own hyper-parameter vector (the path shards over independent hyper-parameter evaluations,
+weak scaling) and the per-rank results (log-determinant, alpha norm, predictive checksum) are
+all-gathered over RCCL inside the timed region.
+
+Extra objects on the JSON line:
+  roofline      the potrf trailing SYRK/GEMM update (fp64 MFMA bound): algorithmic FLOP per launch
+                divided by the HIP-event duration of each launch on its own stream (gpmi_profile_*)
+  cpu_baseline  the CPU oracle (NumPy/SciPy restatement of the reference, kind "port") timed on the
+                host cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "inference-tools_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+PEAK_FP64_MFMA_TFLOPS = 78.6  # 256 CU x 4 SIMD x 2048 FLOP / 64 clk x 2.4 GHz (tools/mfma_probe.hip)
+
+
+def cpu_baseline(n_cpu, d, m_cpu):
+    """Oracle (port of the reference path) on the host: fit + batched predict at a bounded size."""
+    from oracle import gp_oracle as orc  # checker / baseline only
+    import workloads as wl
+
+    x, y, e = wl.synthetic_dataset(2, n_cpu, d)
+    theta = wl.timing_theta(wl.SE, y, d)
+    pts = wl.query_points(2, m_cpu, d)
+    threads = os.cpu_count() or 1
+    try:
+        from threadpoolctl import threadpool_info
+
+        info = threadpool_info()
+        if info:
+            threads = max(i.get("num_threads", 1) for i in info)
+    except Exception:
+        pass
+    t0 = time.perf_counter()
+    gp = orc.OracleGp(x, y, e, kernel=orc.SE, hyperpars=theta)
+    gp(pts)
+    dt = time.perf_counter() - t0
+    flops = n_cpu**3 / 3.0 + m_cpu * float(n_cpu) ** 2
+    return {
+        "value": flops / dt / 1e9,
+        "unit": "GFLOP/s",
+        "cores": int(threads),
+        "kind": "port",
+        "sample": f"oracle fit+predict SE N={n_cpu} d={d} M={m_cpu}, 1 run, {dt:.1f} s wall "
+        f"(NumPy/SciPy + BLAS threads={threads}); K-build included as in the reference",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--m", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import workloads as wl
+    from inference_amd import _lib
+    from inference_amd.gp import GpRegressor, SquaredExponential
+
+    N, d, M = args.n, args.d, args.m
+    x, y, e = wl.synthetic_dataset(2, N, d)
+    thetas = wl.theta_set(wl.SE, y, d, max(world, 1), seed=11)
+    theta = thetas[rank % len(thetas)] if world > 1 else thetas[0]
+    pts = wl.query_points(2, M, d)
+
+    gp = GpRegressor(x, y, y_err=e, hyperpars=theta, kernel=SquaredExponential, device=local_rank)
+    eng = gp.engine
+
+    def step():
+        gp.set_hyperparameters(theta)  # K-build + potrf + alpha
+        mu, sig = gp(pts)  # cross-covariance + TRSM + reductions
+        res = torch.tensor(
+            [gp._logdet, float(np.linalg.norm(gp.alpha)), float(mu.sum()), float(sig.sum())],
+            dtype=torch.float64,
+            device="cuda",
+        )
+        if dist is not None:
+            out = [torch.empty_like(res) for _ in range(world)]
+            dist.all_gather(out, res)  # RCCL: the only collective of the path (result gather)
+            res = torch.stack(out)
+        return res
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.profile_enable(2 << _lib.PROF_SYRK)
+    eng.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read(_lib.PROF_SYRK)
+    eng.profile_enable(0)
+
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    flops_step = N**3 / 3.0 + M * float(N) ** 2
+    value = flops_step * args.steps * world / dt / 1e9
+
+    if rank == 0:
+        ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
+        line = {
+            "metric": "GpRegressor fit+predict GFLOP/s at N=16384, d=8 (fp64)",
+            "value": value,
+            "unit": "GFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"GpRegressor SquaredExponential fit (fixed theta) + predict, N={N} d={d} M={M}",
+                "flop_per_step": flops_step,
+                "pct_fp64_mfma_peak_whole_step": 100.0 * value / world / 1e3 / PEAK_FP64_MFMA_TFLOPS,
+                "parallelism": f"{world} independent hyper-parameter evaluations (one per GPU), RCCL all_gather of results",
+            },
+            "roofline": {
+                "kernel": "gemm_nt_kernel<TILES_LOWER, OP_SUB> (potrf trailing SYRK update, K=512)",
+                "bound": "mfma",
+                "achieved": ach,
+                "peak": PEAK_FP64_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": ach / PEAK_FP64_MFMA_TFLOPS,
+                "traffic": None,
+                "launches": prof["launches"],
+                "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
+                "flop_per_launch_avg": prof["flops"] / max(prof["launches"], 1),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(4096, d, 256)
+        print(json.dumps(line), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

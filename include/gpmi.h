@@ -164,6 +164,7 @@ int gpmi_timer_stop(gpmi_ctx* ctx, float* ms);
 #define GPMI_PROF_PANEL 2   /* potrf diagonal block + panel TRSM (latency bound) */
 #define GPMI_PROF_SOLVE 3   /* triangular solves / reductions */
 #define GPMI_PROF_NCLASS 4
+/* on = 0: off; 1: every class; otherwise a class bitmask shifted left by one (2 << klass) */
 int gpmi_profile_enable(gpmi_ctx* ctx, int on);
 /* accumulated since the last reset: launches, total ms, algorithmic flops and bytes */
 int gpmi_profile_read(gpmi_ctx* ctx, int klass, int64_t* launches, double* ms, double* flops,

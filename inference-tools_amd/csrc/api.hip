@@ -158,7 +158,7 @@ int ensure_query_ws(gpmi_ctx* c, int64_t mp) {
 // ---- instrumentation scope ----------------------------------------------------------
 ProfScope::ProfScope(gpmi_ctx* ctx, hipStream_t st, int klass, double flops, double bytes)
     : c(ctx), s(st), slot(nullptr) {
-  if (!c->prof) return;
+  if (!((c->prof_mask >> klass) & 1)) return;
   if (c->prof_used == c->prof_slots.size()) {
     ProfSlot ns{};
     if (hipEventCreate(&ns.e0) != hipSuccess || hipEventCreate(&ns.e1) != hipSuccess) return;
@@ -569,7 +569,7 @@ int gpmi_timer_stop(gpmi_ctx* c, float* ms) {
 
 int gpmi_profile_enable(gpmi_ctx* c, int on) {
   if (!c) return GPMI_ERR_ARG;
-  c->prof = on != 0;
+  c->prof_mask = (on == 1) ? 0xF : (unsigned)on >> 1;
   return GPMI_OK;
 }
 

@@ -69,7 +69,7 @@ struct gpmi_ctx {
   int64_t h_stage_bytes = 0;
   // instrumentation
   hipEvent_t t0 = nullptr, t1 = nullptr;
-  bool prof = false;
+  unsigned prof_mask = 0;
   std::vector<ProfSlot> prof_slots;
   size_t prof_used = 0;
   double prof_ms[GPMI_PROF_NCLASS] = {0, 0, 0, 0};

@@ -15,72 +15,166 @@
 namespace {
 
 constexpr int NB = GPMI_NB;
-constexpr int SP = NB + 1;  // LDS row pitch (conflict-free row and column walks)
+constexpr int SP = NB + 1;  // LDS row pitch of the 128 x 128 block (conflict-free row and column walks)
+constexpr int BS = 16;      // base block = one MFMA tile
+constexpr int NBLK = NB / BS;
+constexpr int WP = BS + 1;  // pitch of the 16 x 16 inverse diagonal blocks
 
-// One workgroup: L = chol(A_blk) in place (lower part), invD = L^-1 (dense 128 x 128, zero above
-// the diagonal).
+// value of `v` in lane `src` (compile-time constant) as a wave-uniform scalar
+__device__ inline double lane_bcast(double v, int src) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, src);
+  hi = __builtin_amdgcn_readlane(hi, src);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ inline double rcp_newton(double p) {
+  double y = __builtin_amdgcn_rcp(p);
+  double e = fma(-p, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-p, y, 1.0);
+  return fma(y, e, y);
+}
+
+// One wave: factor the symmetric 16 x 16 diagonal block `kb` of S (both triangles valid) and
+// invert the factor.  Lane k (= lane & 15; the four 16-lane rows of the wave run the same
+// computation) holds column k.  Gaussian elimination without square roots on the critical path:
+// row_i -= (A[i][c] / p_c) row_c, with A[i][c] read from lane c by symmetry of the Schur
+// complement; the same row operations applied to the identity give M^-1 (A = M D M^T).  Then
+// L[k][i] = U[i][k] / sqrt(p_i) and W = L^-1 = D^-1/2 M^-1.
+__device__ inline void factor16(double* S, double* Wl, int kb, int* info, int col0, int lane) {
+  const int k = lane & 15;
+  const int base = kb * BS;
+  double a[BS], e[BS];
+#pragma unroll
+  for (int i = 0; i < BS; ++i) {
+    a[i] = S[(base + i) * SP + base + k];
+    e[i] = (i == k) ? 1.0 : 0.0;
+  }
+  double myp = 1.0;
+  int badcol = -1;
+#pragma unroll
+  for (int c = 0; c < BS; ++c) {
+    double p = lane_bcast(a[c], c);
+    if (!(p > 0.0) || !(p < 1.79e308)) {  // wave-uniform
+      if (badcol < 0) badcol = c;
+      p = 1.0;
+    }
+    if (k == c) myp = p;
+    const double ip = rcp_newton(p);
+#pragma unroll
+    for (int i = c + 1; i < BS; ++i) {
+      const double m = lane_bcast(a[i], c) * ip;
+      a[i] = fma(-m, a[c], a[i]);
+      e[i] = fma(-m, e[c], e[i]);
+    }
+  }
+  const double rs = 1.0 / sqrt(myp);
+#pragma unroll
+  for (int i = 0; i < BS; ++i) {
+    const double rsi = lane_bcast(rs, i);
+    if (lane < BS) {
+      if (i <= k) S[(base + k) * SP + base + i] = a[i] * rsi;  // row k of L
+      Wl[kb * BS * WP + i * WP + k] = e[i] * rsi;               // column k of W (zero above the diagonal)
+    }
+  }
+  if (badcol >= 0 && lane == 0 && *info == 0) *info = col0 + base + badcol + 1;
+}
+
+// One workgroup (4 waves): L = chol(A_blk) in place (lower part of A), invD = L^-1 (dense
+// 128 x 128, zero above the diagonal).  Blocked by 16 inside LDS: factor16 on one wave, panel and
+// trailing updates as 16 x 16 x 16 products on v_mfma_f64_16x16x4_f64, then the inverse row-block by
+// row-block, X[ib][jb] = -W_ib * sum_kb L[ib][kb] X[kb][jb], kept (transposed) in the upper blocks
+// of the same LDS image.
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A, int64_t ld,
                                                          double* __restrict__ invD,
                                                          int* __restrict__ info, int col0) {
   __shared__ double S[NB * SP];
-  __shared__ double dinv[NB];
-  const int tid = threadIdx.x;
+  __shared__ double Wl[NBLK * BS * WP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
   for (int idx = tid; idx < NB * NB; idx += 256) {
     const int r = idx >> 7, c = idx & 127;
-    S[r * SP + c] = A[(int64_t)r * ld + c];
+    if (c <= r) {
+      const double v = A[(int64_t)r * ld + c];
+      S[r * SP + c] = v;
+      S[c * SP + r] = v;  // mirror: the diagonal 16-blocks must be symmetric for factor16
+    }
   }
   __syncthreads();
-  const int ty = tid >> 4, tx = tid & 15;
-  for (int j = 0; j < NB; ++j) {
-    double ajj = S[j * SP + j];
-    if (!(ajj > 0.0) || !(ajj < 1.79e308)) {
-      if (tid == 0 && *info == 0) *info = col0 + j + 1;
-      ajj = 1.0;
-    }
-    const double dj = sqrt(ajj);
-    __syncthreads();  // everyone has read the pivot before it is overwritten
-    if (tid == j) {
-      S[j * SP + j] = dj;
-      dinv[j] = 1.0 / dj;
-    }
-    if (tid > j && tid < NB) S[tid * SP + j] = S[tid * SP + j] / dj;
+  for (int kb = 0; kb < NBLK; ++kb) {
+    const int base = kb * BS;
+    if (wave == 0) factor16(S, Wl, kb, info, col0, lane);
     __syncthreads();
-    // rank-1 update of the trailing lower triangle
-    for (int i = j + 1 + ty; i < NB; i += 16) {
-      const double lij = S[i * SP + j];
-      for (int k = j + 1 + tx; k <= i; k += 16) S[i * SP + k] -= lij * S[k * SP + j];
+    // panel: A[ib][kb] <- A[ib][kb] * W^T
+    for (int ib = kb + 1 + wave; ib < NBLK; ib += 4) {
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double av = S[(ib * BS + fr) * SP + base + fk + 4 * q];
+        const double bv = Wl[kb * BS * WP + fr * WP + fk + 4 * q];  // B[k][j] = W[j][k]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[(ib * BS + fk + 4 * r) * SP + base + fr] = acc[r];
     }
-    // the next pivot S[j+1][j+1] is final only after the update
+    __syncthreads();
+    // trailing: A[ib][jb] -= P_ib P_jb^T for ib >= jb > kb (diagonal tiles computed in full: symmetric)
+    const int m = NBLK - 1 - kb;
+    const int ntile = m * (m + 1) / 2;
+    for (int t = wave; t < ntile; t += 4) {
+      int i = 0;
+      while ((i + 1) * (i + 2) / 2 <= t) ++i;
+      const int j = t - i * (i + 1) / 2;
+      const int ib = kb + 1 + i, jb = kb + 1 + j;
+      d4_t acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = S[(ib * BS + fk + 4 * r) * SP + jb * BS + fr];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double av = -S[(ib * BS + fr) * SP + base + fk + 4 * q];
+        const double bv = S[(jb * BS + fr) * SP + base + fk + 4 * q];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[(ib * BS + fk + 4 * r) * SP + jb * BS + fr] = acc[r];
+    }
     __syncthreads();
   }
-  // write L back (lower triangle incl. diagonal; the upper triangle of A is left untouched)
+  // L back to global memory (lower triangle incl. diagonal; the upper triangle of A is untouched)
   for (int idx = tid; idx < NB * NB; idx += 256) {
     const int r = idx >> 7, c = idx & 127;
     if (c <= r) A[(int64_t)r * ld + c] = S[r * SP + c];
   }
-  // X = L^-1 by forward substitution, thread c owns column c.  X[i][c] (i > c) is kept in the
-  // upper triangle of S (transposed: S[c][i]) so that both L and X stay in LDS.
-  __syncthreads();
-  if (tid < NB) {
-    const int c = tid;
-    for (int i = 1; i < NB; ++i) {
-      // all lanes walk k uniformly so that L[i][k] is a broadcast read
-      double acc = 0.0;
-      for (int k = 0; k < i; ++k) {
-        const double lik = S[i * SP + k];
-        double xk = 0.0;
-        if (k == c) xk = dinv[c];
-        else if (k > c) xk = S[c * SP + k];
-        acc = fma(lik, xk, acc);
+  // inverse, row-block by row-block; X[ib][jb] (ib > jb) is stored transposed at S[jb-block][ib-block]
+  for (int ib = 1; ib < NBLK; ++ib) {
+    for (int jb = wave; jb < ib; jb += 4) {
+      d4_t T = {0.0, 0.0, 0.0, 0.0};
+      for (int kb = jb; kb < ib; ++kb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double av = S[(ib * BS + fr) * SP + kb * BS + fk + 4 * q];  // L[ib][kb]
+          const double bv = (kb == jb) ? Wl[jb * BS * WP + (fk + 4 * q) * WP + fr]
+                                       : S[(jb * BS + fr) * SP + kb * BS + fk + 4 * q];
+          T = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, T, 0, 0, 0);
+        }
       }
-      if (i > c) S[c * SP + i] = -acc * dinv[i];
+      // the D layout of T (row = fk + 4 r) is exactly the B-operand layout of k-step q = r
+      d4_t X = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double av = -Wl[ib * BS * WP + fr * WP + fk + 4 * q];
+        X = __builtin_amdgcn_mfma_f64_16x16x4f64(av, T[q], X, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[(jb * BS + fr) * SP + ib * BS + fk + 4 * r] = X[r];
     }
+    __syncthreads();
   }
-  __syncthreads();
   for (int idx = tid; idx < NB * NB; idx += 256) {
     const int r = idx >> 7, c = idx & 127;
     double v = 0.0;
-    if (c == r) v = dinv[r];
+    if ((r >> 4) == (c >> 4)) v = Wl[(r >> 4) * BS * WP + (r & 15) * WP + (c & 15)];
     else if (c < r) v = S[c * SP + r];
     invD[r * NB + c] = v;
   }
