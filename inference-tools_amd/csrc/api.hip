@@ -29,8 +29,18 @@ thread_local std::string g_create_err;
 
 constexpr int RED_SLOTS = 8192;  // per-lane result slots for batched evaluations
 
+int lane_streams(gpmi_ctx* c, Lane& L) {
+  int lo = 0, hi = 0;
+  HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi is the numerically lowest = highest priority
+  HIPCHK(c, hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, lo));
+  HIPCHK(c, hipStreamCreateWithPriority(&L.stream2, hipStreamNonBlocking, hi));
+  HIPCHK(c, hipEventCreateWithFlags(&L.ev_la, hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&L.ev_panel, hipEventDisableTiming));
+  return GPMI_OK;
+}
+
 int lane_alloc(gpmi_ctx* c, Lane& L) {
-  HIPCHK(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+  if (int rc = lane_streams(c, L)) return rc;
   const int64_t nt = c->np / GPMI_NB;
   HIPCHK(c, hipMalloc(&L.A, sizeof(double) * c->np * c->ld));
   HIPCHK(c, hipMalloc(&L.invD, sizeof(double) * nt * GPMI_NB * GPMI_NB));
@@ -44,6 +54,10 @@ int lane_alloc(gpmi_ctx* c, Lane& L) {
 
 void lane_free(Lane& L) {
   if (L.stream) (void)hipStreamSynchronize(L.stream);
+  if (L.stream2) (void)hipStreamSynchronize(L.stream2);
+  if (L.ev_la) (void)hipEventDestroy(L.ev_la);
+  if (L.ev_panel) (void)hipEventDestroy(L.ev_panel);
+  if (L.stream2) (void)hipStreamDestroy(L.stream2);
   if (L.A) (void)hipFree(L.A);
   if (L.invD) (void)hipFree(L.invD);
   if (L.vec) (void)hipFree(L.vec);
@@ -127,7 +141,7 @@ int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const dou
     launch_kbuild_square(s, p, c->x, c->n, c->np, c->noise, L.A, c->ld, true);
   }
   if (c->ycov) launch_add_full(s, L.A, c->ld, c->ycov, c->n);
-  potrf_lower(c, s, L.A, c->np, c->ld, L.invD, L.info + slot);
+  potrf_lower(c, L, L.A, c->np, c->ld, L.invD, L.info + slot);
   launch_residual(s, c->y, mu_dev, mu_const, L.vec, c->n, c->np);
   trsv_forward(c, s, L.A, c->np, c->ld, L.invD, L.vec);
   launch_lml_reduce(s, L.vec, L.A, c->ld, c->np, L.red + 2 * slot);
@@ -233,7 +247,10 @@ const char* gpmi_last_error(const gpmi_ctx* c) { return c ? c->err.c_str() : g_c
 int gpmi_sync(gpmi_ctx* c) {
   if (!c) return GPMI_ERR_ARG;
   if (set_device(c)) return GPMI_ERR_HIP;
-  for (auto& L : c->lanes) HIPCHK(c, hipStreamSynchronize(L.stream));
+  for (auto& L : c->lanes) {
+    HIPCHK(c, hipStreamSynchronize(L.stream));
+    if (L.stream2) HIPCHK(c, hipStreamSynchronize(L.stream2));
+  }
   return GPMI_OK;
 }
 
@@ -641,7 +658,7 @@ static int dev_stream(gpmi_ctx* c, hipStream_t* s) {
   if (c->lanes.empty()) {
     // a bare handle (no data yet): give it a stream-only lane
     c->lanes.emplace_back();
-    HIPCHK(c, hipStreamCreateWithFlags(&c->lanes[0].stream, hipStreamNonBlocking));
+    if (int rc = lane_streams(c, c->lanes[0])) return rc;
   }
   *s = c->lanes[0].stream;
   return GPMI_OK;
@@ -658,7 +675,7 @@ int gpmi_dev_potrf(gpmi_ctx* c, double* A, int64_t n, int64_t ld, int* info) {
   HIPCHK(c, hipMalloc(&invD, sizeof(double) * (n / GPMI_NB) * GPMI_NB * GPMI_NB));
   HIPCHK(c, hipMalloc(&dinfo, sizeof(int)));
   HIPCHK(c, hipMemsetAsync(dinfo, 0, sizeof(int), s));
-  potrf_lower(c, s, A, n, ld, invD, dinfo);
+  potrf_lower(c, c->lanes[0], A, n, ld, invD, dinfo);
   int h = 0;
   hipError_t e = hipMemcpyAsync(&h, dinfo, sizeof(int), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);

@@ -34,7 +34,9 @@ struct ProfSlot {
 
 // One independent evaluation lane: a stream with its own n x n scratch matrix and vectors.
 struct Lane {
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // main stream: covariance build, trailing updates, solves
+  hipStream_t stream2 = nullptr;  // panel stream (higher priority): look-ahead factorisation of the next panel
+  hipEvent_t ev_la = nullptr, ev_panel = nullptr;
   double* A = nullptr;      // np x ld scratch (K then L)
   double* invD = nullptr;   // (np/128) x 128 x 128 inverses of the diagonal blocks
   double* vec = nullptr;    // 4 x np work vectors
@@ -108,7 +110,7 @@ void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_
 // potrf.hip
 void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0);
 // blocked right-looking Cholesky, in place, lower; invD receives the inverses of the diagonal blocks
-void potrf_lower(gpmi_ctx* c, hipStream_t s, double* A, int64_t np, int64_t ld, double* invD,
+void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t ld, double* invD,
                  int* info);
 
 // solve.hip

@@ -15,7 +15,6 @@
 namespace {
 
 constexpr int NB = GPMI_NB;
-constexpr int SP = NB + 1;  // LDS row pitch of the 128 x 128 block (conflict-free row and column walks)
 constexpr int BS = 16;      // base block = one MFMA tile
 constexpr int NBLK = NB / BS;
 constexpr int WP = BS + 1;  // pitch of the 16 x 16 inverse diagonal blocks
@@ -36,19 +35,32 @@ __device__ inline double rcp_newton(double p) {
   return fma(y, e, y);
 }
 
+// LDS image of the 128 x 128 block: only the block-lower part is kept (block row ib holds
+// (ib + 1) * 16 columns), each row padded by one double so that row and column walks are
+// conflict-free.  74,752 bytes: together with the 2 KiB inverse block this leaves room for a
+// 72 KiB GEMM workgroup on the same CU, which is what lets the panel stream overlap the trailing
+// update (a 150 KiB image had to wait for a completely idle CU).
+constexpr int S_DOUBLES = 16 * (16 * 36 + 8);
+__device__ inline int prow(int r) {
+  const int ib = r >> 4;
+  return 16 * (8 * ib * (ib + 1) + ib) + (r & 15) * ((ib + 1) * 16 + 1);
+}
+
 // One wave: factor the symmetric 16 x 16 diagonal block `kb` of S (both triangles valid) and
 // invert the factor.  Lane k (= lane & 15; the four 16-lane rows of the wave run the same
 // computation) holds column k.  Gaussian elimination without square roots on the critical path:
 // row_i -= (A[i][c] / p_c) row_c, with A[i][c] read from lane c by symmetry of the Schur
 // complement; the same row operations applied to the identity give M^-1 (A = M D M^T).  Then
-// L[k][i] = U[i][k] / sqrt(p_i) and W = L^-1 = D^-1/2 M^-1.
-__device__ inline void factor16(double* S, double* Wl, int kb, int* info, int col0, int lane) {
+// L[k][i] = U[i][k] / sqrt(p_i) and W = L^-1 = D^-1/2 M^-1 (to LDS for the panel phase and to the
+// diagonal block of invD in global memory).
+__device__ inline void factor16(double* S, double* Wl, double* __restrict__ invD, int kb, int* info,
+                                int col0, int lane) {
   const int k = lane & 15;
   const int base = kb * BS;
   double a[BS], e[BS];
 #pragma unroll
   for (int i = 0; i < BS; ++i) {
-    a[i] = S[(base + i) * SP + base + k];
+    a[i] = S[prow(base + i) + base + k];
     e[i] = (i == k) ? 1.0 : 0.0;
   }
   double myp = 1.0;
@@ -70,12 +82,15 @@ __device__ inline void factor16(double* S, double* Wl, int kb, int* info, int co
     }
   }
   const double rs = 1.0 / sqrt(myp);
+  const int rowk = prow(base + k);
 #pragma unroll
   for (int i = 0; i < BS; ++i) {
     const double rsi = lane_bcast(rs, i);
     if (lane < BS) {
-      if (i <= k) S[(base + k) * SP + base + i] = a[i] * rsi;  // row k of L
-      Wl[kb * BS * WP + i * WP + k] = e[i] * rsi;               // column k of W (zero above the diagonal)
+      if (i <= k) S[rowk + base + i] = a[i] * rsi;  // row k of L
+      const double w = e[i] * rsi;                    // column k of W (zero above the diagonal)
+      Wl[i * WP + k] = w;
+      invD[(base + i) * NB + base + k] = w;
     }
   }
   if (badcol >= 0 && lane == 0 && *info == 0) *info = col0 + base + badcol + 1;
@@ -84,39 +99,42 @@ __device__ inline void factor16(double* S, double* Wl, int kb, int* info, int co
 // One workgroup (4 waves): L = chol(A_blk) in place (lower part of A), invD = L^-1 (dense
 // 128 x 128, zero above the diagonal).  Blocked by 16 inside LDS: factor16 on one wave, panel and
 // trailing updates as 16 x 16 x 16 products on v_mfma_f64_16x16x4_f64, then the inverse row-block by
-// row-block, X[ib][jb] = -W_ib * sum_kb L[ib][kb] X[kb][jb], kept (transposed) in the upper blocks
-// of the same LDS image.
+// row-block, X[ib][jb] = -W_ib * sum_kb L[ib][kb] X[kb][jb], written straight to invD (earlier
+// row-blocks are read back through L2).
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A, int64_t ld,
                                                          double* __restrict__ invD,
                                                          int* __restrict__ info, int col0) {
-  __shared__ double S[NB * SP];
-  __shared__ double Wl[NBLK * BS * WP];
+  __shared__ double S[S_DOUBLES];
+  __shared__ double Wl[BS * WP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
   for (int idx = tid; idx < NB * NB; idx += 256) {
     const int r = idx >> 7, c = idx & 127;
-    if (c <= r) {
-      const double v = A[(int64_t)r * ld + c];
-      S[r * SP + c] = v;
-      S[c * SP + r] = v;  // mirror: the diagonal 16-blocks must be symmetric for factor16
+    if ((c >> 4) <= (r >> 4)) {
+      // the upper part of a diagonal 16-block is mirrored from the lower triangle of A
+      const double v = (c <= r) ? A[(int64_t)r * ld + c] : A[(int64_t)c * ld + r];
+      S[prow(r) + c] = v;
+    } else {
+      invD[idx] = 0.0;
     }
   }
   __syncthreads();
   for (int kb = 0; kb < NBLK; ++kb) {
     const int base = kb * BS;
-    if (wave == 0) factor16(S, Wl, kb, info, col0, lane);
+    if (wave == 0) factor16(S, Wl, invD, kb, info, col0, lane);
     __syncthreads();
     // panel: A[ib][kb] <- A[ib][kb] * W^T
     for (int ib = kb + 1 + wave; ib < NBLK; ib += 4) {
       d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      const int ra = prow(ib * BS + fr) + base + fk;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const double av = S[(ib * BS + fr) * SP + base + fk + 4 * q];
-        const double bv = Wl[kb * BS * WP + fr * WP + fk + 4 * q];  // B[k][j] = W[j][k]
+        const double av = S[ra + 4 * q];
+        const double bv = Wl[fr * WP + fk + 4 * q];  // B[k][j] = W[j][k]
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) S[(ib * BS + fk + 4 * r) * SP + base + fr] = acc[r];
+      for (int r = 0; r < 4; ++r) S[prow(ib * BS + fk + 4 * r) + base + fr] = acc[r];
     }
     __syncthreads();
     // trailing: A[ib][jb] -= P_ib P_jb^T for ib >= jb > kb (diagonal tiles computed in full: symmetric)
@@ -128,34 +146,37 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
       const int j = t - i * (i + 1) / 2;
       const int ib = kb + 1 + i, jb = kb + 1 + j;
       d4_t acc;
+      int rc[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = S[(ib * BS + fk + 4 * r) * SP + jb * BS + fr];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double av = -S[(ib * BS + fr) * SP + base + fk + 4 * q];
-        const double bv = S[(jb * BS + fr) * SP + base + fk + 4 * q];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      for (int r = 0; r < 4; ++r) {
+        rc[r] = prow(ib * BS + fk + 4 * r) + jb * BS + fr;
+        acc[r] = S[rc[r]];
       }
+      const int ra = prow(ib * BS + fr) + base + fk, rb = prow(jb * BS + fr) + base + fk;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) S[(ib * BS + fk + 4 * r) * SP + jb * BS + fr] = acc[r];
+      for (int q = 0; q < 4; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[ra + 4 * q], S[rb + 4 * q], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[rc[r]] = acc[r];
     }
     __syncthreads();
   }
   // L back to global memory (lower triangle incl. diagonal; the upper triangle of A is untouched)
   for (int idx = tid; idx < NB * NB; idx += 256) {
     const int r = idx >> 7, c = idx & 127;
-    if (c <= r) A[(int64_t)r * ld + c] = S[r * SP + c];
+    if (c <= r) A[(int64_t)r * ld + c] = S[prow(r) + c];
   }
-  // inverse, row-block by row-block; X[ib][jb] (ib > jb) is stored transposed at S[jb-block][ib-block]
+  // inverse, row-block by row-block (the barrier orders the global writes of one row-block before
+  // the reads of the next: same CU, lines never read before they are written)
   for (int ib = 1; ib < NBLK; ++ib) {
     for (int jb = wave; jb < ib; jb += 4) {
       d4_t T = {0.0, 0.0, 0.0, 0.0};
+      const int ra = prow(ib * BS + fr) + fk;
       for (int kb = jb; kb < ib; ++kb) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const double av = S[(ib * BS + fr) * SP + kb * BS + fk + 4 * q];  // L[ib][kb]
-          const double bv = (kb == jb) ? Wl[jb * BS * WP + (fk + 4 * q) * WP + fr]
-                                       : S[(jb * BS + fr) * SP + kb * BS + fk + 4 * q];
+          const double av = S[ra + kb * BS + 4 * q];                                    // L[ib][kb]
+          const double bv = invD[(kb * BS + fk + 4 * q) * NB + jb * BS + fr];           // X[kb][jb]
           T = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, T, 0, 0, 0);
         }
       }
@@ -163,20 +184,14 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
       d4_t X = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const double av = -Wl[ib * BS * WP + fr * WP + fk + 4 * q];
+        const double av = -invD[(ib * BS + fr) * NB + ib * BS + fk + 4 * q];            // W_ib
         X = __builtin_amdgcn_mfma_f64_16x16x4f64(av, T[q], X, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) S[(jb * BS + fr) * SP + ib * BS + fk + 4 * r] = X[r];
+      for (int r = 0; r < 4; ++r) invD[(ib * BS + fk + 4 * r) * NB + jb * BS + fr] = X[r];
     }
+    __threadfence_block();
     __syncthreads();
-  }
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int r = idx >> 7, c = idx & 127;
-    double v = 0.0;
-    if ((r >> 4) == (c >> 4)) v = Wl[(r >> 4) * BS * WP + (r & 15) * WP + (c & 15)];
-    else if (c < r) v = S[c * SP + r];
-    invD[r * NB + c] = v;
   }
 }
 
@@ -186,10 +201,15 @@ void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, in
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, s, Ablk, ld, invD, info, col0);
 }
 
-void potrf_lower(gpmi_ctx* c, hipStream_t s, double* A, int64_t np, int64_t ld, double* invD,
+void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t ld, double* invD,
                  int* info) {
+  // Look-ahead over two streams: the panel stream factors outer panel J+1 while the main stream
+  // still applies the trailing update of panel J to the columns right of it.
+  hipStream_t s = lane.stream, sp = lane.stream2;
   const int nt = (int)(np / NB);
   const int OBT = 4;  // outer panel = 4 inner blocks = 512 columns
+  (void)hipEventRecord(lane.ev_la, s);
+  (void)hipStreamWaitEvent(sp, lane.ev_la, 0);
   for (int J = 0; J < nt; J += OBT) {
     const int Je = (J + OBT < nt) ? J + OBT : nt;
     for (int j = J; j < Je; ++j) {
@@ -197,13 +217,14 @@ void potrf_lower(gpmi_ctx* c, hipStream_t s, double* A, int64_t np, int64_t ld, 
       double* invDj = invD + (int64_t)j * NB * NB;
       const int below = nt - j - 1;
       {
-        ProfScope ps(c, s, GPMI_PROF_PANEL, (double)NB * NB * NB / 3.0 + 2.0 * below * NB * NB * NB,
+        ProfScope ps(c, sp, GPMI_PROF_PANEL,
+                     (double)NB * NB * NB / 3.0 + 2.0 * below * NB * NB * NB,
                      8.0 * NB * NB * (2.0 + 2.0 * below));
-        launch_potrf_diag(s, Ajj, ld, invDj, info, j * NB);
+        launch_potrf_diag(sp, Ajj, ld, invDj, info, j * NB);
         if (below > 0) {
           // panel TRSM: A21 <- A21 * L11^-T  (in place: one tile column, see gemm_f64.hip)
           double* A21 = Ajj + (int64_t)NB * ld;
-          launch_gemm_nt(s, TILES_RECT, OP_ASSIGN, A21, ld, A21, ld, invDj, NB, below, 1, NB);
+          launch_gemm_nt(sp, TILES_RECT, OP_ASSIGN, A21, ld, A21, ld, invDj, NB, below, 1, NB);
         }
       }
       const int pc = Je - j - 1;  // remaining block columns of the outer panel
@@ -212,20 +233,37 @@ void potrf_lower(gpmi_ctx* c, hipStream_t s, double* A, int64_t np, int64_t ld, 
         double* A21 = Ajj + (int64_t)NB * ld;
         double* C = A21 + NB;
         const double tiles = pc * (pc + 1) / 2.0 + (double)(below - pc) * pc;
-        ProfScope ps(c, s, GPMI_PROF_PANEL, tiles * 2.0 * NB * NB * NB, tiles * 16.0 * NB * NB);
-        launch_gemm_nt(s, TILES_LOWER, OP_SUB, C, ld, A21, ld, A21, ld, below, pc, NB);
+        ProfScope ps(c, sp, GPMI_PROF_PANEL, tiles * 2.0 * NB * NB * NB, tiles * 16.0 * NB * NB);
+        launch_gemm_nt(sp, TILES_LOWER, OP_SUB, C, ld, A21, ld, A21, ld, below, pc, NB);
       }
     }
+    (void)hipEventRecord(lane.ev_panel, sp);
+    (void)hipStreamWaitEvent(s, lane.ev_panel, 0);
     const int rem = nt - Je;
     if (rem > 0) {
-      // trailing update: A22 -= P P^T with P = A[Je.., J..Je) (K = (Je - J) * 128), lower tiles only
+      // trailing update A22 -= P P^T, P = A[Je.., J..Je) (K = (Je - J) * 128), lower tiles only, split into
+      // the columns of the next panel (which releases the panel stream) and the rest
       const int kw = (Je - J) * NB;
+      const int la = rem < OBT ? rem : OBT;
       double* P = A + (int64_t)Je * NB * ld + (int64_t)J * NB;
       double* C = A + (int64_t)Je * NB * ld + (int64_t)Je * NB;
-      const double tiles = rem * (rem + 1) / 2.0;
-      ProfScope ps(c, s, GPMI_PROF_SYRK, tiles * 2.0 * NB * NB * kw,
-                   tiles * 16.0 * NB * NB + 8.0 * rem * NB * kw);
-      launch_gemm_nt(s, TILES_LOWER, OP_SUB, C, ld, P, ld, P, ld, rem, rem, kw);
+      {
+        const double tiles = la * (la + 1) / 2.0 + (double)(rem - la) * la;
+        ProfScope ps(c, s, GPMI_PROF_SYRK, tiles * 2.0 * NB * NB * kw,
+                     tiles * 16.0 * NB * NB + 8.0 * rem * NB * kw);
+        launch_gemm_nt(s, TILES_LOWER, OP_SUB, C, ld, P, ld, P, ld, rem, la, kw);
+      }
+      (void)hipEventRecord(lane.ev_la, s);
+      (void)hipStreamWaitEvent(sp, lane.ev_la, 0);
+      const int rest = rem - la;
+      if (rest > 0) {
+        const double tiles = rest * (rest + 1) / 2.0;
+        double* P2 = P + (int64_t)la * NB * ld;
+        double* C2 = C + (int64_t)la * NB * ld + (int64_t)la * NB;
+        ProfScope ps(c, s, GPMI_PROF_SYRK, tiles * 2.0 * NB * NB * kw,
+                     tiles * 16.0 * NB * NB + 8.0 * rest * NB * kw);
+        launch_gemm_nt(s, TILES_LOWER, OP_SUB, C2, ld, P2, ld, P2, ld, rest, rest, kw);
+      }
     }
   }
 }
