@@ -153,6 +153,12 @@ int gpmi_get_L(gpmi_ctx* ctx, double* L_host); /* n x n lower factor, upper tria
 /* ---- leave-one-out (regression.py:451-526) ------------------------------------------ */
 /* diag(K^-1) of the fitted model: var = 1/diag, mu = y - alpha*var on the host (regression.py:460-466) */
 int gpmi_loo_diag(gpmi_ctx* ctx, double* ikdiag_host);
+/* alpha = K^-1 (y - mu) and diag(K^-1) at an arbitrary theta (scratch matrix; the fitted state is not
+ * disturbed): the O(n^3) part of GpRegressor.loo_likelihood (regression.py:468-487); the host forms
+ * -1/2 sum(var alpha^2 + ln var), var = 1/diag.  info != 0 -> the host returns the -1e50 sentinel. */
+int gpmi_loo_terms(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_theta,
+                   double extra_diag, const double* mu_host, double* alpha_host,
+                   double* ikdiag_host, int* info);
 
 /* ---- instrumentation ---------------------------------------------------------------
  * HIP-event timing on the handle's own stream (torch.cuda.Event would not see it). */

@@ -59,6 +59,8 @@ void lane_free(Lane& L) {
   if (L.ev_panel) (void)hipEventDestroy(L.ev_panel);
   if (L.stream2) (void)hipStreamDestroy(L.stream2);
   if (L.A) (void)hipFree(L.A);
+  if (L.B2) (void)hipFree(L.B2);
+  if (L.gws) (void)hipFree(L.gws);
   if (L.invD) (void)hipFree(L.invD);
   if (L.vec) (void)hipFree(L.vec);
   if (L.red) (void)hipFree(L.red);
@@ -147,6 +149,17 @@ int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const dou
   launch_lml_reduce(s, L.vec, L.A, c->ld, c->np, L.red + 2 * slot);
   HIPCHK(c, hipGetLastError());
   return GPMI_OK;
+}
+
+int ensure_second_matrix(gpmi_ctx* c, Lane& L) {
+  if (!L.B2) HIPCHK(c, hipMalloc(&L.B2, sizeof(double) * c->np * c->ld));
+  return GPMI_OK;
+}
+
+// B2 <- L^-T (row j = column j of L^-1), by forward substitution on the identity
+void enqueue_inverse_factor(gpmi_ctx* c, Lane& L, const double* Lmat, const double* invD) {
+  launch_set_identity(L.stream, L.B2, c->ld, c->np);
+  trsm_rows_forward(c, L.stream, Lmat, c->np, c->ld, invD, L.B2, c->np, true);
 }
 
 int ensure_query_ws(gpmi_ctx* c, int64_t mp) {
@@ -386,11 +399,51 @@ int gpmi_lml_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int
   return GPMI_OK;
 }
 
-int gpmi_lml_grad(gpmi_ctx* c, int, const double*, int, double, const double*, double*, double*,
-                  double*, double*, int*) {
+int gpmi_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,
+                  const double* mu, double* lml, double* grad_theta, double* trace_q,
+                  double* alpha_out, int* info) {
   if (!c) return GPMI_ERR_ARG;
-  c->err = "gpmi_lml_grad: not implemented yet";
-  return GPMI_ERR_ARG;
+  KParams p;
+  if (int rc = make_params(c, kernel, theta, n_theta, extra_diag, p)) return rc;
+  ARGCHK(c, mu && lml && grad_theta, "mu / lml / grad_theta is NULL");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = ensure_lanes(c, 2)) return rc;
+  Lane& L = c->lanes[1];
+  if (int rc = ensure_second_matrix(c, L)) return rc;
+  const int64_t need = grad_ws_doubles(c->np, n_theta);
+  if (L.gws_doubles < need) {
+    if (L.gws) (void)hipFree(L.gws);
+    L.gws = nullptr;
+    L.gws_doubles = 0;
+    HIPCHK(c, hipMalloc(&L.gws, sizeof(double) * need));
+    L.gws_doubles = need;
+  }
+  hipStream_t s = L.stream;
+  double* mu_dev = L.vec + 3 * c->np;
+  double* alpha_dev = L.vec + c->np;
+  double* gout = L.red + 16;  // n_theta + 1 values (n_theta <= GPMI_MAX_D + 2)
+  HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
+  if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
+  HIPCHK(c, hipMemcpyAsync(alpha_dev, L.vec, sizeof(double) * c->np, hipMemcpyDeviceToDevice, s));
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, alpha_dev);
+  // K^-1 = L^-T L^-1 (regression.py:556-557), lower tiles, overwriting L
+  enqueue_inverse_factor(c, L, L.A, L.invD);
+  launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, true, L.A, c->ld, L.B2, c->ld, L.B2, c->ld,
+              (int)(c->np / GPMI_NB), (int)(c->np / GPMI_NB), (int)c->np);
+  launch_lml_grad(s, p, n_theta, c->x, c->n, c->np, L.A, c->ld, alpha_dev, L.gws, gout);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(L.h_red + 16, gout, sizeof(double) * (n_theta + 1),
+                           hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (alpha_out)
+    HIPCHK(c, hipMemcpyAsync(alpha_out, alpha_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  *lml = -0.5 * L.h_red[0] - L.h_red[1];
+  for (int j = 0; j < n_theta; ++j) grad_theta[j] = L.h_red[16 + j];
+  if (trace_q) *trace_q = L.h_red[16 + n_theta];
+  if (info) *info = L.h_info[0];
+  return GPMI_OK;
 }
 
 int gpmi_predict(gpmi_ctx* c, const double* pts, int64_t m, double* mu_out, double* var_out) {
@@ -475,10 +528,53 @@ int gpmi_gradient(gpmi_ctx* c, const double*, int64_t, double*, double*) {
   return GPMI_ERR_ARG;
 }
 
-int gpmi_loo_diag(gpmi_ctx* c, double*) {
+int gpmi_loo_diag(gpmi_ctx* c, double* ikdiag) {
   if (!c) return GPMI_ERR_ARG;
-  c->err = "gpmi_loo_diag: not implemented yet";
-  return GPMI_ERR_ARG;
+  ARGCHK(c, c->fitted && ikdiag, "gpmi_loo_diag needs a successful gpmi_fit");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = ensure_lanes(c, 2)) return rc;
+  Lane& F = c->lanes[0];
+  Lane& L = c->lanes[1];
+  if (int rc = ensure_second_matrix(c, L)) return rc;
+  HIPCHK(c, hipStreamSynchronize(F.stream));
+  // diag(K^-1)_a = sum_i (L^-1)_ia^2 = squared norm of row a of L^-T   (regression.py:460-462)
+  enqueue_inverse_factor(c, L, F.A, F.invD);
+  launch_rows_sumsq(L.stream, L.B2, c->ld, c->np, c->np, 0.0, L.vec);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(ikdiag, L.vec, sizeof(double) * c->n, hipMemcpyDeviceToHost, L.stream));
+  HIPCHK(c, hipStreamSynchronize(L.stream));
+  for (int64_t i = 0; i < c->n; ++i) ikdiag[i] = -ikdiag[i];  // rows_sumsq returns base - sum
+  return GPMI_OK;
+}
+
+int gpmi_loo_terms(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,
+                   const double* mu, double* alpha_out, double* ikdiag, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  KParams p;
+  if (int rc = make_params(c, kernel, theta, n_theta, extra_diag, p)) return rc;
+  ARGCHK(c, mu && alpha_out && ikdiag, "mu / alpha / ikdiag is NULL");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = ensure_lanes(c, 2)) return rc;
+  Lane& L = c->lanes[1];
+  if (int rc = ensure_second_matrix(c, L)) return rc;
+  hipStream_t s = L.stream;
+  double* mu_dev = L.vec + 3 * c->np;
+  double* alpha_dev = L.vec + c->np;
+  double* diag_dev = L.vec + 2 * c->np;
+  HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
+  if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
+  HIPCHK(c, hipMemcpyAsync(alpha_dev, L.vec, sizeof(double) * c->np, hipMemcpyDeviceToDevice, s));
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, alpha_dev);
+  enqueue_inverse_factor(c, L, L.A, L.invD);
+  launch_rows_sumsq(s, L.B2, c->ld, c->np, c->np, 0.0, diag_dev);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(alpha_out, alpha_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(ikdiag, diag_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  for (int64_t i = 0; i < c->n; ++i) ikdiag[i] = -ikdiag[i];
+  if (info) *info = L.h_info[0];
+  return GPMI_OK;
 }
 
 int gpmi_covariance(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,

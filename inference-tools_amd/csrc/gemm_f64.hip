@@ -28,7 +28,10 @@ struct GemmArgs {
   const double* B;
   int64_t ldc, lda, ldb;
   int ntr, ntc, k;
+  int kskip;  // TILES_LOWER only: contraction starts at k = ti * 128 (operands are zero before it)
 };
+
+constexpr int LDS_STRIDE_KN = 144;  // B stored k-major: 16 rows of 128 + 16 pad (rows 16 doubles apart mod 32)
 
 // linear workgroup id -> (ti, tj), with an XCD-aware remap: workgroups b and b + 8 run on the same
 // XCD (round-robin dispatch), so each XCD is handed a contiguous chunk of the logical tile list and
@@ -60,7 +63,8 @@ __device__ inline void tile_of(int id, int ntr, int ntc, int& ti, int& tj) {
   }
 }
 
-template <int TILES, int OP>
+// BKN = 0: B is (cols x k), K-contiguous ("NT");  BKN = 1: B is (k x cols), row-major ("NN").
+template <int TILES, int OP, int BKN>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   __shared__ double smem[2 * 2 * TILE_DOUBLES];  // [buffer][A|B][128][18]
   int ti, tj;
@@ -69,18 +73,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const double* __restrict__ Ag = g.A + (int64_t)ti * BM * g.lda;
-  const double* __restrict__ Bg = g.B + (int64_t)tj * BN * g.ldb;
+  const int kbeg = g.kskip ? ti * BM : 0;
+  const double* __restrict__ Ag = g.A + (int64_t)ti * BM * g.lda + kbeg;
+  const double* __restrict__ Bg =
+      BKN ? g.B + (int64_t)kbeg * g.ldb + (int64_t)tj * BN : g.B + (int64_t)tj * BN * g.ldb + kbeg;
 
   // global -> register staging: 4 x 16-byte chunks per operand per thread (8 threads cover a row)
   const int lrow = tid >> 3, lkc = (tid & 7) * 2;
+  const int nrow = tid >> 6, nnc = (tid & 63) * 2;  // k-major B: 64 chunks per k-row
   d2_t ra[4], rb[4];
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = lrow + 32 * i;
       ra[i] = *reinterpret_cast<const d2_t*>(Ag + (int64_t)row * g.lda + k0 + lkc);
-      rb[i] = *reinterpret_cast<const d2_t*>(Bg + (int64_t)row * g.ldb + k0 + lkc);
+      if (BKN)
+        rb[i] = *reinterpret_cast<const d2_t*>(Bg + (int64_t)(k0 + nrow + 4 * i) * g.ldb + nnc);
+      else
+        rb[i] = *reinterpret_cast<const d2_t*>(Bg + (int64_t)row * g.ldb + k0 + lkc);
     }
   };
   auto sstore = [&](int buf) {
@@ -90,7 +100,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     for (int i = 0; i < 4; ++i) {
       const int row = lrow + 32 * i;
       *reinterpret_cast<d2_t*>(sa + row * LDS_STRIDE + lkc) = ra[i];
-      *reinterpret_cast<d2_t*>(sb + row * LDS_STRIDE + lkc) = rb[i];
+      if (BKN)
+        *reinterpret_cast<d2_t*>(sb + (nrow + 4 * i) * LDS_STRIDE_KN + nnc) = rb[i];
+      else
+        *reinterpret_cast<d2_t*>(sb + row * LDS_STRIDE + lkc) = rb[i];
     }
   };
 
@@ -102,12 +115,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 
   const int fr = lane & 15, fk = lane >> 4;
   const int a_off = (wr * 64 + fr) * LDS_STRIDE + fk;
-  const int b_off = (wc * 64 + fr) * LDS_STRIDE + fk;
+  const int b_off = BKN ? fk * LDS_STRIDE_KN + wc * 64 + fr : (wc * 64 + fr) * LDS_STRIDE + fk;
 
   gload(0);
   sstore(0);
   __syncthreads();
-  const int nk = g.k / BK;
+  const int nk = (g.k - kbeg) / BK;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * BK);
@@ -119,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         a[t] = sa[a_off + t * 16 * LDS_STRIDE + q * 4];
-        b[t] = sb[b_off + t * 16 * LDS_STRIDE + q * 4];
+        b[t] = BKN ? sb[b_off + q * 4 * LDS_STRIDE_KN + t * 16] : sb[b_off + t * 16 * LDS_STRIDE + q * 4];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -149,11 +162,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 
 }  // namespace
 
-void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc,
-                    const double* A, int64_t lda, const double* B, int64_t ldb, int ntr, int ntc,
-                    int k) {
+void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, bool kskip, double* C,
+                 int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb, int ntr,
+                 int ntc, int k) {
   if (ntr <= 0 || ntc <= 0 || k <= 0) return;
-  GemmArgs g{C, A, B, ldc, lda, ldb, ntr, ntc, k};
+  GemmArgs g{C, A, B, ldc, lda, ldb, ntr, ntc, k, kskip ? 1 : 0};
   int nwg;
   if (tiles == TILES_RECT) {
     nwg = ntr * ntc;
@@ -162,15 +175,21 @@ void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_
     nwg = ntc * (ntc + 1) / 2 + (ntr - ntc) * ntc;
   }
   dim3 grid((unsigned)nwg), block(256);
+#define GPMI_LAUNCH(T, O, B) hipLaunchKernelGGL((gemm_nt_kernel<T, O, B>), grid, block, 0, s, g)
   if (tiles == TILES_RECT) {
-    if (op == OP_SUB)
-      hipLaunchKernelGGL((gemm_nt_kernel<TILES_RECT, OP_SUB>), grid, block, 0, s, g);
-    else
-      hipLaunchKernelGGL((gemm_nt_kernel<TILES_RECT, OP_ASSIGN>), grid, block, 0, s, g);
+    if (op == OP_SUB) {
+      if (b_kmajor) GPMI_LAUNCH(TILES_RECT, OP_SUB, 1); else GPMI_LAUNCH(TILES_RECT, OP_SUB, 0);
+    } else {
+      if (b_kmajor) GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 1); else GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0);
+    }
   } else {
-    if (op == OP_SUB)
-      hipLaunchKernelGGL((gemm_nt_kernel<TILES_LOWER, OP_SUB>), grid, block, 0, s, g);
-    else
-      hipLaunchKernelGGL((gemm_nt_kernel<TILES_LOWER, OP_ASSIGN>), grid, block, 0, s, g);
+    if (op == OP_SUB) GPMI_LAUNCH(TILES_LOWER, OP_SUB, 0); else GPMI_LAUNCH(TILES_LOWER, OP_ASSIGN, 0);
   }
+#undef GPMI_LAUNCH
+}
+
+void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc,
+                    const double* A, int64_t lda, const double* B, int64_t ldb, int ntr, int ntc,
+                    int k) {
+  launch_gemm(s, tiles, op, false, false, C, ldc, A, lda, B, ldb, ntr, ntc, k);
 }

@@ -39,6 +39,9 @@ struct Lane {
   hipEvent_t ev_la = nullptr, ev_panel = nullptr;
   double* A = nullptr;      // np x ld scratch (K then L)
   double* invD = nullptr;   // (np/128) x 128 x 128 inverses of the diagonal blocks
+  double* B2 = nullptr;     // second np x ld matrix (L^-T for the gradient / LOO paths), allocated lazily
+  double* gws = nullptr;    // gradient partial sums
+  int64_t gws_doubles = 0;
   double* vec = nullptr;    // 4 x np work vectors
   double* red = nullptr;    // small reduction outputs (device)
   int* info = nullptr;      // device info word
@@ -99,6 +102,13 @@ void launch_kbuild_cross(hipStream_t s, const KParams& p, const double* U, int64
                          const double* V, int64_t n, int64_t np, double* out, int64_t ld);
 void launch_add_full(hipStream_t s, double* A, int64_t ld, const double* Y, int64_t n);
 
+// grad.hip: fused contraction 1/2 sum (alpha alpha^T - K^-1) o dK/dtheta_j with dK recomputed from x.
+// out[0..n_theta) = gradient, out[n_theta] = sum_i (alpha_i^2 - K^-1_ii).  iK holds K^-1 (lower tiles).
+int64_t grad_ws_doubles(int64_t np, int n_theta);
+void launch_lml_grad(hipStream_t s, const KParams& p, int n_theta, const double* x, int64_t n,
+                     int64_t np, const double* iK, int64_t ld, const double* alpha, double* ws,
+                     double* out);
+
 // gemm_f64.hip  (all dims multiples of 128, k multiple of 16)
 enum GemmTiles { TILES_RECT = 0, TILES_LOWER = 1 };
 enum GemmOp { OP_SUB = 0, OP_ASSIGN = 1 };
@@ -106,6 +116,11 @@ enum GemmOp { OP_SUB = 0, OP_ASSIGN = 1 };
 void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc,
                     const double* A, int64_t lda, const double* B, int64_t ldb, int ntr, int ntc,
                     int k);
+
+// general form: b_kmajor -> B is (k x cols) row-major; kskip (TILES_LOWER) -> contraction starts at ti*128
+void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, bool kskip, double* C,
+                 int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb, int ntr,
+                 int ntc, int k);
 
 // potrf.hip
 void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0);
@@ -122,7 +137,8 @@ void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int6
                    const double* invD, double* r);
 // Q (mp x np, row-major, ld) <- Q L^-T   (forward solve of mp right-hand sides stored as rows)
 void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                       const double* invD, double* Q, int64_t mp);
+                       const double* invD, double* Q, int64_t mp, bool upper_rhs = false);
+void launch_set_identity(hipStream_t s, double* Q, int64_t ld, int64_t np);
 // r = y - mu (padded with zeros)
 void launch_residual(hipStream_t s, const double* y, const double* mu, double mu_const, double* r,
                      int64_t n, int64_t np);

@@ -77,6 +77,13 @@ __global__ __launch_bounds__(256) void gemv_rowblock_t_kernel(const double* __re
   r[j] -= s;
 }
 
+__global__ void set_identity_kernel(double* __restrict__ Q, int64_t ld, int64_t np) {
+  const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  const int64_t i = blockIdx.y;
+  if (j < np)
+    *reinterpret_cast<d2_t*>(Q + i * ld + j) = d2_t{j == i ? 1.0 : 0.0, j + 1 == i ? 1.0 : 0.0};
+}
+
 __global__ void residual_kernel(const double* __restrict__ y, const double* __restrict__ mu,
                                 double mu_const, double* __restrict__ r, int64_t n, int64_t np) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,10 +194,12 @@ void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int6
 }
 
 void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                       const double* invD, double* Q, int64_t mp) {
-  const int nt = (int)(np / NB), mt = (int)(mp / NB);
+                       const double* invD, double* Q, int64_t mp, bool upper_rhs) {
+  const int nt = (int)(np / NB), mt_all = (int)(mp / NB);
   ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)mp * np * np, 4.0 * np * np);
   for (int k = 0; k < nt; ++k) {
+    // upper_rhs: Q is upper triangular (e.g. the identity): rows below block k are still zero in column k
+    const int mt = upper_rhs ? (k + 1 < mt_all ? k + 1 : mt_all) : mt_all;
     double* Qk = Q + (int64_t)k * NB;
     // Q[:, k] <- Q[:, k] * invD_k^T   (in place, one tile column)
     launch_gemm_nt(s, TILES_RECT, OP_ASSIGN, Qk, ld, Qk, ld, invD + (int64_t)k * NB * NB, NB, mt, 1,
@@ -202,6 +211,11 @@ void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, 
                      L + (int64_t)(k + 1) * NB * ld + (int64_t)k * NB, ld, mt, rem, NB);
     }
   }
+}
+
+void launch_set_identity(hipStream_t s, double* Q, int64_t ld, int64_t np) {
+  dim3 grid((unsigned)((np / 2 + 255) / 256), (unsigned)np);
+  hipLaunchKernelGGL(set_identity_kernel, grid, dim3(256), 0, s, Q, ld, np);
 }
 
 void launch_residual(hipStream_t s, const double* y, const double* mu, double mu_const, double* r,

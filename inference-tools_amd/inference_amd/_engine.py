@@ -130,6 +130,16 @@ class GpEngine:
         self.h.call("gpmi_loo_diag", dptr(out))
         return out
 
+    def loo_terms(self, kernel, theta_cov, extra_diag, mu):
+        theta = as_f64(theta_cov)
+        mu = as_f64(mu)
+        alpha = np.empty(self.n)
+        ikdiag = np.empty(self.n)
+        info = C.c_int(0)
+        self.h.call("gpmi_loo_terms", kernel, dptr(theta), theta.size, float(extra_diag), dptr(mu),
+                    dptr(alpha), dptr(ikdiag), C.byref(info))
+        return alpha, ikdiag, info.value
+
     # -- instrumentation ----------------------------------------------------------------
     def timer_start(self):
         self.h.call("gpmi_timer_start")

@@ -55,6 +55,7 @@ SIGNATURES = {
     "gpmi_get_K": (C.c_int, [_vp, _dp]),
     "gpmi_get_L": (C.c_int, [_vp, _dp]),
     "gpmi_loo_diag": (C.c_int, [_vp, _dp]),
+    "gpmi_loo_terms": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _ip]),
     "gpmi_timer_start": (C.c_int, [_vp]),
     "gpmi_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "gpmi_profile_enable": (C.c_int, [_vp, C.c_int]),

@@ -369,7 +369,16 @@ class GpRegressor:
         return self.y - self.alpha * var, sqrt(var)
 
     def loo_likelihood(self, theta: ndarray) -> float:
-        raise NotImplementedError("loo_likelihood: device path not built yet")
+        """Leave-one-out log-likelihood, R&W eqs. 5.10-5.12 (regression.py:468-487)."""
+        theta = np.asarray(theta, dtype=float)
+        theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
+        mu = self.mean.build_mean(theta[self.mean_slice])
+        alpha, ikdiag, info = self.engine.loo_terms(self._kernel_id, theta_stat, extra, mu)
+        if info != 0:
+            warn("Cholesky decomposition failure in loo_likelihood")
+            return -1e50
+        var = 1.0 / ikdiag
+        return float(-0.5 * (var * alpha**2 + np.log(var)).sum())
 
     def loo_likelihood_gradient(self, theta: ndarray):
         raise NotImplementedError("loo_likelihood_gradient: device path not built yet")

@@ -172,3 +172,86 @@ def test_runs_are_bit_reproducible(gp_mod):
     a1, l1 = gp.alpha.copy(), gp.marginal_likelihood(th)
     gp.set_hyperparameters(th)
     assert np.array_equal(a1, gp.alpha) and l1 == gp.marginal_likelihood(th)
+
+
+# ---------------------------------------------------------------------------------------
+# LML gradient (regression.py:544-567) and leave-one-out (regression.py:451-487)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kid", [("se_", wl.SE), ("rq_", wl.RQ)])
+def test_t32_lml_gradient_and_loo_vs_reference(golden, gp_mod, name, kid):
+    g = golden("t32")
+    th = g[name + "thetas"]
+    gp = gp_mod.GpRegressor(g["x"], g["y"], y_err=g["y_err"], hyperpars=th[0], kernel=kernel_cls(gp_mod, kid))
+    res = [gp.marginal_likelihood_gradient(t) for t in th]
+    check([r[0] for r in res], g[name + "lml_g_val"], what="lml (grad path)")
+    check([r[1] for r in res], g[name + "lml_g_grad"], what="lml gradient")
+    lm, ls = gp.loo_predictions()
+    check(lm, g[name + "loo_mu"], what="loo mu")
+    check(ls, g[name + "loo_sig"], what="loo sigma")
+    check([gp.loo_likelihood(t) for t in th], g[name + "loo"], what="loo likelihood")
+    # the fitted state must be untouched by the scratch-lane evaluations
+    check(gp.alpha, g[name + "alpha"], what="alpha after scratch work")
+    mu, _ = gp(g[name + "pts"])
+    check(mu, g[name + "mu"])
+
+
+def test_t32_white_noise_gradient(golden, gp_mod):
+    g = golden("t32")
+    th = g["sewn_theta"]
+    gp = gp_mod.GpRegressor(
+        g["x"], g["y"], y_err=g["y_err"], hyperpars=th, kernel=gp_mod.SquaredExponential() + gp_mod.WhiteNoise()
+    )
+    v, grad = gp.marginal_likelihood_gradient(th)
+    check(v, g["sewn_lml_g_val"])
+    check(grad, g["sewn_lml_g_grad"], what="gradient incl. WhiteNoise parameter")
+
+
+@pytest.mark.parametrize("case", ["cfg1", "rq256", "cfg4"])
+def test_config_lml_gradient_golden(golden, gp_mod, case):
+    g = golden(case)
+    cfg, kid, n, d = [int(v) for v in g["meta"]]
+    x, y, e = wl.synthetic_dataset(cfg, n, d)
+    th = g["thetas"]
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=th[0], kernel=kernel_cls(gp_mod, kid))
+    k = min(len(th), 4)
+    res = [gp.marginal_likelihood_gradient(t) for t in th[:k]]
+    check([r[0] for r in res], g["lml_g_val"][:k], what="lml")
+    # gradient components: relative to the largest component of each gradient vector
+    for r, ref in zip(res, g["lml_g_grad"][:k]):
+        check(r[1], ref, 1e-9, what="lml gradient")
+
+
+def test_lml_gradient_matches_finite_differences(gp_mod):
+    """The reference's own property test (tests/gp/test_GpRegressor.py:61-76) on the device path."""
+    rng = np.random.default_rng(1)
+    points = rng.uniform(low=0.0, high=2.0, size=(32, 2))
+    values = np.sin(points[:, 0]) * np.cos(points[:, 1]) + rng.normal(scale=0.1, size=32)
+    gp = gp_mod.GpRegressor(points, values, y_err=np.full(32, 0.1), hyperpars=np.array([0.0, -0.5, 0.5, 0.5]))
+    trng = np.random.default_rng(123)
+    for theta in trng.uniform(low=[-0.3, -1.5, 0.1, 0.1], high=[0.3, 0.5, 1.5, 1.5], size=[10, 4]):
+        _, grad = gp.marginal_likelihood_gradient(theta)
+        fd = np.zeros(4)
+        for i in range(4):
+            dx = theta[i] * 1e-5
+            t1, t2 = theta.copy(), theta.copy()
+            t1[i] -= dx
+            t2[i] += dx
+            fd[i] = 0.5 * (gp.marginal_likelihood(t2) - gp.marginal_likelihood(t1)) / dx
+        assert abs(fd / grad - 1.0).max() < 1e-5
+
+
+def test_hyperparameter_search_bfgs_and_diffev(gp_mod):
+    """tests/gp/test_GpRegressor.py:147-151: the optimisers run end to end on the device objective
+    and land on a hyper-parameter vector at least as good as the oracle's fit from the same start."""
+    rng = np.random.default_rng(1)
+    points = rng.uniform(low=0.0, high=2.0, size=(32, 2))
+    values = np.sin(points[:, 0]) * np.cos(points[:, 1]) + rng.normal(scale=0.1, size=32)
+    errs = np.full(32, 0.1)
+    np.random.seed(3)
+    gp = gp_mod.GpRegressor(points, values, y_err=errs, optimizer="bfgs", n_starts=4)
+    centre = np.array([0.5 * (a + b) for a, b in gp.hp_bounds])
+    assert gp.marginal_likelihood(gp.hyperpars) >= gp.marginal_likelihood(centre) - 1e-9
+    gp2 = gp_mod.GpRegressor(points, values, y_err=errs, optimizer="diffev")
+    assert abs(gp2.marginal_likelihood(gp2.hyperpars) - gp.marginal_likelihood(gp.hyperpars)) < 1e-3
+    mu, sig = gp(points)
+    assert np.isfinite(mu).all() and np.isfinite(sig).all()
