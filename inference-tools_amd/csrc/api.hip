@@ -174,8 +174,9 @@ int ensure_query_ws(gpmi_ctx* c, int64_t mp) {
   fr(c->pvec);
   c->mq_cap = 0;
   HIPCHK(c, hipMalloc(&c->Q, sizeof(double) * mp * c->ld));
+  HIPCHK(c, hipMalloc(&c->Q2, sizeof(double) * mp * c->ld));
   HIPCHK(c, hipMalloc(&c->pts, sizeof(double) * mp * c->d));
-  HIPCHK(c, hipMalloc(&c->pvec, sizeof(double) * mp * (2 + 2 * c->d)));
+  HIPCHK(c, hipMalloc(&c->pvec, sizeof(double) * mp * (2 + 2 * c->d + c->d * c->d)));
   c->mq_cap = mp;
   return GPMI_OK;
 }
@@ -516,16 +517,70 @@ int gpmi_posterior(gpmi_ctx* c, const double* pts, int64_t m, double* mu_out, do
   return GPMI_OK;
 }
 
-int gpmi_spatial_derivatives(gpmi_ctx* c, const double*, int64_t, double*, double*) {
+int gpmi_spatial_derivatives(gpmi_ctx* c, const double* pts, int64_t m, double* dmu_out,
+                             double* dvar_out) {
   if (!c) return GPMI_ERR_ARG;
-  c->err = "gpmi_spatial_derivatives: not implemented yet";
-  return GPMI_ERR_ARG;
+  ARGCHK(c, c->fitted, "gpmi_spatial_derivatives needs a successful gpmi_fit");
+  ARGCHK(c, c->fit_params.kernel == GPMI_KERNEL_SE, "spatial derivatives: SquaredExponential only");
+  ARGCHK(c, pts && m > 0 && dmu_out && dvar_out, "NULL argument or m <= 0");
+  if (int rc = set_device(c)) return rc;
+  Lane& L = c->lanes[0];
+  hipStream_t s = L.stream;
+  KParams p = c->fit_params;
+  const int64_t chunk = 1024, d = c->d;
+  for (int64_t m0 = 0; m0 < m; m0 += chunk) {
+    const int64_t mc = (m - m0 < chunk) ? m - m0 : chunk;
+    const int64_t mp = round_up(mc, GPMI_NB);
+    if (int rc = ensure_query_ws(c, mp)) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->pts, pts + m0 * d, sizeof(double) * mc * d, hipMemcpyHostToDevice, s));
+    launch_kbuild_cross(s, p, c->pts, mc, mp, c->x, c->n, c->np, c->Q, c->ld);
+    HIPCHK(c, hipMemcpyAsync(c->Q2, c->Q, sizeof(double) * mp * c->ld, hipMemcpyDeviceToDevice, s));
+    // Z = K^-1 k per row: forward then backward solve (regression.py:410)
+    trsm_rows_forward(c, s, L.A, c->np, c->ld, L.invD, c->Q2, mp);
+    trsm_rows_backward(c, s, L.A, c->np, c->ld, L.invD, c->Q2, mp);
+    double* dmu_dev = c->pvec;
+    double* dvar_dev = c->pvec + mp * d;
+    launch_sd_reduce(s, p, c->x, c->n, c->pts, mc, c->Q, c->ld, c->alpha, 0, 1.0, dmu_dev);
+    launch_sd_reduce(s, p, c->x, c->n, c->pts, mc, c->Q, c->ld, c->Q2, c->ld, -2.0, dvar_dev);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(dmu_out + m0 * d, dmu_dev, sizeof(double) * mc * d, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(dvar_out + m0 * d, dvar_dev, sizeof(double) * mc * d, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+  }
+  return GPMI_OK;
 }
 
-int gpmi_gradient(gpmi_ctx* c, const double*, int64_t, double*, double*) {
+int gpmi_gradient(gpmi_ctx* c, const double* pts, int64_t m, double* gmu_out, double* gcov_out) {
   if (!c) return GPMI_ERR_ARG;
-  c->err = "gpmi_gradient: not implemented yet";
-  return GPMI_ERR_ARG;
+  ARGCHK(c, c->fitted, "gpmi_gradient needs a successful gpmi_fit");
+  ARGCHK(c, c->fit_params.kernel == GPMI_KERNEL_SE, "gradient: SquaredExponential only");
+  ARGCHK(c, pts && m > 0 && gmu_out && gcov_out, "NULL argument or m <= 0");
+  if (int rc = set_device(c)) return rc;
+  Lane& L = c->lanes[0];
+  hipStream_t s = L.stream;
+  KParams p = c->fit_params;
+  const int64_t d = c->d;
+  int64_t chunk = 1024 / d;  // d right-hand sides per point
+  if (chunk < 1) chunk = 1;
+  for (int64_t m0 = 0; m0 < m; m0 += chunk) {
+    const int64_t mc = (m - m0 < chunk) ? m - m0 : chunk;
+    const int64_t rp = round_up(mc * d, GPMI_NB);
+    if (int rc = ensure_query_ws(c, rp)) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->pts, pts + m0 * d, sizeof(double) * mc * d, hipMemcpyHostToDevice, s));
+    launch_kbuild_cross(s, p, c->pts, mc, round_up(mc, GPMI_NB), c->x, c->n, c->np, c->Q, c->ld);
+    double* gmu_dev = c->pvec;
+    double* gcov_dev = c->pvec + rp;
+    launch_sd_reduce(s, p, c->x, c->n, c->pts, mc, c->Q, c->ld, c->alpha, 0, 1.0, gmu_dev);
+    launch_grad_rhs(s, p, c->x, c->n, c->np, c->pts, mc * d, rp, c->Q, c->ld, c->Q2);
+    trsm_rows_forward(c, s, L.A, c->np, c->ld, L.invD, c->Q2, rp);
+    launch_grad_cov(s, p, c->Q2, c->ld, c->np, mc, gcov_dev);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(gmu_out + m0 * d, gmu_dev, sizeof(double) * mc * d, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(gcov_out + m0 * d * d, gcov_dev, sizeof(double) * mc * d * d,
+                             hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+  }
+  return GPMI_OK;
 }
 
 int gpmi_loo_diag(gpmi_ctx* c, double* ikdiag) {

@@ -151,3 +151,17 @@ void launch_rows_dot(hipStream_t s, const double* Q, int64_t ld, int64_t mp, int
 // out[m] = base - sum_n Q[m][n]^2
 void launch_rows_sumsq(hipStream_t s, const double* Q, int64_t ld, int64_t mp, int64_t np,
                        double base, double* out);
+
+// Q (mp x np) <- Q L^-1   (backward solve of mp right-hand sides stored as rows)
+void trsm_rows_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
+                        const double* invD, double* Q, int64_t mp);
+
+// predgrad.hip
+void launch_sd_reduce(hipStream_t s, const KParams& p, const double* x, int64_t n, const double* pts,
+                      int64_t m, const double* Kq, int64_t ld, const double* W, int64_t ldw,
+                      double scale, double* out);
+void launch_grad_rhs(hipStream_t s, const KParams& p, const double* x, int64_t n, int64_t np,
+                     const double* pts, int64_t rows_valid, int64_t rows_padded, const double* Kq,
+                     int64_t ld, double* G);
+void launch_grad_cov(hipStream_t s, const KParams& p, const double* G, int64_t ld, int64_t np,
+                     int64_t m, double* cov);

@@ -213,6 +213,22 @@ void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, 
   }
 }
 
+void trsm_rows_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
+                        const double* invD, double* Q, int64_t mp) {
+  const int nt = (int)(np / NB), mt = (int)(mp / NB);
+  ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)mp * np * np, 4.0 * np * np);
+  for (int k = nt - 1; k >= 0; --k) {
+    double* Qk = Q + (int64_t)k * NB;
+    // Q[:, k] <- Q[:, k] * invD_k          (B = invD_k is k-major here)
+    launch_gemm(s, TILES_RECT, OP_ASSIGN, true, false, Qk, ld, Qk, ld, invD + (int64_t)k * NB * NB,
+                NB, mt, 1, NB);
+    // Q[:, 0:k] -= Q[:, k] * L[k, 0:k]     (B = block row k of L, k-major)
+    if (k > 0)
+      launch_gemm(s, TILES_RECT, OP_SUB, true, false, Q, ld, Qk, ld, L + (int64_t)k * NB * ld, ld, mt,
+                  k, NB);
+  }
+}
+
 void launch_set_identity(hipStream_t s, double* Q, int64_t ld, int64_t np) {
   dim3 grid((unsigned)((np / 2 + 255) / 256), (unsigned)np);
   hipLaunchKernelGGL(set_identity_kernel, grid, dim3(256), 0, s, Q, ld, np);

@@ -1,4 +1,10 @@
 from inference_amd.gp.regression import GpRegressor
+from inference_amd.gp.optimisation import GpOptimiser
+from inference_amd.gp.acquisition import (
+    ExpectedImprovement,
+    UpperConfidenceBound,
+    MaxVariance,
+)
 from inference_amd.gp.mean import ConstantMean, LinearMean, QuadraticMean
 from inference_amd.gp.covariance import (
     SquaredExponential,
@@ -8,6 +14,10 @@ from inference_amd.gp.covariance import (
 
 __all__ = [
     "GpRegressor",
+    "GpOptimiser",
+    "ExpectedImprovement",
+    "UpperConfidenceBound",
+    "MaxVariance",
     "ConstantMean",
     "LinearMean",
     "QuadraticMean",

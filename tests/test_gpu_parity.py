@@ -255,3 +255,105 @@ def test_hyperparameter_search_bfgs_and_diffev(gp_mod):
     assert abs(gp2.marginal_likelihood(gp2.hyperpars) - gp.marginal_likelihood(gp.hyperpars)) < 1e-3
     mu, sig = gp(points)
     assert np.isfinite(mu).all() and np.isfinite(sig).all()
+
+
+# ---------------------------------------------------------------------------------------
+# spatial gradients (regression.py:351-419) and acquisition functions (acquisition.py:44-232)
+# ---------------------------------------------------------------------------------------
+def test_t32_spatial_gradients_vs_reference(golden, gp_mod):
+    g = golden("t32")
+    gp = gp_mod.GpRegressor(g["x"], g["y"], y_err=g["y_err"], hyperpars=g["se_thetas"][0])
+    pts = g["se_pts"]
+    gm, gc = gp.gradient(pts[:16])
+    check(gm, g["se_grad_mu"], what="gradient mean")
+    check(gc, g["se_grad_cov"], what="gradient covariance")
+    sm, sv = gp.spatial_derivatives(pts[:16])
+    check(sm, g["se_sd_mu"], what="d mu / dx")
+    check(sv, g["se_sd_var"], what="d var / dx")
+    # 1-D input: squeezed shapes (regression.py:385, 419)
+    gp1 = gp_mod.GpRegressor(g["d1_x"], g["d1_y"], y_err=g["d1_err"], hyperpars=g["d1_theta"])
+    gm, gc = gp1.gradient(g["d1_pts"])
+    assert gm.shape == g["d1_grad_mu"].shape and gc.shape == g["d1_grad_cov"].shape
+    check(gm, g["d1_grad_mu"])
+    check(gc, g["d1_grad_cov"])
+    sm, sv = gp1.spatial_derivatives(g["d1_pts"])
+    check(sm, g["d1_sd_mu"])
+    check(sv, g["d1_sd_var"])
+    # RationalQuadratic has no gradient_terms: same NotImplementedError as the reference
+    gq = gp_mod.GpRegressor(g["x"], g["y"], y_err=g["y_err"], hyperpars=g["rq_thetas"][0], kernel=gp_mod.RationalQuadratic)
+    with pytest.raises(NotImplementedError):
+        gq.gradient(pts[:2])
+    with pytest.raises(NotImplementedError):
+        gq.spatial_derivatives(pts[:2])
+
+
+@pytest.mark.parametrize("nm", ["ei", "ucb", "mv"])
+def test_t32_acquisition_vs_reference(golden, gp_mod, nm):
+    g = golden("t32")
+    gp = gp_mod.GpRegressor(g["x"], g["y"], y_err=g["y_err"], hyperpars=g["se_thetas"][0])
+    acq = {"ei": gp_mod.ExpectedImprovement, "ucb": gp_mod.UpperConfidenceBound, "mv": gp_mod.MaxVariance}[nm]()
+    acq.update_gp(gp)
+    pts = g["se_pts"]
+    check([acq(p) for p in pts[:6]], g[f"se_{nm}_call"][:6], what="__call__")
+    check(acq.call_batch(pts), g[f"se_{nm}_call"], what="call_batch")
+    check([acq.opt_func(p) for p in pts[:6]], g[f"se_{nm}_opt"][:6], what="opt_func")
+    check(acq.opt_func_batch(pts), g[f"se_{nm}_opt"], what="opt_func_batch")
+    val, grad = acq.opt_func_gradient_batch(pts)
+    check(val, g[f"se_{nm}_optg_val"], what="opt_func_gradient value")
+    check(grad, g[f"se_{nm}_optg_grad"], 1e-9, what="opt_func_gradient gradient")
+    v1, g1 = acq.opt_func_gradient(pts[3])
+    check(float(v1), g[f"se_{nm}_optg_val"][3])
+    check(g1, g[f"se_{nm}_optg_grad"][3], 1e-9)
+    check([acq.convergence_metric(p) for p in pts[:4]], g[f"se_{nm}_conv"], what="convergence metric")
+
+
+def test_cfg4_expected_improvement_1000_candidates(golden, gp_mod):
+    """BASELINE config 4: N=4096, d=4, 1000 EI candidates in one batched evaluation, both branches
+    of the Z < -3 switch (acquisition.py:79, 91, 104)."""
+    g = golden("cfg4")
+    x, y, e = wl.synthetic_dataset(4, 4096, 4)
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=g["thetas"][0])
+    ei = gp_mod.ExpectedImprovement()
+    ei.update_gp(gp)
+    check(ei.mu_max, g["mu_max"], 0.0)
+    check(ei.call_batch(g["cand"]), g["ei_call"], 1e-9, "EI")
+    check(ei.opt_func_batch(g["cand"]), g["ei_opt"], 1e-9, "-ln EI")
+    val, grad = ei.opt_func_gradient_batch(g["cand"][:200])
+    check(val, g["ei_optg_val"], 1e-9)
+    check(grad, g["ei_optg_grad"], 1e-8, "grad -ln EI")
+    ei.mu_max = float(g["ei_far_mu_max"])  # forces Z < -3
+    check(ei.call_batch(g["cand"][:200]), g["ei_far_call"], 1e-9, "EI (Z < -3)")
+    check(ei.opt_func_batch(g["cand"][:200]), g["ei_far_opt"], 1e-9)
+    val, grad = ei.opt_func_gradient_batch(g["cand"][:200])
+    check(val, g["ei_far_optg_val"], 1e-9)
+    check(grad, g["ei_far_optg_grad"], 1e-8)
+
+
+@pytest.mark.parametrize("acq", ["ei", "ucb", "mv"])
+def test_gp_optimiser_loop(gp_mod, acq):
+    """tests/gp/test_GpOptimiser.py:21-68 of the reference: propose / add iterations stay in bounds."""
+    acquisition = {"ei": gp_mod.ExpectedImprovement, "ucb": gp_mod.UpperConfidenceBound, "mv": gp_mod.MaxVariance}[acq]
+
+    def objective(x):
+        return np.sin(0.5 * x[0]) * 3 / (2 + 0.5 * (x[1] - 1.0) ** 2) + 0.1 * x[0]
+
+    rng = np.random.default_rng(4)
+    bounds = [(-4.0, 6.0), (-3.0, 5.0)]
+    x = rng.uniform([b[0] for b in bounds], [b[1] for b in bounds], size=(8, 2))
+    y = np.array([objective(k) for k in x])
+    np.random.seed(11)
+    opt = gp_mod.GpOptimiser(x, y, bounds=bounds, acquisition=acquisition)
+    for _ in range(3):
+        new_x = opt.propose_evaluation()
+        assert len(new_x) == 2
+        assert all(b[0] <= v <= b[1] for v, b in zip(new_x, bounds))
+        opt.add_evaluation(new_x, objective(new_x))
+    assert opt.y.size == 11 and len(opt.iteration_history) == 3
+    # 1-D problem with errors and the differential-evolution proposal path
+    x1 = np.linspace(-3, 3, 7)
+    y1 = np.cos(x1) + 0.1 * x1
+    opt1 = gp_mod.GpOptimiser(x1, y1, bounds=[(-4.0, 4.0)], y_err=np.full(7, 0.05), acquisition=acquisition)
+    nx = opt1.propose_evaluation(optimizer="diffev")
+    assert -4.0 <= float(nx) <= 4.0
+    opt1.add_evaluation(nx, np.cos(nx) + 0.1 * nx, new_y_err=0.05)
+    assert opt1.y.size == 8
