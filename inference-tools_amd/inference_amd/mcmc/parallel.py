@@ -1,0 +1,166 @@
+"""
+`ParallelTempering` — counterpart of `inference.mcmc.parallel.ParallelTempering`
+(reference: inference/mcmc/parallel.py:69-384): a ladder of chains at increasing
+temperature which periodically propose pairwise position swaps.
+
+Same class surface (`take_steps`, `swap`, `advance`, `run_for`, `tight_pairs`,
+`uniform_pairs`, `return_chains`, `shutdown`, swap counters) and the same swap
+rule, U <= exp(-(b_i - b_j)(p_i / b_i - p_j / b_j)) with the swapped log-probability
+re-tempered by the receiving chain (parallel.py:207-231, :62).
+
+Mechanism differs: the reference spawns one OS process per chain and talks to it
+over pipes (parallel.py:127-136); here the chains live in this process and advance
+in lockstep so that each proposal round of the whole ladder is one batched
+log-marginal-likelihood evaluation on the GPU.  Several ladders are advanced
+together by `advance_ladders`; ladders are the unit sharded over GPUs (every swap
+stays GPU-local, nothing but the final samples is gathered).
+`swap_diagnostics` (matplotlib) is out of scope.
+"""
+import sys
+from random import choice
+from time import time
+from warnings import warn
+
+from numpy import arange, exp, identity, zeros
+from numpy.random import default_rng
+
+from inference_amd.mcmc.gibbs import advance_lockstep
+
+
+def _common_batch_posterior(chains):
+    """If every chain's posterior is `marginal_likelihood` of one device-backed GpRegressor,
+    return its batched form."""
+    owner = None
+    for ch in chains:
+        fn = getattr(ch, "posterior", None)
+        obj = getattr(fn, "__self__", None)
+        if obj is None or getattr(fn, "__name__", "") != "marginal_likelihood":
+            return None
+        if not hasattr(obj, "marginal_likelihood_batch") or (owner is not None and obj is not owner):
+            return None
+        owner = obj
+    return owner.marginal_likelihood_batch if owner is not None else None
+
+
+class ParallelTempering:
+    """
+    :param chains: chain objects (e.g. `GibbsChain`) sorted by increasing temperature.
+    :param batch_posterior: optional `thetas (B, P) -> (B,)` batched form of the chains'
+        posterior; detected automatically for `GpRegressor.marginal_likelihood`.
+    """
+
+    def __init__(self, chains, batch_posterior=None):
+        self.rng = default_rng()
+        self.chains = list(chains)
+        self.temperatures = [1.0 / chain.inv_temp for chain in self.chains]
+        self.inv_temps = [chain.inv_temp for chain in self.chains]
+        self.N_chains = len(self.chains)
+        self.attempted_swaps = identity(self.N_chains)
+        self.successful_swaps = zeros([self.N_chains, self.N_chains])
+        self.batch_posterior = batch_posterior or _common_batch_posterior(self.chains)
+        self.posterior_evaluations = 0
+        if sorted(self.temperatures) != self.temperatures:
+            warn(
+                """
+                The list of Markov-chain objects passed to ParallelTempering
+                should be sorted in order of increasing chain temperature.
+                """
+            )
+
+    def take_steps(self, n: int):
+        """Advance all the chains `n` steps without performing any swaps."""
+        if self.batch_posterior is not None:
+            self.posterior_evaluations += advance_lockstep(self.chains, n, self.batch_posterior)
+        else:
+            for chain in self.chains:
+                for _ in range(n):
+                    chain.take_step()
+
+    def uniform_pairs(self):
+        proposed = arange(self.N_chains)
+        self.rng.shuffle(proposed)
+        return list(zip(proposed[::2], proposed[1::2]))
+
+    def tight_pairs(self):
+        """Random pairing with almost all pairs 1 or 2 temperature levels apart
+        (parallel.py:162-188; uses the stdlib `random.choice` and the NumPy generator)."""
+        pairs = [(i, i + j) for i in range(self.N_chains - 1) for j in [1, 2]][:-1]
+        sample = []
+        while len(pairs) > 0:
+            p = choice(pairs)
+            pairs = [k for k in pairs if not any(j in k for j in p)]
+            sample.append(p)
+        remaining = len(sample) - self.N_chains // 2
+        if remaining != 0:
+            leftovers = [i for i in range(self.N_chains) if not any(i in p for p in sample)]
+            self.rng.shuffle(leftovers)
+            sample.extend(
+                [p if p[0] < p[1] else (p[1], p[0]) for p in zip(leftovers[::2], leftovers[1::2])]
+            )
+        return sample
+
+    def swap(self):
+        """Propose a position swap between randomly paired chains (parallel.py:190-231)."""
+        positions = [chain.get_last() for chain in self.chains]
+        probabilities = [chain.probs[-1] for chain in self.chains]
+        proposed_swaps = self.tight_pairs()
+        for pair in proposed_swaps:
+            self.attempted_swaps[pair] += 1
+        for i, j in proposed_swaps:
+            dt = self.inv_temps[i] - self.inv_temps[j]
+            pi = probabilities[i] / self.inv_temps[i]
+            pj = probabilities[j] / self.inv_temps[j]
+            dp = pi - pj
+            if self.rng.random() <= exp(-dt * dp):
+                self.chains[i].replace_last(positions[j])
+                self.chains[i].probs[-1] = pj * self.chains[i].inv_temp
+                self.chains[j].replace_last(positions[i])
+                self.chains[j].probs[-1] = pi * self.chains[j].inv_temp
+                self.successful_swaps[i, j] += 1
+
+    def advance(self, n: int, swap_interval=10, display_progress=False):
+        """Advance each chain by `n` steps with swap attempts every `swap_interval` steps."""
+        total_cycles = n // swap_interval
+        t_start = time()
+        for j in range(total_cycles):
+            self.take_steps(swap_interval)
+            self.swap()
+            if display_progress:
+                pct = int(100 * (j + 1) / total_cycles)
+                eta = int((time() - t_start) * (total_cycles / (j + 1) - 1))
+                sys.stdout.write(f"\r  [ Running ParallelTempering - {pct}% complete   ETA: {eta} sec ]    ")
+                sys.stdout.flush()
+        if n % swap_interval != 0:
+            self.take_steps(n % swap_interval)
+        if display_progress:
+            sys.stdout.write("\r  [ Running ParallelTempering - complete! ]                    \n")
+
+    def run_for(self, minutes=0, hours=0, swap_interval=10):
+        end_time = time() + (hours * 60.0 + minutes) * 60.0
+        while time() < end_time:
+            self.take_steps(swap_interval)
+            self.swap()
+
+    def return_chains(self):
+        return self.chains
+
+    def shutdown(self):
+        """Nothing to stop: there are no worker processes."""
+
+
+def advance_ladders(ladders, n: int, swap_interval=10, batch_posterior=None):
+    """Advance several ParallelTempering ladders together: all chains of all ladders propose in
+    lockstep (one batched device evaluation per proposal round), then every ladder performs its own
+    swaps.  This is the per-GPU unit of config 5 (whole ladders per GPU, swaps GPU-local)."""
+    bp = batch_posterior or ladders[0].batch_posterior
+    if bp is None:
+        raise ValueError("advance_ladders needs a batched posterior")
+    chains = [c for lad in ladders for c in lad.chains]
+    evals = 0
+    for _ in range(n // swap_interval):
+        evals += advance_lockstep(chains, swap_interval, bp)
+        for lad in ladders:
+            lad.swap()
+    if n % swap_interval:
+        evals += advance_lockstep(chains, n % swap_interval, bp)
+    return evals

@@ -248,7 +248,67 @@ def case_fail():
     return out
 
 
+def pt_problem():
+    """Small GP whose log-marginal likelihood is the chains' posterior (shared with the tests)."""
+    rng = np.random.default_rng(31)
+    x = np.sort(rng.uniform(0, 6, 48))
+    y = np.sin(x) + 0.3 * np.cos(2.5 * x) + 0.2 * rng.normal(size=48)
+    y_err = np.full(48, 0.2)
+    start = np.array([y.mean(), np.log(y.std()), np.log(1.0)])
+    widths = np.array([0.1, 0.2, 0.2])
+    return x, y, y_err, start, widths
+
+
+def case_pt():
+    """Teacher-forced traces of GibbsChain (gibbs.py:627-656) and ParallelTempering
+    (parallel.py:190-281): every generator is seeded by assignment after construction, the chains'
+    posterior is the reference GpRegressor.marginal_likelihood."""
+    import random
+    from numpy.random import default_rng
+    from inference.mcmc import GibbsChain, ParallelTempering
+
+    out = {}
+    x, y, y_err, start, widths = pt_problem()
+    gp = GpRegressor(x, y, y_err=y_err, hyperpars=start)
+    bounds = gp.hp_bounds
+    out["hp_bounds"] = np.array(bounds, dtype=float)
+
+    def make_chain(temp, seed, progress=True):
+        # display_progress=False makes the reference chain unpicklable (return_chains then fails)
+        ch = GibbsChain(posterior=gp.marginal_likelihood, start=start, widths=widths, temperature=temp,
+                        display_progress=progress)
+        for i, b in enumerate(bounds):
+            ch.set_boundaries(i, b)
+        ch.rng = default_rng(seed)
+        for i, par in enumerate(ch.params):
+            par.rng = default_rng(seed + 1 + i)
+        return ch
+
+    ch = make_chain(1.0, 100)
+    ch.advance(60)
+    out["single_samples"] = ch.get_sample(burn=0)
+    out["single_probs"] = np.array(ch.probs)
+    out["single_sigmas"] = np.array([par.sigma for par in ch.params])
+
+    temps = [1.0, 2.0, 4.0, 8.0]
+    chains = [make_chain(t, 1000 + 10 * k) for k, t in enumerate(temps)]
+    pt = ParallelTempering(chains)
+    pt.rng = default_rng(7)
+    random.seed(9)
+    pt.advance(40, swap_interval=5)
+    got = pt.return_chains()
+    pt.shutdown()
+    out["temps"] = np.array(temps)
+    for k, c in enumerate(got):
+        out[f"pt_samples_{k}"] = c.get_sample(burn=0)
+        out[f"pt_probs_{k}"] = np.array(c.probs)
+    out["pt_successful"] = pt.successful_swaps
+    out["pt_attempted"] = pt.attempted_swaps
+    return out
+
+
 CASES = {
+    "pt": case_pt,
     "t32": case_t32,
     "cfg1": case_cfg1,
     "rq256": case_rq256,

@@ -357,3 +357,72 @@ def test_gp_optimiser_loop(gp_mod, acq):
     assert -4.0 <= float(nx) <= 4.0
     opt1.add_evaluation(nx, np.cos(nx) + 0.1 * nx, new_y_err=0.05)
     assert opt1.y.size == 8
+
+
+# ---------------------------------------------------------------------------------------
+# MCMC callers on the device posterior (configs 3 and 5)
+# ---------------------------------------------------------------------------------------
+def _pt_problem():
+    rng = np.random.default_rng(31)
+    x = np.sort(rng.uniform(0, 6, 48))
+    y = np.sin(x) + 0.3 * np.cos(2.5 * x) + 0.2 * rng.normal(size=48)
+    return x, y, np.full(48, 0.2), np.array([y.mean(), np.log(y.std()), np.log(1.0)]), np.array([0.1, 0.2, 0.2])
+
+
+def test_parallel_tempering_on_device_reproduces_reference_trace(golden, gp_mod):
+    """Teacher-forced ParallelTempering (parallel.py:190-281) over GibbsChains whose posterior is the
+    DEVICE marginal_likelihood, advanced in lockstep (batched LML evaluations): same accept / swap
+    decisions and sample paths as the reference's process-per-chain run."""
+    import random
+    from numpy.random import default_rng
+    from inference_amd.mcmc import GibbsChain, ParallelTempering
+
+    g = golden("pt")
+    x, y, e, start, widths = _pt_problem()
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=start)
+    gp.engine.set_streams(4)
+    check(np.array(gp.hp_bounds), g["hp_bounds"], 1e-12)
+
+    def make_chain(temp, seed):
+        ch = GibbsChain(posterior=gp.marginal_likelihood, start=start, widths=widths, temperature=temp)
+        for i, b in enumerate(gp.hp_bounds):
+            ch.set_boundaries(i, b)
+        ch.rng = default_rng(seed)
+        for i, par in enumerate(ch.params):
+            par.rng = default_rng(seed + 1 + i)
+        return ch
+
+    ch = make_chain(1.0, 100)
+    ch.advance(60)
+    assert np.allclose(ch.get_sample(burn=0), g["single_samples"], rtol=0, atol=1e-8)
+    check(np.array(ch.probs), g["single_probs"], 1e-10)
+
+    chains = [make_chain(t, 1000 + 10 * k) for k, t in enumerate(g["temps"])]
+    pt = ParallelTempering(chains)
+    assert pt.batch_posterior is not None  # detected GpRegressor.marginal_likelihood -> batched lockstep
+    pt.rng = default_rng(7)
+    random.seed(9)
+    pt.advance(40, swap_interval=5)
+    for k, c in enumerate(pt.return_chains()):
+        assert np.allclose(c.get_sample(burn=0), g[f"pt_samples_{k}"], rtol=0, atol=1e-8), k
+        check(np.array(c.probs), g[f"pt_probs_{k}"], 1e-10)
+    assert np.array_equal(pt.successful_swaps, g["pt_successful"])
+    assert pt.posterior_evaluations >= 4 * 40 * 3
+
+
+def test_sweep_single_rank(gp_mod):
+    """Config 3 shape at reduced size: RQ, d = 16, an 8 x 8 theta grid through the sharded sweep
+    (one rank here; the 2-rank gather is covered by tests/test_sharding_cpu.py)."""
+    from inference_amd import sharding
+    from oracle import gp_oracle as orc
+
+    x, y, e = wl.synthetic_dataset(3, 384, 16)
+    grid = wl.theta_grid_cfg3(y, 16)
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=grid[0], kernel=gp_mod.RationalQuadratic)
+    gp.engine.set_streams(4)
+    vals = sharding.marginal_likelihood_sweep(gp, grid)
+    ref = orc.OracleGp(x, y, e, kernel=orc.RQ)
+    want = np.array([ref.marginal_likelihood(t) for t in grid])
+    check(vals, want, what="64-point RQ sweep")
+    # a checksum of the sweep is invariant under the order in which streams finish
+    assert vals.sum() == sharding.marginal_likelihood_sweep(gp, grid).sum()
