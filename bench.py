@@ -7,10 +7,13 @@ reference regression.py:218-244) followed by a batched predict of M=1024 points 
 on the synthetic data of workloads.py, x / y / y_err already resident in HBM.
 value = (N^3/3 + M N^2) FLOP per step * steps * n_gpus / wall  in GFLOP/s (whole job).
 
-N GPUs: one process per GPU (torch.distributed, backend nccl = RCCL), each rank runs the same step
-at its own hyper-parameter vector (the path shards over independent hyper-parameter evaluations,
-weak scaling) and the per-rank results (log-determinant, alpha norm, predictive checksum) are
-all-gathered over RCCL inside the timed region.
+N GPUs: one process per GPU, each rank runs the same step at its own hyper-parameter vector (the path
+shards over independent hyper-parameter evaluations, weak scaling) and the per-rank results
+(log-determinant, alpha norm, predictive checksum) are all-gathered over RCCL / xGMI inside the timed
+region through the library's own communicator (gpmi_comm_*).  torch.distributed (gloo, CPU) provides
+rank / world / barrier and the RCCL unique-id bootstrap only: libgpmi is loaded BEFORE torch so that
+the process runs on the system ROCm 7.2 runtime — with torch's bundled HIP runtime initialised first
+the same kernels ran 2x slower with multi-10-ms stalls.
 
 Extra objects on the JSON line:
   roofline      the potrf trailing SYRK/GEMM update (fp64 MFMA bound): algorithmic FLOP per launch
@@ -77,22 +80,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    import torch
+    import workloads as wl
+    from inference_amd import _lib
+
+    _lib.load()  # system ROCm runtime first (see module docstring)
+    from inference_amd import sharding
+    from inference_amd.gp import GpRegressor, SquaredExponential
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
+        import torch
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    import workloads as wl
-    from inference_amd import _lib
-    from inference_amd.gp import GpRegressor, SquaredExponential
+        dist.init_process_group(backend="gloo")
 
     N, d, M = args.n, args.d, args.m
     x, y, e = wl.synthetic_dataset(2, N, d)
@@ -102,19 +106,28 @@ def main():
 
     gp = GpRegressor(x, y, y_err=e, hyperpars=theta, kernel=SquaredExponential, device=local_rank)
     eng = gp.engine
+    gather = "none"
+    if world > 1:
+        try:
+            sharding.init_device_comm(eng)
+            gather = "rccl"
+        except Exception as err:  # keep the scaling run alive: the gather is 4 doubles per rank
+            gather = f"gloo-fallback ({type(err).__name__}: {err})"
 
     def step():
         gp.set_hyperparameters(theta)  # K-build + potrf + alpha
         mu, sig = gp(pts)  # cross-covariance + TRSM + reductions
-        res = torch.tensor(
-            [gp._logdet, float(np.linalg.norm(gp.alpha)), float(mu.sum()), float(sig.sum())],
-            dtype=torch.float64,
-            device="cuda",
-        )
-        if dist is not None:
-            out = [torch.empty_like(res) for _ in range(world)]
-            dist.all_gather(out, res)  # RCCL: the only collective of the path (result gather)
-            res = torch.stack(out)
+        # plain NumPy reductions only: a BLAS call here (np.linalg.norm -> OpenBLAS nrm2) starts OpenBLAS's
+        # spinning worker pool, which starves the HIP runtime's completion handling and doubled the
+        # step time from the next step on (tools/phase_times3.py)
+        res = np.array([gp._logdet, float(np.sqrt(np.sum(gp.alpha**2))), float(mu.sum()), float(sig.sum())])
+        if world > 1:
+            if gather == "rccl":
+                res = eng.comm_allgather(res)  # RCCL over xGMI: the only collective of the path
+            else:
+                out = [None] * world
+                dist.all_gather_object(out, res)
+                res = np.array(out)
         return res
 
     for _ in range(args.warmup):
@@ -123,9 +136,10 @@ def main():
     def fence():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        eng.sync()  # every stream of the library on this device (nothing else runs on the GPU)
 
-    eng.profile_enable(2 << _lib.PROF_SYRK)
+    if not os.environ.get("BENCH_NO_PROF"):
+        eng.profile_enable(2 << _lib.PROF_SYRK)
     eng.profile_reset()
     fence()
     t0 = time.perf_counter()
@@ -137,7 +151,7 @@ def main():
     eng.profile_enable(0)
 
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -163,7 +177,7 @@ def main():
                 "workload": f"GpRegressor SquaredExponential fit (fixed theta) + predict, N={N} d={d} M={M}",
                 "flop_per_step": flops_step,
                 "pct_fp64_mfma_peak_whole_step": 100.0 * value / world / 1e3 / PEAK_FP64_MFMA_TFLOPS,
-                "parallelism": f"{world} independent hyper-parameter evaluations (one per GPU), RCCL all_gather of results",
+                "parallelism": f"{world} independent hyper-parameter evaluations (one per GPU), result all-gather: {gather}",
             },
             "roofline": {
                 "kernel": "gemm_nt_kernel<TILES_LOWER, OP_SUB> (potrf trailing SYRK update, K=512)",

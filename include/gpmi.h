@@ -160,6 +160,17 @@ int gpmi_loo_terms(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_th
                    double extra_diag, const double* mu_host, double* alpha_host,
                    double* ikdiag_host, int* info);
 
+/* ---- multi-GPU result gather (RCCL over xGMI) ----------------------------------------
+ * Replaces the result return of multiprocessing.Pool.map (regression.py:600-601) and the
+ * (theta, log-prob) messages of the tempering processes (mcmc/parallel.py:195-201).  One process per
+ * GPU.  Rank 0 calls gpmi_comm_unique_id (128 bytes), the caller distributes the id over any host
+ * channel, every rank calls gpmi_comm_init, then gpmi_comm_allgather gathers `count` doubles per
+ * rank (recv_host: world * count, in rank order).  librccl is loaded on first use. */
+int gpmi_comm_unique_id(char* id_out_128);
+int gpmi_comm_init(gpmi_ctx* ctx, int rank, int world, const char* id_128);
+int gpmi_comm_allgather(gpmi_ctx* ctx, const double* send_host, double* recv_host, int64_t count);
+int gpmi_comm_destroy(gpmi_ctx* ctx);
+
 /* ---- instrumentation ---------------------------------------------------------------
  * HIP-event timing on the handle's own stream (torch.cuda.Event would not see it). */
 int gpmi_timer_start(gpmi_ctx* ctx);

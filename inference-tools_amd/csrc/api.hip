@@ -1,7 +1,9 @@
 // C-ABI of libgpmi (see include/gpmi.h): handle management, host<->device plumbing and the
 // orchestration of the GP hot path (covariance build -> Cholesky -> solves -> reductions).
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "gpmi_internal.h"
@@ -30,12 +32,26 @@ thread_local std::string g_create_err;
 constexpr int RED_SLOTS = 8192;  // per-lane result slots for batched evaluations
 
 int lane_streams(gpmi_ctx* c, Lane& L) {
-  int lo = 0, hi = 0;
-  HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));  // hi is the numerically lowest = highest priority
-  HIPCHK(c, hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, lo));
-  HIPCHK(c, hipStreamCreateWithPriority(&L.stream2, hipStreamNonBlocking, hi));
+  HIPCHK(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+  // CU-masked pair for the look-ahead: mask bits are dealt round-robin over the 8 XCDs (probed with
+  // tools/cumask_probe.hip), so the first 32 bits are 4 CUs on every XCD
+  hipDeviceProp_t prop;
+  HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+  const int ncu = prop.multiProcessorCount;
+  if (ncu >= 64 && ncu % 32 == 0) {
+    std::vector<uint32_t> panel((size_t)ncu / 32, 0u), upd((size_t)ncu / 32, 0xffffffffu);
+    panel[0] = 0xffffffffu;
+    upd[0] = 0u;
+    if (hipExtStreamCreateWithCUMask(&L.stream2, (uint32_t)panel.size(), panel.data()) != hipSuccess ||
+        hipExtStreamCreateWithCUMask(&L.stream_upd, (uint32_t)upd.size(), upd.data()) != hipSuccess) {
+      if (L.stream2) (void)hipStreamDestroy(L.stream2);
+      L.stream2 = L.stream_upd = nullptr;  // no look-ahead: everything on the full-chip stream
+      (void)hipGetLastError();
+    }
+  }
   HIPCHK(c, hipEventCreateWithFlags(&L.ev_la, hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&L.ev_panel, hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
   return GPMI_OK;
 }
 
@@ -55,9 +71,12 @@ int lane_alloc(gpmi_ctx* c, Lane& L) {
 void lane_free(Lane& L) {
   if (L.stream) (void)hipStreamSynchronize(L.stream);
   if (L.stream2) (void)hipStreamSynchronize(L.stream2);
+  if (L.stream_upd) (void)hipStreamSynchronize(L.stream_upd);
   if (L.ev_la) (void)hipEventDestroy(L.ev_la);
   if (L.ev_panel) (void)hipEventDestroy(L.ev_panel);
+  if (L.ev_join) (void)hipEventDestroy(L.ev_join);
   if (L.stream2) (void)hipStreamDestroy(L.stream2);
+  if (L.stream_upd) (void)hipStreamDestroy(L.stream_upd);
   if (L.A) (void)hipFree(L.A);
   if (L.B2) (void)hipFree(L.B2);
   if (L.gws) (void)hipFree(L.gws);
@@ -183,10 +202,28 @@ int ensure_query_ws(gpmi_ctx* c, int64_t mp) {
 
 }  // namespace
 
-// ---- instrumentation scope ----------------------------------------------------------
+// ---- instrumentation ----------------------------------------------------------------
+namespace {
+__global__ void stamp_init_kernel(unsigned long long* pool, int slots) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < slots) {
+    pool[2 * i] = ~0ull;
+    pool[2 * i + 1] = 0ull;
+  }
+}
+}  // namespace
+
+unsigned long long* prof_stamp_slot(gpmi_ctx* c, double flops, double bytes) {
+  if (!((c->prof_mask >> GPMI_PROF_SYRK) & 1) || !c->stamp_pool) return nullptr;
+  if ((int)c->stamp_flops.size() >= GPMI_STAMP_SLOTS) return nullptr;
+  c->stamp_flops.push_back(flops);
+  c->stamp_bytes.push_back(bytes);
+  return c->stamp_pool + 2 * (c->stamp_flops.size() - 1);
+}
+
 ProfScope::ProfScope(gpmi_ctx* ctx, hipStream_t st, int klass, double flops, double bytes)
     : c(ctx), s(st), slot(nullptr) {
-  if (!((c->prof_mask >> klass) & 1)) return;
+  if (!((c->prof_mask >> klass) & 1) || klass == GPMI_PROF_SYRK) return;
   if (c->prof_used == c->prof_slots.size()) {
     ProfSlot ns{};
     if (hipEventCreate(&ns.e0) != hipSuccess || hipEventCreate(&ns.e1) != hipSuccess) return;
@@ -244,11 +281,13 @@ int gpmi_create(int device, gpmi_ctx** out) {
 int gpmi_destroy(gpmi_ctx* c) {
   if (!c) return GPMI_OK;
   (void)hipSetDevice(c->device);
+  (void)gpmi_comm_destroy(c);
   free_data(c);
   for (auto& sl : c->prof_slots) {
     (void)hipEventDestroy(sl.e0);
     (void)hipEventDestroy(sl.e1);
   }
+  if (c->stamp_pool) (void)hipFree(c->stamp_pool);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->t0) (void)hipEventDestroy(c->t0);
   if (c->t1) (void)hipEventDestroy(c->t1);
@@ -264,6 +303,7 @@ int gpmi_sync(gpmi_ctx* c) {
   for (auto& L : c->lanes) {
     HIPCHK(c, hipStreamSynchronize(L.stream));
     if (L.stream2) HIPCHK(c, hipStreamSynchronize(L.stream2));
+    if (L.stream_upd) HIPCHK(c, hipStreamSynchronize(L.stream_upd));
   }
   return GPMI_OK;
 }
@@ -319,16 +359,26 @@ int gpmi_fit(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double e
   Lane& L = c->lanes[0];
   hipStream_t s = L.stream;
   double* mu_dev = L.vec + 3 * c->np;
+  const bool dbg = std::getenv("GPMI_DEBUG_TIMING") != nullptr;
+  const auto h0 = std::chrono::steady_clock::now();
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
   if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
+  const auto h1 = std::chrono::steady_clock::now();
   // alpha = L^-T v
-  HIPCHK(c, hipMemcpyAsync(c->alpha, L.vec, sizeof(double) * c->np, hipMemcpyDeviceToDevice, s));
+  launch_copy(s, L.vec, c->alpha, c->np);
   trsv_backward(c, s, L.A, c->np, c->ld, L.invD, c->alpha);
   HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
   if (alpha_out)
     HIPCHK(c, hipMemcpyAsync(alpha_out, c->alpha, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  const auto h2 = std::chrono::steady_clock::now();
   HIPCHK(c, hipStreamSynchronize(s));
+  if (dbg) {
+    const auto h3 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::fprintf(stderr, "[gpmi_fit] host enqueue factor+forward %.2f ms, backward+copies %.2f ms, final sync %.2f ms\n",
+                 ms(h0, h1), ms(h1, h2), ms(h2, h3));
+  }
   if (logdet_out) *logdet_out = L.h_red[1];
   if (info) *info = L.h_info[0];
   c->fit_params = p;
@@ -425,7 +475,7 @@ int gpmi_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
   double* gout = L.red + 16;  // n_theta + 1 values (n_theta <= GPMI_MAX_D + 2)
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
   if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
-  HIPCHK(c, hipMemcpyAsync(alpha_dev, L.vec, sizeof(double) * c->np, hipMemcpyDeviceToDevice, s));
+  launch_copy(s, L.vec, alpha_dev, c->np);
   trsv_backward(c, s, L.A, c->np, c->ld, L.invD, alpha_dev);
   // K^-1 = L^-T L^-1 (regression.py:556-557), lower tiles, overwriting L
   enqueue_inverse_factor(c, L, L.A, L.invD);
@@ -534,7 +584,7 @@ int gpmi_spatial_derivatives(gpmi_ctx* c, const double* pts, int64_t m, double* 
     if (int rc = ensure_query_ws(c, mp)) return rc;
     HIPCHK(c, hipMemcpyAsync(c->pts, pts + m0 * d, sizeof(double) * mc * d, hipMemcpyHostToDevice, s));
     launch_kbuild_cross(s, p, c->pts, mc, mp, c->x, c->n, c->np, c->Q, c->ld);
-    HIPCHK(c, hipMemcpyAsync(c->Q2, c->Q, sizeof(double) * mp * c->ld, hipMemcpyDeviceToDevice, s));
+    launch_copy(s, c->Q, c->Q2, mp * c->ld);
     // Z = K^-1 k per row: forward then backward solve (regression.py:410)
     trsm_rows_forward(c, s, L.A, c->np, c->ld, L.invD, c->Q2, mp);
     trsm_rows_backward(c, s, L.A, c->np, c->ld, L.invD, c->Q2, mp);
@@ -618,7 +668,7 @@ int gpmi_loo_terms(gpmi_ctx* c, int kernel, const double* theta, int n_theta, do
   double* diag_dev = L.vec + 2 * c->np;
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
   if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
-  HIPCHK(c, hipMemcpyAsync(alpha_dev, L.vec, sizeof(double) * c->np, hipMemcpyDeviceToDevice, s));
+  launch_copy(s, L.vec, alpha_dev, c->np);
   trsv_backward(c, s, L.A, c->np, c->ld, L.invD, alpha_dev);
   enqueue_inverse_factor(c, L, L.A, L.invD);
   launch_rows_sumsq(s, L.B2, c->ld, c->np, c->np, 0.0, diag_dev);
@@ -738,6 +788,13 @@ int gpmi_timer_stop(gpmi_ctx* c, float* ms) {
 int gpmi_profile_enable(gpmi_ctx* c, int on) {
   if (!c) return GPMI_ERR_ARG;
   c->prof_mask = (on == 1) ? 0xF : (unsigned)on >> 1;
+  if (((c->prof_mask >> GPMI_PROF_SYRK) & 1) && !c->stamp_pool) {
+    if (int rc = set_device(c)) return rc;
+    HIPCHK(c, hipMalloc(&c->stamp_pool, sizeof(unsigned long long) * 2 * GPMI_STAMP_SLOTS));
+    hipLaunchKernelGGL(stamp_init_kernel, dim3(GPMI_STAMP_SLOTS / 256), dim3(256), 0, 0, c->stamp_pool,
+                       GPMI_STAMP_SLOTS);
+    HIPCHK(c, hipDeviceSynchronize());
+  }
   return GPMI_OK;
 }
 
@@ -753,6 +810,24 @@ static int profile_collect(gpmi_ctx* c) {
     c->prof_launches[sl.klass] += 1;
   }
   c->prof_used = 0;
+  // device-stamped trailing-update launches: duration = (max end - min start) / 100 MHz
+  const size_t ns = c->stamp_flops.size();
+  if (ns && c->stamp_pool) {
+    std::vector<unsigned long long> h(2 * ns);
+    HIPCHK(c, hipMemcpy(h.data(), c->stamp_pool, sizeof(unsigned long long) * 2 * ns, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < ns; ++i) {
+      if (h[2 * i + 1] <= h[2 * i]) continue;  // launch never ran
+      c->prof_ms[GPMI_PROF_SYRK] += (double)(h[2 * i + 1] - h[2 * i]) * 1e-5;  // 10 ns ticks -> ms
+      c->prof_flops[GPMI_PROF_SYRK] += c->stamp_flops[i];
+      c->prof_bytes[GPMI_PROF_SYRK] += c->stamp_bytes[i];
+      c->prof_launches[GPMI_PROF_SYRK] += 1;
+    }
+    hipLaunchKernelGGL(stamp_init_kernel, dim3(GPMI_STAMP_SLOTS / 256), dim3(256), 0, 0, c->stamp_pool,
+                       GPMI_STAMP_SLOTS);
+    HIPCHK(c, hipDeviceSynchronize());
+    c->stamp_flops.clear();
+    c->stamp_bytes.clear();
+  }
   return GPMI_OK;
 }
 
@@ -849,10 +924,10 @@ int gpmi_dev_gemm_nt(gpmi_ctx* c, double* C, int64_t ldc, const double* A, int64
     const double tiles = lower ? (double)(n / GPMI_NB) * (n / GPMI_NB + 1) / 2.0 +
                                      (double)(m / GPMI_NB - n / GPMI_NB) * (n / GPMI_NB)
                                : (double)(m / GPMI_NB) * (n / GPMI_NB);
-    ProfScope ps(c, s, GPMI_PROF_SYRK, tiles * 2.0 * GPMI_NB * GPMI_NB * k,
-                 tiles * 16.0 * GPMI_NB * GPMI_NB);
+    unsigned long long* stamp =
+        prof_stamp_slot(c, tiles * 2.0 * GPMI_NB * GPMI_NB * k, tiles * 16.0 * GPMI_NB * GPMI_NB);
     launch_gemm_nt(s, lower ? TILES_LOWER : TILES_RECT, OP_SUB, C, ldc, A, lda, B, ldb,
-                   (int)(m / GPMI_NB), (int)(n / GPMI_NB), (int)k);
+                   (int)(m / GPMI_NB), (int)(n / GPMI_NB), (int)k, stamp);
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(s));

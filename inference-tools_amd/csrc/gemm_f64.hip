@@ -22,9 +22,8 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDS_STRIDE = 18;                   // doubles per staged row (16 + 2 pad)
-constexpr int TILE_DOUBLES = BM * LDS_STRIDE;    // one operand tile in LDS
+constexpr int BK = 16;
+constexpr int LDS_STRIDE = 18;  // doubles per staged row (16 + 2 pad)
 
 struct GemmArgs {
   double* C;
@@ -33,9 +32,13 @@ struct GemmArgs {
   int64_t ldc, lda, ldb;
   int ntr, ntc, k;
   int kskip;  // TILES_LOWER only: contraction starts at k = ti * 128 (operands are zero before it)
+  // optional {min start, max end} wall-clock stamps of this launch (s_memrealtime, 100 MHz): per-launch
+  // durations for the roofline without HIP events in the stream (event records between the look-ahead
+  // streams slowed the factorisation 2x)
+  unsigned long long* stamp;
 };
 
-constexpr int LDS_STRIDE_KN = 144;  // B stored k-major: 16 rows of 128 + 16 pad (rows 16 doubles apart mod 32)
+// B stored k-major: 16 rows of BN + 16 pad (rows 16 doubles apart mod 32)
 
 // linear workgroup id -> (ti, tj), with an XCD-aware remap: workgroups b and b + 8 run on the same
 // XCD (round-robin dispatch), so each XCD is handed a contiguous chunk of the logical tile list and
@@ -80,13 +83,22 @@ __device__ inline void tile_of(int id, int ntr, int ntc, int& ti, int& tj) {
 }
 
 // BKN = 0: B is (cols x k), K-contiguous ("NT");  BKN = 1: B is (k x cols), row-major ("NN").
-template <int TILES, int OP, int BKN>
+// BM x BN is the workgroup tile (128 or 64 each): the small tiles serve launches with few 128-tiles
+// or K = 128 (panel TRSM, inner panel updates, solves with few right-hand sides), which are bound
+// by the time of ONE tile rather than by throughput.
+template <int TILES, int OP, int BKN, int BM, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
-  __shared__ double smem[2 * 2 * TILE_DOUBLES];  // [buffer][A|B][128][18]
+  constexpr int TM = BM / 32, TN = BN / 32;  // 16 x 16 MFMA tiles per wave (2 x 2 waves)
+  constexpr int LDS_STRIDE_KN = BN + 16;
+  constexpr int A_DOUBLES = BM * LDS_STRIDE;
+  constexpr int B_DOUBLES = BKN ? BK * LDS_STRIDE_KN : BN * LDS_STRIDE;
+  constexpr int BUF_DOUBLES = A_DOUBLES + B_DOUBLES;
+  __shared__ double smem[2 * BUF_DOUBLES];  // [buffer][A | B]
   int ti, tj;
   tile_of<TILES>(xcd_remap(blockIdx.x, gridDim.x), g.ntr, g.ntc, ti, tj);
 
   const int tid = threadIdx.x;
+  if (g.stamp && tid == 0) atomicMin(g.stamp, (unsigned long long)__builtin_amdgcn_s_memrealtime());
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int kbeg = g.kskip ? ti * BM : 0;
@@ -99,44 +111,47 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   // swizzled position of this thread's 16-byte piece: rows 4..11 (mod 16) swap their 32-byte chunk pairs
   // (lrow + 32 i has the same row & 15 for every i)
   const int lkc_sw = lkc ^ ((((lrow & 15) >= 4) && ((lrow & 15) < 12)) ? 4 : 0);
-  const int nrow = tid >> 6, nnc = (tid & 63) * 2;  // k-major B: 64 chunks per k-row
-  d2_t ra[4], rb[4];
+  // k-major B: BN / 2 chunks per k-row, 512 / BN k-rows per pass
+  const int nrow = tid / (BN / 2), nnc = (tid % (BN / 2)) * 2;
+  d2_t ra[TM], rb[TN];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = lrow + 32 * i;
-      ra[i] = *reinterpret_cast<const d2_t*>(Ag + (int64_t)row * g.lda + k0 + lkc);
+    for (int i = 0; i < TM; ++i)
+      ra[i] = *reinterpret_cast<const d2_t*>(Ag + (int64_t)(lrow + 32 * i) * g.lda + k0 + lkc);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
       if (BKN)
-        rb[i] = *reinterpret_cast<const d2_t*>(Bg + (int64_t)(k0 + nrow + 4 * i) * g.ldb + nnc);
+        rb[i] = *reinterpret_cast<const d2_t*>(Bg + (int64_t)(k0 + nrow + (512 / BN) * i) * g.ldb + nnc);
       else
-        rb[i] = *reinterpret_cast<const d2_t*>(Bg + (int64_t)row * g.ldb + k0 + lkc);
+        rb[i] = *reinterpret_cast<const d2_t*>(Bg + (int64_t)(lrow + 32 * i) * g.ldb + k0 + lkc);
     }
   };
   auto sstore = [&](int buf) {
-    double* sa = smem + buf * 2 * TILE_DOUBLES;
-    double* sb = sa + TILE_DOUBLES;
+    double* sa = smem + buf * BUF_DOUBLES;
+    double* sb = sa + A_DOUBLES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = lrow + 32 * i;
-      *reinterpret_cast<d2_t*>(sa + row * LDS_STRIDE + lkc_sw) = ra[i];
+    for (int i = 0; i < TM; ++i)
+      *reinterpret_cast<d2_t*>(sa + (lrow + 32 * i) * LDS_STRIDE + lkc_sw) = ra[i];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
       if (BKN)
-        *reinterpret_cast<d2_t*>(sb + (nrow + 4 * i) * LDS_STRIDE_KN + nnc) = rb[i];
+        *reinterpret_cast<d2_t*>(sb + (nrow + (512 / BN) * i) * LDS_STRIDE_KN + nnc) = rb[i];
       else
-        *reinterpret_cast<d2_t*>(sb + row * LDS_STRIDE + lkc_sw) = rb[i];
+        *reinterpret_cast<d2_t*>(sb + (lrow + 32 * i) * LDS_STRIDE + lkc_sw) = rb[i];
     }
   };
 
-  d4_t acc[4][4];
+  d4_t acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < TN; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
 
   const int fr = lane & 15, fk = lane >> 4;
   const int sw = (fr >= 4 && fr < 12) ? 1 : 0;
-  const int a_off = (wr * 64 + fr) * LDS_STRIDE + ((fk ^ sw) << 2);
-  const int b_off =
-      BKN ? 4 * fk * LDS_STRIDE_KN + wc * 64 + fr : (wc * 64 + fr) * LDS_STRIDE + ((fk ^ sw) << 2);
+  const int a_off = (wr * (BM / 2) + fr) * LDS_STRIDE + ((fk ^ sw) << 2);
+  const int b_off = BKN ? 4 * fk * LDS_STRIDE_KN + wc * (BN / 2) + fr
+                        : (wc * (BN / 2) + fr) * LDS_STRIDE + ((fk ^ sw) << 2);
 
   gload(0);
   sstore(0);
@@ -145,15 +160,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * BK);
-    const double* sa = smem + cur * 2 * TILE_DOUBLES;
-    const double* sb = sa + TILE_DOUBLES;
+    const double* sa = smem + cur * BUF_DOUBLES;
+    const double* sb = sa + A_DOUBLES;
     // lane (fr, fk) supplies k = 4 fk + q of the slab to MFMA step q (same map for A and B)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      d2_t a[4], b[4];
+      d2_t a[TM], b[TN];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < TM; ++t)
         a[t] = *reinterpret_cast<const d2_t*>(sa + a_off + t * 16 * LDS_STRIDE + 2 * h);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
         if (BKN)
           b[t] = d2_t{sb[b_off + (2 * h) * LDS_STRIDE_KN + t * 16],
                       sb[b_off + (2 * h + 1) * LDS_STRIDE_KN + t * 16]};
@@ -163,9 +180,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) sstore(cur ^ 1);
@@ -175,28 +192,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   // epilogue: each access covers 4 rows x 128 contiguous bytes.  The 16 loads of one row-tile are
   // issued together before any store (a load-subtract-store chain per element serialises on memory
   // latency: 64 round trips per tile, measured 27 % of a workgroup's lifetime at K = 512).
-  double* Cg = g.C + ((int64_t)ti * BM + wr * 64) * g.ldc + (int64_t)tj * BN + wc * 64;
+  double* Cg = g.C + ((int64_t)ti * BM + wr * (BM / 2)) * g.ldc + (int64_t)tj * BN + wc * (BN / 2);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < TM; ++i) {
     double* rowp[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) rowp[r] = Cg + (int64_t)(i * 16 + fk + 4 * r) * g.ldc + fr;
     if (OP == OP_SUB) {
-      double cv[4][4];
+      double cv[TN][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) cv[j][r] = rowp[r][j * 16];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) rowp[r][j * 16] = cv[j][r] - acc[i][j][r];
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) rowp[r][j * 16] = acc[i][j][r];
     }
+  }
+  if (g.stamp && tid == 0) {
+    __builtin_amdgcn_s_waitcnt(0);  // stores issued; the stamp marks the end of this workgroup's work
+    atomicMax(g.stamp + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
   }
 }
 
@@ -204,32 +225,62 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 
 void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, bool kskip, double* C,
                  int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb, int ntr,
-                 int ntc, int k) {
+                 int ntc, int k, unsigned long long* stamp) {
+  // ntr, ntc are in units of 128 rows / columns
   if (ntr <= 0 || ntc <= 0 || k <= 0) return;
-  GemmArgs g{C, A, B, ldc, lda, ldb, ntr, ntc, k, kskip ? 1 : 0};
-  int nwg;
-  if (tiles == TILES_RECT) {
-    nwg = ntr * ntc;
-  } else {
-    if (ntc > ntr) ntc = g.ntc = ntr;
-    nwg = ntc * (ntc + 1) / 2 + (ntr - ntc) * ntc;
-  }
-  dim3 grid((unsigned)nwg), block(256);
-#define GPMI_LAUNCH(T, O, B) hipLaunchKernelGGL((gemm_nt_kernel<T, O, B>), grid, block, 0, s, g)
-  if (tiles == TILES_RECT) {
-    if (op == OP_SUB) {
-      if (b_kmajor) GPMI_LAUNCH(TILES_RECT, OP_SUB, 1); else GPMI_LAUNCH(TILES_RECT, OP_SUB, 0);
-    } else {
-      if (b_kmajor) GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 1); else GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0);
+  if (tiles == TILES_LOWER && ntc > ntr) ntc = ntr;
+  const int64_t big = (tiles == TILES_RECT) ? (int64_t)ntr * ntc
+                                            : (int64_t)ntc * (ntc + 1) / 2 + (int64_t)(ntr - ntc) * ntc;
+  // tile shape: full 128 x 128 tiles when there is enough work to fill the chip at K >= 256,
+  // 64-row tiles for one-tile-column products (in place: a workgroup must own whole rows),
+  // 64 x 64 tiles for the remaining short / small launches
+  int bm = 128, bn = 128;
+  const bool small = (k <= 128) || (big < 384);
+  if (small && !kskip) {
+    if (ntc == 1 && tiles == TILES_RECT && op == OP_ASSIGN) {
+      bm = 64;
+    } else if (!b_kmajor || op == OP_SUB) {
+      bm = 64;
+      bn = 64;
     }
+  }
+  GemmArgs g{C, A, B, ldc, lda, ldb, ntr * (128 / bm), ntc * (128 / bn), k, kskip ? 1 : 0, stamp};
+  int64_t nwg;
+  if (tiles == TILES_RECT)
+    nwg = (int64_t)g.ntr * g.ntc;
+  else
+    nwg = (int64_t)g.ntc * (g.ntc + 1) / 2 + (int64_t)(g.ntr - g.ntc) * g.ntc;
+  dim3 grid((unsigned)nwg), block(256);
+#define GPMI_LAUNCH(T, O, B, M, N) \
+  hipLaunchKernelGGL((gemm_nt_kernel<T, O, B, M, N>), grid, block, 0, s, g)
+  if (bm == 128) {
+    if (tiles == TILES_RECT) {
+      if (op == OP_SUB) {
+        if (b_kmajor) GPMI_LAUNCH(TILES_RECT, OP_SUB, 1, 128, 128); else GPMI_LAUNCH(TILES_RECT, OP_SUB, 0, 128, 128);
+      } else {
+        if (b_kmajor) GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 1, 128, 128); else GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0, 128, 128);
+      }
+    } else {
+      if (op == OP_SUB) GPMI_LAUNCH(TILES_LOWER, OP_SUB, 0, 128, 128); else GPMI_LAUNCH(TILES_LOWER, OP_ASSIGN, 0, 128, 128);
+    }
+  } else if (bn == 128) {
+    if (b_kmajor) GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 1, 64, 128); else GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0, 64, 128);
   } else {
-    if (op == OP_SUB) GPMI_LAUNCH(TILES_LOWER, OP_SUB, 0); else GPMI_LAUNCH(TILES_LOWER, OP_ASSIGN, 0);
+    if (tiles == TILES_RECT) {
+      if (op == OP_SUB) {
+        if (b_kmajor) GPMI_LAUNCH(TILES_RECT, OP_SUB, 1, 64, 64); else GPMI_LAUNCH(TILES_RECT, OP_SUB, 0, 64, 64);
+      } else {
+        GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0, 64, 64);
+      }
+    } else {
+      if (op == OP_SUB) GPMI_LAUNCH(TILES_LOWER, OP_SUB, 0, 64, 64); else GPMI_LAUNCH(TILES_LOWER, OP_ASSIGN, 0, 64, 64);
+    }
   }
 #undef GPMI_LAUNCH
 }
 
 void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc,
                     const double* A, int64_t lda, const double* B, int64_t ldb, int ntr, int ntc,
-                    int k) {
-  launch_gemm(s, tiles, op, false, false, C, ldc, A, lda, B, ldb, ntr, ntc, k);
+                    int k, unsigned long long* stamp) {
+  launch_gemm(s, tiles, op, false, false, C, ldc, A, lda, B, ldb, ntr, ntc, k, stamp);
 }

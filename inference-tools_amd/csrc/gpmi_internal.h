@@ -34,9 +34,11 @@ struct ProfSlot {
 
 // One independent evaluation lane: a stream with its own n x n scratch matrix and vectors.
 struct Lane {
-  hipStream_t stream = nullptr;   // main stream: covariance build, trailing updates, solves
-  hipStream_t stream2 = nullptr;  // panel stream (higher priority): look-ahead factorisation of the next panel
-  hipEvent_t ev_la = nullptr, ev_panel = nullptr;
+  hipStream_t stream = nullptr;    // full-chip stream: covariance build, solves, small factorisations
+  // look-ahead pair (CU-masked, disjoint): trailing updates on 224 CUs, next panel on the other 32
+  hipStream_t stream_upd = nullptr;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_la = nullptr, ev_panel = nullptr, ev_join = nullptr;
   double* A = nullptr;      // np x ld scratch (K then L)
   double* invD = nullptr;   // (np/128) x 128 x 128 inverses of the diagonal blocks
   double* B2 = nullptr;     // second np x ld matrix (L^-T for the gradient / LOO paths), allocated lazily
@@ -72,9 +74,18 @@ struct gpmi_ctx {
   // host staging (pinned)
   double* h_stage = nullptr;
   int64_t h_stage_bytes = 0;
+  // RCCL result gather (comm.hip)
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  hipStream_t comm_stream = nullptr;
+  double* comm_buf = nullptr;
+  int64_t comm_buf_doubles = 0;
   // instrumentation
   hipEvent_t t0 = nullptr, t1 = nullptr;
   unsigned prof_mask = 0;
+  // device-stamped launches (trailing-update class): {min start, max end} per launch
+  unsigned long long* stamp_pool = nullptr;
+  std::vector<double> stamp_flops, stamp_bytes;
   std::vector<ProfSlot> prof_slots;
   size_t prof_used = 0;
   double prof_ms[GPMI_PROF_NCLASS] = {0, 0, 0, 0};
@@ -84,6 +95,9 @@ struct gpmi_ctx {
 };
 
 // instrumentation helpers (api.hip)
+constexpr int GPMI_STAMP_SLOTS = 16384;
+// next {start, end} stamp slot for a trailing-update launch, or nullptr when that class is not profiled
+unsigned long long* prof_stamp_slot(gpmi_ctx* c, double flops, double bytes);
 struct ProfScope {
   gpmi_ctx* c;
   hipStream_t s;
@@ -115,12 +129,12 @@ enum GemmOp { OP_SUB = 0, OP_ASSIGN = 1 };
 // C(ntr*128 x ntc*128) op= A(rows x k) * B(cols x k)^T ; TILES_LOWER visits tiles ti >= tj only
 void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc,
                     const double* A, int64_t lda, const double* B, int64_t ldb, int ntr, int ntc,
-                    int k);
+                    int k, unsigned long long* stamp = nullptr);
 
 // general form: b_kmajor -> B is (k x cols) row-major; kskip (TILES_LOWER) -> contraction starts at ti*128
 void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, bool kskip, double* C,
                  int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb, int ntr,
-                 int ntc, int k);
+                 int ntc, int k, unsigned long long* stamp = nullptr);
 
 // potrf.hip
 void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0);
@@ -139,6 +153,8 @@ void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int6
 void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
                        const double* invD, double* Q, int64_t mp, bool upper_rhs = false);
 void launch_set_identity(hipStream_t s, double* Q, int64_t ld, int64_t np);
+// device-to-device vector copy as a kernel (a runtime D2D memcpy stalled the stream for tens of ms)
+void launch_copy(hipStream_t s, const double* src, double* dst, int64_t n);
 // r = y - mu (padded with zeros)
 void launch_residual(hipStream_t s, const double* y, const double* mu, double mu_const, double* r,
                      int64_t n, int64_t np);

@@ -10,6 +10,8 @@
 // A non-positive or non-finite pivot is reported LAPACK-style through `info` (first failing
 // column + 1); the factorisation then continues with a unit pivot so that the launch sequence stays
 // asynchronous — the host inspects `info` once at the end (regression.py:540-542 behaviour).
+#include <cstdlib>
+
 #include "gpmi_internal.h"
 
 namespace {
@@ -201,69 +203,110 @@ void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, in
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, s, Ablk, ld, invD, info, col0);
 }
 
+namespace {
+
+// factor outer panel [J, Je): inner right-looking steps on stream sp
+void factor_panel(gpmi_ctx* c, hipStream_t sp, double* A, int64_t ld, double* invD, int* info, int nt,
+                  int J, int Je) {
+  for (int j = J; j < Je; ++j) {
+    double* Ajj = A + (int64_t)j * NB * ld + (int64_t)j * NB;
+    double* invDj = invD + (int64_t)j * NB * NB;
+    const int below = nt - j - 1;
+    {
+      ProfScope ps(c, sp, GPMI_PROF_PANEL, (double)NB * NB * NB / 3.0 + 2.0 * below * NB * NB * NB,
+                   8.0 * NB * NB * (2.0 + 2.0 * below));
+      launch_potrf_diag(sp, Ajj, ld, invDj, info, j * NB);
+      if (below > 0) {
+        // panel TRSM: A21 <- A21 * L11^-T  (in place: one tile column, see gemm_f64.hip)
+        double* A21 = Ajj + (int64_t)NB * ld;
+        launch_gemm_nt(sp, TILES_RECT, OP_ASSIGN, A21, ld, A21, ld, invDj, NB, below, 1, NB);
+      }
+    }
+    const int pc = Je - j - 1;  // remaining block columns of the outer panel
+    if (below > 0 && pc > 0) {
+      // inner update of the rest of the outer panel, rows below: tiles (ti >= tj, tj < pc)
+      double* A21 = Ajj + (int64_t)NB * ld;
+      double* C = A21 + NB;
+      const double tiles = pc * (pc + 1) / 2.0 + (double)(below - pc) * pc;
+      ProfScope ps(c, sp, GPMI_PROF_PANEL, tiles * 2.0 * NB * NB * NB, tiles * 16.0 * NB * NB);
+      launch_gemm_nt(sp, TILES_LOWER, OP_SUB, C, ld, A21, ld, A21, ld, below, pc, NB);
+    }
+  }
+}
+
+// trailing update of tile columns [c0, c1) (relative to the trailing matrix, rows c0 .. rem):
+// A22 -= P P^T with P = A[Je.., J..Je), K = (Je - J) * 128, lower tiles only
+void trailing_update(gpmi_ctx* c, hipStream_t s, double* A, int64_t ld, int nt, int J, int Je, int c0,
+                     int c1) {
+  const int rem = nt - Je;
+  const int kw = (Je - J) * NB;
+  const int rows = rem - c0, cols = c1 - c0;
+  if (rows <= 0 || cols <= 0) return;
+  double* P = A + (int64_t)(Je + c0) * NB * ld + (int64_t)J * NB;
+  double* C = A + (int64_t)(Je + c0) * NB * ld + (int64_t)(Je + c0) * NB;
+  const double tiles = cols * (cols + 1) / 2.0 + (double)(rows - cols) * cols;
+  unsigned long long* stamp =
+      prof_stamp_slot(c, tiles * 2.0 * NB * NB * kw, tiles * 16.0 * NB * NB + 8.0 * rows * NB * kw);
+  launch_gemm_nt(s, TILES_LOWER, OP_SUB, C, ld, P, ld, P, ld, rows, cols, kw, stamp);
+}
+
+}  // namespace
+
 void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t ld, double* invD,
                  int* info) {
-  // Look-ahead over two streams: the panel stream factors outer panel J+1 while the main stream
-  // still applies the trailing update of panel J to the columns right of it.
-  hipStream_t s = lane.stream, sp = lane.stream2;
+  // Two regimes (GPMI_LOOKAHEAD_MIN=<tile rows> moves the switch, 0 disables the look-ahead).
+  // While the trailing matrix is large, look-ahead over two CU-masked streams: the
+  // panel stream (32 CUs, 4 per XCD) factors outer panel J+1 while the update stream (the other 224
+  // CUs) still applies the trailing update of panel J to the columns right of it — disjoint CUs,
+  // because a 75 KiB potrf_diag workgroup never finds a slot on a chip saturated by GEMM
+  // workgroups.  Once the trailing update is shorter than a panel factorisation everything runs in
+  // order on the full-chip stream.
+  hipStream_t sf = lane.stream, su = lane.stream_upd, sp = lane.stream2;
   const int nt = (int)(np / NB);
-  const int OBT = 4;  // outer panel = 4 inner blocks = 512 columns
-  (void)hipEventRecord(lane.ev_la, s);
-  (void)hipStreamWaitEvent(sp, lane.ev_la, 0);
+  const int OBT = 4;            // outer panel = 4 inner blocks = 512 columns
+  // trailing tile rows below which the look-ahead stops paying (GPMI_LOOKAHEAD_MIN overrides; 0 disables)
+  static const int LOOKAHEAD_MIN = [] {
+    const char* e = std::getenv("GPMI_LOOKAHEAD_MIN");
+    const int v = e ? std::atoi(e) : 60;
+    return v > 0 ? v : (1 << 30);
+  }();
+  bool overlapped = false;
   for (int J = 0; J < nt; J += OBT) {
     const int Je = (J + OBT < nt) ? J + OBT : nt;
-    for (int j = J; j < Je; ++j) {
-      double* Ajj = A + (int64_t)j * NB * ld + (int64_t)j * NB;
-      double* invDj = invD + (int64_t)j * NB * NB;
-      const int below = nt - j - 1;
-      {
-        ProfScope ps(c, sp, GPMI_PROF_PANEL,
-                     (double)NB * NB * NB / 3.0 + 2.0 * below * NB * NB * NB,
-                     8.0 * NB * NB * (2.0 + 2.0 * below));
-        launch_potrf_diag(sp, Ajj, ld, invDj, info, j * NB);
-        if (below > 0) {
-          // panel TRSM: A21 <- A21 * L11^-T  (in place: one tile column, see gemm_f64.hip)
-          double* A21 = Ajj + (int64_t)NB * ld;
-          launch_gemm_nt(sp, TILES_RECT, OP_ASSIGN, A21, ld, A21, ld, invDj, NB, below, 1, NB);
-        }
-      }
-      const int pc = Je - j - 1;  // remaining block columns of the outer panel
-      if (below > 0 && pc > 0) {
-        // inner update of the rest of the outer panel, rows below: tiles (ti >= tj, tj < pc)
-        double* A21 = Ajj + (int64_t)NB * ld;
-        double* C = A21 + NB;
-        const double tiles = pc * (pc + 1) / 2.0 + (double)(below - pc) * pc;
-        ProfScope ps(c, sp, GPMI_PROF_PANEL, tiles * 2.0 * NB * NB * NB, tiles * 16.0 * NB * NB);
-        launch_gemm_nt(sp, TILES_LOWER, OP_SUB, C, ld, A21, ld, A21, ld, below, pc, NB);
-      }
-    }
-    (void)hipEventRecord(lane.ev_panel, sp);
-    (void)hipStreamWaitEvent(s, lane.ev_panel, 0);
     const int rem = nt - Je;
-    if (rem > 0) {
-      // trailing update A22 -= P P^T, P = A[Je.., J..Je) (K = (Je - J) * 128), lower tiles only, split into
-      // the columns of the next panel (which releases the panel stream) and the rest
-      const int kw = (Je - J) * NB;
-      const int la = rem < OBT ? rem : OBT;
-      double* P = A + (int64_t)Je * NB * ld + (int64_t)J * NB;
-      double* C = A + (int64_t)Je * NB * ld + (int64_t)Je * NB;
-      {
-        const double tiles = la * (la + 1) / 2.0 + (double)(rem - la) * la;
-        ProfScope ps(c, s, GPMI_PROF_SYRK, tiles * 2.0 * NB * NB * kw,
-                     tiles * 16.0 * NB * NB + 8.0 * rem * NB * kw);
-        launch_gemm_nt(s, TILES_LOWER, OP_SUB, C, ld, P, ld, P, ld, rem, la, kw);
-      }
-      (void)hipEventRecord(lane.ev_la, s);
-      (void)hipStreamWaitEvent(sp, lane.ev_la, 0);
-      const int rest = rem - la;
-      if (rest > 0) {
-        const double tiles = rest * (rest + 1) / 2.0;
-        double* P2 = P + (int64_t)la * NB * ld;
-        double* C2 = C + (int64_t)la * NB * ld + (int64_t)la * NB;
-        ProfScope ps(c, s, GPMI_PROF_SYRK, tiles * 2.0 * NB * NB * kw,
-                     tiles * 16.0 * NB * NB + 8.0 * rest * NB * kw);
-        launch_gemm_nt(s, TILES_LOWER, OP_SUB, C2, ld, P2, ld, P2, ld, rest, rest, kw);
-      }
+    const bool want = (sp != nullptr) && (rem >= LOOKAHEAD_MIN);
+    if (want && !overlapped) {
+      // enter the look-ahead regime: both masked streams start after everything queued so far
+      (void)hipEventRecord(lane.ev_join, sf);
+      (void)hipStreamWaitEvent(sp, lane.ev_join, 0);
+      (void)hipStreamWaitEvent(su, lane.ev_join, 0);
+      overlapped = true;
+    } else if (!want && overlapped) {
+      // leave it: the full-chip stream continues after both masked streams have drained
+      (void)hipEventRecord(lane.ev_join, su);
+      (void)hipStreamWaitEvent(sf, lane.ev_join, 0);
+      (void)hipEventRecord(lane.ev_panel, sp);
+      (void)hipStreamWaitEvent(sf, lane.ev_panel, 0);
+      overlapped = false;
     }
+    if (overlapped) {
+      factor_panel(c, sp, A, ld, invD, info, nt, J, Je);
+      (void)hipEventRecord(lane.ev_panel, sp);
+      (void)hipStreamWaitEvent(su, lane.ev_panel, 0);
+      const int la = rem < OBT ? rem : OBT;
+      trailing_update(c, su, A, ld, nt, J, Je, 0, la);  // columns of the next panel first
+      (void)hipEventRecord(lane.ev_la, su);
+      (void)hipStreamWaitEvent(sp, lane.ev_la, 0);
+      trailing_update(c, su, A, ld, nt, J, Je, la, rem);
+    } else {
+      factor_panel(c, sf, A, ld, invD, info, nt, J, Je);
+      trailing_update(c, sf, A, ld, nt, J, Je, 0, rem);
+    }
+  }
+  if (overlapped) {
+    (void)hipEventRecord(lane.ev_join, su);
+    (void)hipStreamWaitEvent(sf, lane.ev_join, 0);
+    (void)hipEventRecord(lane.ev_panel, sp);
+    (void)hipStreamWaitEvent(sf, lane.ev_panel, 0);
   }
 }

@@ -84,6 +84,11 @@ __global__ void set_identity_kernel(double* __restrict__ Q, int64_t ld, int64_t 
     *reinterpret_cast<d2_t*>(Q + i * ld + j) = d2_t{j == i ? 1.0 : 0.0, j + 1 == i ? 1.0 : 0.0};
 }
 
+__global__ void copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
 __global__ void residual_kernel(const double* __restrict__ y, const double* __restrict__ mu,
                                 double mu_const, double* __restrict__ r, int64_t n, int64_t np) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -232,6 +237,10 @@ void trsm_rows_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np,
 void launch_set_identity(hipStream_t s, double* Q, int64_t ld, int64_t np) {
   dim3 grid((unsigned)((np / 2 + 255) / 256), (unsigned)np);
   hipLaunchKernelGGL(set_identity_kernel, grid, dim3(256), 0, s, Q, ld, np);
+}
+
+void launch_copy(hipStream_t s, const double* src, double* dst, int64_t n) {
+  hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
 }
 
 void launch_residual(hipStream_t s, const double* y, const double* mu, double mu_const, double* r,

@@ -140,6 +140,25 @@ class GpEngine:
                     dptr(alpha), dptr(ikdiag), C.byref(info))
         return alpha, ikdiag, info.value
 
+    # -- multi-GPU gather (RCCL) -----------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = _lib.load().gpmi_comm_unique_id(buf)
+        if rc != 0:
+            raise _lib.GpmiError(f"gpmi_comm_unique_id failed with status {rc} (librccl missing?)")
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        self.h.call("gpmi_comm_init", int(rank), int(world), unique_id)
+        self.comm_world = world
+
+    def comm_allgather(self, values):
+        send = as_f64(values).ravel()
+        recv = np.empty(send.size * self.comm_world)
+        self.h.call("gpmi_comm_allgather", dptr(send), dptr(recv), send.size)
+        return recv.reshape(self.comm_world, send.size)
+
     # -- instrumentation ----------------------------------------------------------------
     def timer_start(self):
         self.h.call("gpmi_timer_start")

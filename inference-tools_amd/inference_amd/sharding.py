@@ -3,11 +3,15 @@ Multi-GPU sharding of independent hyper-parameter evaluations (BASELINE configs 
 and 5; reference counterpart: the `multiprocessing.Pool.map` task farming of
 regression.py:597-601 and the per-chain processes of mcmc/parallel.py:127-136).
 
-One process per GPU (`torch.distributed`; backend "nccl" is RCCL over xGMI on
-MI355X, "gloo" for the CPU tests).  The path needs exactly one collective: an
-all-gather of the per-rank results (a few doubles per evaluation — latency-bound,
-bandwidth irrelevant).  There is no data-path collective: x, y are tiny and every
-rank builds them itself.
+One process per GPU.  `torch.distributed` supplies the process group (rank /
+world size / barrier; backend "gloo", CPU only — `import inference_amd` must come
+BEFORE `import torch` so that the process runs on the system ROCm runtime, see
+DESIGN.md section 6); the path's one collective — an all-gather of the per-rank
+results, a few doubles per evaluation, latency-bound — goes over RCCL / xGMI
+through the library's own communicator (`gpmi_comm_*`, bootstrapped by
+broadcasting the RCCL unique id over the process group).  Without a device
+communicator (CPU tests) the gather falls back to the process group itself.
+There is no data-path collective: x, y are tiny and every rank builds them itself.
 """
 import numpy as np
 
@@ -31,8 +35,21 @@ def shard_bounds(n_items: int, world_size: int, rank: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def sharded_map(batch_fn, items, width: int = 1):
-    """Evaluate `batch_fn(items[lo:hi]) -> (hi - lo, width)` on every rank's block and all-gather.
+def init_device_comm(engine):
+    """Create the RCCL communicator of `engine` (a GpEngine): rank 0 makes the unique id, the
+    process group broadcasts it, every rank joins."""
+    rank, size = world()
+    uid = [engine.comm_unique_id() if rank == 0 else None]
+    if size > 1:
+        import torch.distributed as dist
+
+        dist.broadcast_object_list(uid, src=0)
+    engine.comm_init(rank, size, uid[0])
+
+
+def sharded_map(batch_fn, items, width: int = 1, engine=None):
+    """Evaluate `batch_fn(items[lo:hi]) -> (hi - lo, width)` on every rank's block and all-gather
+    (over RCCL when `engine` carries a device communicator, else over the process group).
 
     Returns the (n_items, width) array in the original order on every rank."""
     items = np.asarray(items)
@@ -41,6 +58,13 @@ def sharded_map(batch_fn, items, width: int = 1):
     local = np.asarray(batch_fn(items[lo:hi]), dtype=np.float64).reshape(hi - lo, width)
     if size == 1:
         return local
+    if engine is not None and getattr(engine, "comm_world", 0) == size:
+        per = -(-len(items) // size)
+        send = np.zeros((per, width))
+        send[: hi - lo] = local
+        got = engine.comm_allgather(send).reshape(size, per, width)
+        return np.concatenate([got[r, : b - a] for r, (a, b) in
+                               enumerate(shard_bounds(len(items), size, r) for r in range(size))], axis=0)
     import torch
     import torch.distributed as dist
 
@@ -61,4 +85,5 @@ def sharded_map(batch_fn, items, width: int = 1):
 def marginal_likelihood_sweep(gp, thetas):
     """Config 3: log-marginal likelihood of `gp` at every row of `thetas`, rows sharded over the
     ranks (each rank drives its own GPU), results all-gathered."""
-    return sharded_map(lambda th: gp.marginal_likelihood_batch(th), np.asarray(thetas, dtype=float))[:, 0]
+    eng = gp.engine if getattr(gp.engine, "comm_world", 0) > 1 else None
+    return sharded_map(lambda th: gp.marginal_likelihood_batch(th), np.asarray(thetas, dtype=float), engine=eng)[:, 0]
