@@ -10,10 +10,12 @@ value = (N^3/3 + M N^2) FLOP per step * steps * n_gpus / wall  in GFLOP/s (whole
 N GPUs: one process per GPU, each rank runs the same step at its own hyper-parameter vector (the path
 shards over independent hyper-parameter evaluations, weak scaling) and the per-rank results
 (log-determinant, alpha norm, predictive checksum) are all-gathered over RCCL / xGMI inside the timed
-region through the library's own communicator (gpmi_comm_*).  torch.distributed (gloo, CPU) provides
-rank / world / barrier and the RCCL unique-id bootstrap only: libgpmi is loaded BEFORE torch so that
-the process runs on the system ROCm 7.2 runtime — with torch's bundled HIP runtime initialised first
-the same kernels ran 2x slower with multi-10-ms stalls.
+region through the library's own communicator (gpmi_comm_*); barriers and the max-over-ranks of the
+timing are RCCL all-gathers too.  The ranks launched by torch.distributed.run read RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_PORT from the environment and exchange the RCCL unique id through a per-job
+directory in /tmp (inference_amd.sharding.FileRendezvous): torch itself is NOT imported, because
+importing it loads torch's bundled HIP / HSA runtime beside the system ROCm 7.2 one, and RCCL then
+binds to the uninitialised copy.
 
 Extra objects on the JSON line:
   roofline      the potrf trailing SYRK/GEMM update (fp64 MFMA bound): algorithmic FLOP per launch
@@ -90,13 +92,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo")
+    rdv = sharding.FileRendezvous(rank, world) if world > 1 else None
 
     N, d, M = args.n, args.d, args.m
     x, y, e = wl.synthetic_dataset(2, N, d)
@@ -109,10 +105,20 @@ def main():
     gather = "none"
     if world > 1:
         try:
-            sharding.init_device_comm(eng)
-            gather = "rccl"
+            sharding.init_device_comm_files(eng, rdv)
+            eng.comm_allgather(np.zeros(1))
+            ok = True
         except Exception as err:  # keep the scaling run alive: the gather is 4 doubles per rank
-            gather = f"gloo-fallback ({type(err).__name__}: {err})"
+            ok = False
+            why = f"{type(err).__name__}: {err}"
+        # every rank must take the same path
+        oks = rdv.allgather_obj(ok)
+        gather = "rccl" if all(oks) else f"file-fallback ({'; '.join(str(o) for o in oks)}{'' if ok else ' ' + why})"
+
+    def allgather(vec):
+        if gather == "rccl":
+            return eng.comm_allgather(vec)  # RCCL over xGMI: the only collective of the path
+        return np.array(rdv.allgather_obj(np.asarray(vec, dtype=float)))
 
     def step():
         gp.set_hyperparameters(theta)  # K-build + potrf + alpha
@@ -122,21 +128,16 @@ def main():
         # step time from the next step on (tools/phase_times3.py)
         res = np.array([gp._logdet, float(np.sqrt(np.sum(gp.alpha**2))), float(mu.sum()), float(sig.sum())])
         if world > 1:
-            if gather == "rccl":
-                res = eng.comm_allgather(res)  # RCCL over xGMI: the only collective of the path
-            else:
-                out = [None] * world
-                dist.all_gather_object(out, res)
-                res = np.array(out)
+            res = allgather(res)
         return res
 
     for _ in range(args.warmup):
         step()
 
     def fence():
-        if dist is not None:
-            dist.barrier()
         eng.sync()  # every stream of the library on this device (nothing else runs on the GPU)
+        if world > 1:
+            allgather(np.zeros(1))  # barrier over all ranks
 
     if not os.environ.get("BENCH_NO_PROF"):
         eng.profile_enable(2 << _lib.PROF_SYRK)
@@ -150,10 +151,8 @@ def main():
     prof = eng.profile_read(_lib.PROF_SYRK)
     eng.profile_enable(0)
 
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    if world > 1:
+        dt = float(np.max(allgather(np.array([dt]))))  # MAX over ranks
 
     flops_step = N**3 / 3.0 + M * float(N) ** 2
     value = flops_step * args.steps * world / dt / 1e9
@@ -196,9 +195,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(4096, d, 256)
         print(json.dumps(line), flush=True)
 
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rdv is not None:
+        rdv.close()
 
 
 if __name__ == "__main__":

@@ -150,7 +150,19 @@ class GpEngine:
         return buf.raw
 
     def comm_init(self, rank: int, world: int, unique_id: bytes):
-        self.h.call("gpmi_comm_init", int(rank), int(world), unique_id)
+        # RCCL prints a version banner on stdout from rank 0; keep stdout clean for callers that
+        # emit machine-readable output (bench.py prints one JSON line) by sending it to stderr
+        import os
+        import sys
+
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            self.h.call("gpmi_comm_init", int(rank), int(world), unique_id)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
         self.comm_world = world
 
     def comm_allgather(self, values):

@@ -13,6 +13,10 @@ broadcasting the RCCL unique id over the process group).  Without a device
 communicator (CPU tests) the gather falls back to the process group itself.
 There is no data-path collective: x, y are tiny and every rank builds them itself.
 """
+import os
+import pickle
+import time
+
 import numpy as np
 
 
@@ -87,3 +91,70 @@ def marginal_likelihood_sweep(gp, thetas):
     ranks (each rank drives its own GPU), results all-gathered."""
     eng = gp.engine if getattr(gp.engine, "comm_world", 0) > 1 else None
     return sharded_map(lambda th: gp.marginal_likelihood_batch(th), np.asarray(thetas, dtype=float), engine=eng)[:, 0]
+
+
+class FileRendezvous:
+    """Torch-free bootstrap for the ranks of ONE node (what `torch.distributed.run --nnodes=1`
+    launches): exchanges small byte strings through a per-job directory in /tmp.  Used to hand the
+    RCCL unique id to every rank — and as a last-resort gather if RCCL cannot be initialised — so
+    that a multi-GPU job never has to import torch (importing it loads torch's bundled HIP / HSA
+    runtime beside the system one, which RCCL then picks up uninitialised).
+    All ranks are children of the same launcher process, whose pid keys the directory."""
+
+    def __init__(self, rank=None, world=None, timeout=90.0):
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+        self.timeout = timeout
+        key = os.environ.get("GPMI_RDV_KEY") or f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}"
+        self.dir = os.path.join(os.environ.get("GPMI_RDV_DIR", "/tmp"), f"gpmi_rdv_{key}")
+        os.makedirs(self.dir, exist_ok=True)
+        self.round = 0
+
+    def allgather_obj(self, obj):
+        """Every rank contributes a picklable object; returns the list in rank order."""
+        self.round += 1
+        mine = os.path.join(self.dir, f"r{self.round}.{self.rank}")
+        with open(mine + ".tmp", "wb") as f:
+            pickle.dump(obj, f)
+        os.replace(mine + ".tmp", mine)
+        out, t0 = [], time.time()
+        for r in range(self.world):
+            path = os.path.join(self.dir, f"r{self.round}.{r}")
+            while not os.path.exists(path):
+                if time.time() - t0 > self.timeout:
+                    raise TimeoutError(f"rank {r} did not reach rendezvous round {self.round}")
+                time.sleep(0.002)
+            with open(path, "rb") as f:
+                out.append(pickle.load(f))
+        return out
+
+    def broadcast_obj(self, obj, src=0):
+        return self.allgather_obj(obj if self.rank == src else None)[src]
+
+    def barrier(self):
+        self.allgather_obj(0)
+
+    def close(self):
+        """Leave the rendezvous: every rank removes its own files, rank 0 the directory."""
+        self.barrier()
+        time.sleep(0.05)  # let the slowest reader of the last round finish
+        for name in os.listdir(self.dir):
+            if name.endswith(f".{self.rank}"):
+                try:
+                    os.remove(os.path.join(self.dir, name))
+                except OSError:
+                    pass
+        if self.rank == 0:
+            t0 = time.time()
+            while time.time() - t0 < 2.0:
+                try:
+                    os.rmdir(self.dir)
+                    break
+                except OSError:
+                    time.sleep(0.02)
+
+
+def init_device_comm_files(engine, rdv: "FileRendezvous"):
+    """RCCL communicator bootstrap over a FileRendezvous (no torch in the process)."""
+    uid = rdv.broadcast_obj(engine.comm_unique_id() if rdv.rank == 0 else None)
+    engine.comm_init(rdv.rank, rdv.world, uid)
