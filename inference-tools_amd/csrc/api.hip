@@ -163,8 +163,8 @@ int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const dou
   }
   if (c->ycov) launch_add_full(s, L.A, c->ld, c->ycov, c->n);
   potrf_lower(c, L, L.A, c->np, c->ld, L.invD, L.info + slot);
-  launch_residual(s, c->y, mu_dev, mu_const, L.vec, c->n, c->np);
-  trsv_forward(c, s, L.A, c->np, c->ld, L.invD, L.vec);
+  launch_residual(s, c->y, mu_dev, mu_const, L.vec + 2 * c->np, c->n, c->np);
+  trsv_forward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, L.vec);
   launch_lml_reduce(s, L.vec, L.A, c->ld, c->np, L.red + 2 * slot);
   HIPCHK(c, hipGetLastError());
   return GPMI_OK;
@@ -365,8 +365,8 @@ int gpmi_fit(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double e
   if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
   const auto h1 = std::chrono::steady_clock::now();
   // alpha = L^-T v
-  launch_copy(s, L.vec, c->alpha, c->np);
-  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, c->alpha);
+  launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, c->alpha);
   HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
   if (alpha_out)
@@ -475,8 +475,8 @@ int gpmi_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
   double* gout = L.red + 16;  // n_theta + 1 values (n_theta <= GPMI_MAX_D + 2)
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
   if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
-  launch_copy(s, L.vec, alpha_dev, c->np);
-  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, alpha_dev);
+  launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev);
   // K^-1 = L^-T L^-1 (regression.py:556-557), lower tiles, overwriting L
   enqueue_inverse_factor(c, L, L.A, L.invD);
   launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, true, L.A, c->ld, L.B2, c->ld, L.B2, c->ld,
@@ -668,8 +668,8 @@ int gpmi_loo_terms(gpmi_ctx* c, int kernel, const double* theta, int n_theta, do
   double* diag_dev = L.vec + 2 * c->np;
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
   if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
-  launch_copy(s, L.vec, alpha_dev, c->np);
-  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, alpha_dev);
+  launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev);
   enqueue_inverse_factor(c, L, L.A, L.invD);
   launch_rows_sumsq(s, L.B2, c->ld, c->np, c->np, 0.0, diag_dev);
   HIPCHK(c, hipGetLastError());

@@ -143,12 +143,12 @@ void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t l
                  int* info);
 
 // solve.hip
-// forward substitution  L v = r  (in place on r), single right-hand side
+// forward substitution  L v = r : r is consumed as scratch, the solution goes to `out` (no aliasing)
 void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                  const double* invD, double* r);
-// backward substitution  L^T a = v  (in place)
+                  const double* invD, double* r, double* out);
+// backward substitution  L^T a = v : v (in r) is consumed as scratch, the solution goes to `out`
 void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                   const double* invD, double* r);
+                   const double* invD, double* r, double* out);
 // Q (mp x np, row-major, ld) <- Q L^-T   (forward solve of mp right-hand sides stored as rows)
 void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
                        const double* invD, double* Q, int64_t mp, bool upper_rhs = false);

@@ -17,64 +17,94 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
-// out[0:128] = invD (128 x 128, lower) * r[0:128]        (one workgroup, one wave per row)
-__global__ __launch_bounds__(256) void diag_apply_kernel(const double* __restrict__ invD,
-                                                         double* __restrict__ r) {
+// ---- fused single-right-hand-side sweeps -------------------------------------------------------
+// One launch per 128-block (instead of a diagonal-apply launch plus a panel launch): every
+// workgroup recomputes the 128-vector of the block itself (a 128 x 128 GEMV out of L2, ~1 us) and
+// then applies it to its own 64 rows / columns of L, so the only serialisation left is the kernel
+// boundary.  Small workgroup slices (64 KiB of L each) keep every CU under its ~10 B/clk load limit.
+
+// forward, block k:  v = invD_k r_k ;  block 0 of the grid stores v to vout ;  r[rows below] -= L[rows, k] v
+// (r_k itself is left untouched: other workgroups of the launch are still reading it)
+__global__ __launch_bounds__(256) void trsv_fwd_step_kernel(const double* __restrict__ Lp, int64_t ld,
+                                                            const double* __restrict__ invD,
+                                                            const double* __restrict__ rk,
+                                                            double* __restrict__ vout,
+                                                            double* __restrict__ rbelow, int64_t rows) {
   __shared__ double rin[NB];
-  __shared__ double rout[NB];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < NB) rin[tid] = r[tid];
+  __shared__ double v[NB];
+  const int tid = threadIdx.x;
+  if (tid < NB) rin[tid] = rk[tid];
   __syncthreads();
-  for (int row = wave; row < NB; row += 4) {
-    double s = invD[row * NB + lane] * rin[lane] + invD[row * NB + 64 + lane] * rin[64 + lane];
-    s = wave_sum(s);
-    if (lane == 0) rout[row] = s;
-  }
-  __syncthreads();
-  if (tid < NB) r[tid] = rout[tid];
-}
-
-// out[c] = sum_i invD[i][c] * r[i]   (transposed apply, thread per column)
-__global__ __launch_bounds__(128) void diag_apply_t_kernel(const double* __restrict__ invD,
-                                                           double* __restrict__ r) {
-  __shared__ double rin[NB];
-  const int c = threadIdx.x;
-  rin[c] = r[c];
-  __syncthreads();
-  double s = 0.0;
-  for (int i = 0; i < NB; ++i) s = fma(invD[i * NB + c], rin[i], s);  // zero above the diagonal
-  r[c] = s;
-}
-
-// forward sweep: r[i] -= sum_c Lpanel[i][c] * v[c]  for `rows` rows below the block (wave per row)
-__global__ __launch_bounds__(256) void gemv_panel_kernel(const double* __restrict__ Lp, int64_t ld,
-                                                         const double* __restrict__ v,
-                                                         double* __restrict__ r, int64_t rows) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t nw = (int64_t)gridDim.x * 4;
-  const double v0 = v[lane], v1 = v[64 + lane];
-  for (int64_t row = wave; row < rows; row += nw) {
-    const double* p = Lp + row * ld;
-    double s = wave_sum(p[lane] * v0 + p[64 + lane] * v1);
-    if (lane == 0) r[row] -= s;
-  }
-}
-
-// backward sweep: r[j] -= sum_i Lrow[i][j] * a[i]  for `cols` columns left of the block (thread per column)
-__global__ __launch_bounds__(256) void gemv_rowblock_t_kernel(const double* __restrict__ Lr,
-                                                              int64_t ld,
-                                                              const double* __restrict__ a,
-                                                              double* __restrict__ r, int64_t cols) {
-  __shared__ double as[NB];
-  if (threadIdx.x < NB) as[threadIdx.x] = a[threadIdx.x];
-  __syncthreads();
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= cols) return;
-  double s = 0.0;
+  {
+    // v[row] = sum_c invD[row][c] rin[c]: two threads per row, 64 columns each (invD is lower triangular)
+    const int row = tid >> 1, half = tid & 1;
+    const double* p = invD + row * NB + half * 64;
+    double s = 0.0;
 #pragma unroll 8
-  for (int i = 0; i < NB; ++i) s = fma(Lr[(int64_t)i * ld + j], as[i], s);
-  r[j] -= s;
+    for (int c = 0; c < 64; c += 2) {
+      const d2_t a = *reinterpret_cast<const d2_t*>(p + c);
+      s = fma(a[0], rin[half * 64 + c], s);
+      s = fma(a[1], rin[half * 64 + c + 1], s);
+    }
+    s += __shfl_xor(s, 1, 64);
+    if (half == 0) v[row] = s;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < NB) vout[tid] = v[tid];
+  // rows below: 64 rows per workgroup, 4 threads per row (32 columns each)
+  const int64_t row = (int64_t)blockIdx.x * 64 + (tid >> 2);
+  const int part = tid & 3;
+  double s = 0.0;
+  if (row < rows) {
+    const double* p = Lp + row * ld + part * 32;
+#pragma unroll 8
+    for (int c = 0; c < 32; c += 2) {
+      const d2_t a = *reinterpret_cast<const d2_t*>(p + c);
+      s = fma(a[0], v[part * 32 + c], s);
+      s = fma(a[1], v[part * 32 + c + 1], s);
+    }
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  if (row < rows && part == 0) rbelow[row] -= s;
+}
+
+// backward, block k:  a = invD_k^T r_k ;  block 0 stores a to aout ;  r[j] -= sum_i L[k-block row i][j] a[i], j < cols
+__global__ __launch_bounds__(256) void trsv_bwd_step_kernel(const double* __restrict__ Lr, int64_t ld,
+                                                            const double* __restrict__ invD,
+                                                            const double* __restrict__ rk,
+                                                            double* __restrict__ aout,
+                                                            double* __restrict__ r, int64_t cols) {
+  __shared__ double rin[NB];
+  __shared__ double part[2 * NB];
+  __shared__ double a[NB];
+  __shared__ double red[4 * 64];
+  const int tid = threadIdx.x;
+  if (tid < NB) rin[tid] = rk[tid];
+  __syncthreads();
+  {
+    // a[c] = sum_i invD[i][c] rin[i]: thread (half, c) sums 64 rows; coalesced along c
+    const int c = tid & 127, half = tid >> 7;
+    double s = 0.0;
+#pragma unroll 8
+    for (int i = half * 64; i < half * 64 + 64; ++i) s = fma(invD[i * NB + c], rin[i], s);
+    part[half * NB + c] = s;
+  }
+  __syncthreads();
+  if (tid < NB) a[tid] = part[tid] + part[NB + tid];
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < NB) aout[tid] = a[tid];
+  // columns left of the block: 64 columns per workgroup, 4 row groups of 32 rows
+  const int64_t j = (int64_t)blockIdx.x * 64 + (tid & 63);
+  const int rg = tid >> 6;
+  double s = 0.0;
+  if (j < cols) {
+#pragma unroll 8
+    for (int i = rg * 32; i < rg * 32 + 32; ++i) s = fma(Lr[(int64_t)i * ld + j], a[i], s);
+  }
+  red[rg * 64 + (tid & 63)] = s;
+  __syncthreads();
+  if (tid < 64 && j < cols) r[j] -= red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
 }
 
 __global__ void set_identity_kernel(double* __restrict__ Q, int64_t ld, int64_t np) {
@@ -166,35 +196,27 @@ __global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restric
 }  // namespace
 
 void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                  const double* invD, double* r) {
+                  const double* invD, double* r, double* out) {
   const int nt = (int)(np / NB);
   ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)np * np, 4.0 * np * np);
   for (int k = 0; k < nt; ++k) {
-    hipLaunchKernelGGL(diag_apply_kernel, dim3(1), dim3(256), 0, s, invD + (int64_t)k * NB * NB,
-                       r + (int64_t)k * NB);
     const int64_t rows = np - (int64_t)(k + 1) * NB;
-    if (rows > 0) {
-      int64_t blocks = (rows + 3) / 4;
-      if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(gemv_panel_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-                         L + (int64_t)(k + 1) * NB * ld + (int64_t)k * NB, ld, r + (int64_t)k * NB,
-                         r + (int64_t)(k + 1) * NB, rows);
-    }
+    const unsigned blocks = rows > 0 ? (unsigned)((rows + 63) / 64) : 1u;
+    hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(blocks), dim3(256), 0, s,
+                       L + (int64_t)(k + 1) * NB * ld + (int64_t)k * NB, ld, invD + (int64_t)k * NB * NB,
+                       r + (int64_t)k * NB, out + (int64_t)k * NB, r + (int64_t)(k + 1) * NB, rows);
   }
 }
 
 void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                   const double* invD, double* r) {
+                   const double* invD, double* r, double* out) {
   const int nt = (int)(np / NB);
   ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)np * np, 4.0 * np * np);
   for (int k = nt - 1; k >= 0; --k) {
-    hipLaunchKernelGGL(diag_apply_t_kernel, dim3(1), dim3(128), 0, s, invD + (int64_t)k * NB * NB,
-                       r + (int64_t)k * NB);
     const int64_t cols = (int64_t)k * NB;
-    if (cols > 0) {
-      hipLaunchKernelGGL(gemv_rowblock_t_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0,
-                         s, L + (int64_t)k * NB * ld, ld, r + (int64_t)k * NB, r, cols);
-    }
+    const unsigned blocks = cols > 0 ? (unsigned)((cols + 63) / 64) : 1u;
+    hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(blocks), dim3(256), 0, s, L + (int64_t)k * NB * ld, ld,
+                       invD + (int64_t)k * NB * NB, r + (int64_t)k * NB, out + (int64_t)k * NB, r, cols);
   }
 }
 
