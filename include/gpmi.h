@@ -136,6 +136,15 @@ int gpmi_spatial_derivatives(gpmi_ctx* ctx, const double* pts_host, int64_t m, d
 int gpmi_gradient(gpmi_ctx* ctx, const double* pts_host, int64_t m, double* gmu_host,
                   double* gcov_host);
 
+/* Replaces GpRegressor.loo_likelihood_gradient (regression.py:489-526): besides alpha and diag(K^-1)
+ * returns p = K^-1 (alpha / diag) (for the mean-parameter gradients, regression.py:516-520) and
+ *   grad_theta_host[j] = sum_ab dK_j[a][b] (sym(p alpha^T) - K^-1 diag(c2) K^-1)_ab   (regression.py:511-514)
+ *   trace_q_host       = trace of that matrix (WhiteNoise gradient = 2 sigma^2 trace).
+ * No sentinel: info != 0 makes the host raise, as regression.py:501 has no LinAlgError guard. */
+int gpmi_loo_grad(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_theta, double extra_diag,
+                  const double* mu_host, double* alpha_host, double* ikdiag_host, double* p_host,
+                  double* grad_theta_host, double* trace_q_host, int* info);
+
 /* ---- covariance plugin surface -----------------------------------------------------
  * Replaces CovarianceFunction.build_covariance (covariance.py:247-255, 343-348): the n x n matrix
  * a^2 (C + 1e-12 I) + extra_diag I, plus the data-error covariance when with_noise != 0. */

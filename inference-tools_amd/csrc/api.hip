@@ -204,6 +204,11 @@ int ensure_query_ws(gpmi_ctx* c, int64_t mp) {
 
 // ---- instrumentation ----------------------------------------------------------------
 namespace {
+__global__ void negate_kernel(double* v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = -v[i];
+}
+
 __global__ void stamp_init_kernel(unsigned long long* pool, int slots) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < slots) {
@@ -481,7 +486,7 @@ int gpmi_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
   enqueue_inverse_factor(c, L, L.A, L.invD);
   launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, true, L.A, c->ld, L.B2, c->ld, L.B2, c->ld,
               (int)(c->np / GPMI_NB), (int)(c->np / GPMI_NB), (int)c->np);
-  launch_lml_grad(s, p, n_theta, c->x, c->n, c->np, L.A, c->ld, alpha_dev, L.gws, gout);
+  launch_lml_grad(s, p, n_theta, c->x, c->n, c->np, L.A, c->ld, alpha_dev, alpha_dev, L.gws, gout);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(L.h_red + 16, gout, sizeof(double) * (n_theta + 1),
@@ -678,6 +683,70 @@ int gpmi_loo_terms(gpmi_ctx* c, int kernel, const double* theta, int n_theta, do
   HIPCHK(c, hipMemcpyAsync(ikdiag, diag_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   for (int64_t i = 0; i < c->n; ++i) ikdiag[i] = -ikdiag[i];
+  if (info) *info = L.h_info[0];
+  return GPMI_OK;
+}
+
+int gpmi_loo_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,
+                  const double* mu, double* alpha_out, double* ikdiag, double* p_out,
+                  double* grad_theta, double* trace_q, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  KParams p;
+  if (int rc = make_params(c, kernel, theta, n_theta, extra_diag, p)) return rc;
+  ARGCHK(c, mu && alpha_out && ikdiag && p_out && grad_theta, "NULL argument");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = ensure_lanes(c, 2)) return rc;
+  Lane& L = c->lanes[1];
+  if (int rc = ensure_second_matrix(c, L)) return rc;
+  const int64_t need = grad_ws_doubles(c->np, n_theta) + 4 * c->np;
+  if (L.gws_doubles < need) {
+    if (L.gws) (void)hipFree(L.gws);
+    L.gws = nullptr;
+    L.gws_doubles = 0;
+    HIPCHK(c, hipMalloc(&L.gws, sizeof(double) * need));
+    L.gws_doubles = need;
+  }
+  hipStream_t s = L.stream;
+  const int nt = (int)(c->np / GPMI_NB);
+  double* mu_dev = L.vec + 3 * c->np;
+  double* alpha_dev = L.vec + c->np;
+  double* diag_dev = L.gws;              // 4 extra vectors live in front of the partial sums
+  double* c1_dev = L.gws + c->np;
+  double* sc2_dev = L.gws + 2 * c->np;
+  double* p_dev = L.gws + 3 * c->np;
+  double* partial = L.gws + 4 * c->np;
+  double* gout = L.red + 16;
+  HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
+  if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
+  launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev);
+  // K^-1 (full, both triangles) in A
+  enqueue_inverse_factor(c, L, L.A, L.invD);
+  launch_rows_sumsq(s, L.B2, c->ld, c->np, c->np, 0.0, diag_dev);  // = -diag(K^-1)
+  launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, true, L.A, c->ld, L.B2, c->ld, L.B2, c->ld, nt, nt,
+              (int)c->np);
+  launch_mirror_lower(s, L.A, c->ld, c->np);
+  // diag_dev holds -diag: flip sign inside the vector kernel by passing it through a scaled copy
+  hipLaunchKernelGGL(negate_kernel, dim3((unsigned)((c->np + 255) / 256)), dim3(256), 0, s,
+                     diag_dev, c->np);
+  launch_loo_vectors(s, alpha_dev, diag_dev, c1_dev, sc2_dev, c->n, c->np);
+  // p = K^-1 c1  (regression.py:512-513, 518-519 folded: c1^T K^-1 dK_j alpha = p^T dK_j alpha)
+  launch_rows_dot(s, L.A, c->ld, c->np, c->np, c1_dev, p_dev);
+  // M = K^-1 diag(c2) K^-1 = G G^T with G = K^-1 diag(sqrt c2); lower tiles, overwriting K^-1
+  launch_scale_columns(s, L.A, sc2_dev, L.B2, c->ld, c->np);
+  launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, false, L.A, c->ld, L.B2, c->ld, L.B2, c->ld, nt, nt,
+              (int)c->np);
+  launch_lml_grad(s, p, n_theta, c->x, c->n, c->np, L.A, c->ld, p_dev, alpha_dev, partial, gout);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(L.h_red + 16, gout, sizeof(double) * (n_theta + 1), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(alpha_out, alpha_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(ikdiag, diag_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(p_out, p_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  // the contraction returns 1/2 sum Q o dK; the LOO gradient has no 1/2 (regression.py:513)
+  for (int j = 0; j < n_theta; ++j) grad_theta[j] = 2.0 * L.h_red[16 + j];
+  if (trace_q) *trace_q = L.h_red[16 + n_theta];
   if (info) *info = L.h_info[0];
   return GPMI_OK;
 }
@@ -901,6 +970,18 @@ int gpmi_dev_potrf(gpmi_ctx* c, double* A, int64_t n, int64_t ld, int* info) {
   HIPCHK(c, hipMalloc(&invD, sizeof(double) * (n / GPMI_NB) * GPMI_NB * GPMI_NB));
   HIPCHK(c, hipMalloc(&dinfo, sizeof(int)));
   HIPCHK(c, hipMemsetAsync(dinfo, 0, sizeof(int), s));
+  if (n == GPMI_NB && std::getenv("GPMI_DIAG_STAMPS")) {
+    // tools only: phase cycle counts of one potrf_diag launch
+    unsigned long long* dbg = nullptr;
+    HIPCHK(c, hipMalloc(&dbg, 6 * sizeof(unsigned long long)));
+    launch_potrf_diag(s, A, ld, invD, dinfo, 0, dbg);
+    unsigned long long h[6];
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "[potrf_diag cycles] load %llu | factor16 x8 %llu | panel %llu | trailing %llu | store L %llu | inverse %llu\n",
+                 h[0], h[1], h[2], h[3], h[4], h[5]);
+    (void)hipFree(dbg);
+  } else
   potrf_lower(c, c->lanes[0], A, n, ld, invD, dinfo);
   int h = 0;
   hipError_t e = hipMemcpyAsync(&h, dinfo, sizeof(int), hipMemcpyDeviceToHost, s);

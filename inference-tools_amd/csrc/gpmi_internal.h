@@ -119,9 +119,15 @@ void launch_add_full(hipStream_t s, double* A, int64_t ld, const double* Y, int6
 // grad.hip: fused contraction 1/2 sum (alpha alpha^T - K^-1) o dK/dtheta_j with dK recomputed from x.
 // out[0..n_theta) = gradient, out[n_theta] = sum_i (alpha_i^2 - K^-1_ii).  iK holds K^-1 (lower tiles).
 int64_t grad_ws_doubles(int64_t np, int n_theta);
+// general form: Q_ab = 1/2 (u_a v_b + u_b v_a) - iK_ab  (LML gradient: u = v = alpha)
 void launch_lml_grad(hipStream_t s, const KParams& p, int n_theta, const double* x, int64_t n,
-                     int64_t np, const double* iK, int64_t ld, const double* alpha, double* ws,
-                     double* out);
+                     int64_t np, const double* iK, int64_t ld, const double* u, const double* v,
+                     double* ws, double* out);
+void launch_mirror_lower(hipStream_t s, double* A, int64_t ld, int64_t np);
+void launch_scale_columns(hipStream_t s, const double* A, const double* sc, double* G, int64_t ld,
+                          int64_t np);
+void launch_loo_vectors(hipStream_t s, const double* alpha, const double* ikdiag, double* c1,
+                        double* sc2, int64_t n, int64_t np);
 
 // gemm_f64.hip  (all dims multiples of 128, k multiple of 16)
 enum GemmTiles { TILES_RECT = 0, TILES_LOWER = 1 };
@@ -137,7 +143,8 @@ void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, bool 
                  int ntc, int k, unsigned long long* stamp = nullptr);
 
 // potrf.hip
-void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0);
+void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0,
+                       unsigned long long* dbg = nullptr);
 // blocked right-looking Cholesky, in place, lower; invD receives the inverses of the diagonal blocks
 void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t ld, double* invD,
                  int* info);

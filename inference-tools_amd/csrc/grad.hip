@@ -3,6 +3,8 @@
 // Replaces the dense gradient matrices of covariance_and_gradients (covariance.py:268-276, 350-365:
 // d+1 / d+2 N x N arrays) and the reductions of regression.py:565-566
 //     grad_j = 1/2 sum_ab (alpha_a alpha_b - K^-1_ab) dK_j[a][b]
+// and, with u = K^-1 c1, v = alpha, M = K^-1 diag(c2) K^-1, the leave-one-out gradient of
+// regression.py:508-514 (the same contraction: sum_ab dK_j[a][b] (sym(u v^T) - M)_ab)
 // by one pass over the lower triangle of K^-1: every 64 x 64 tile recomputes K and dK_j from the
 // staged point panels, weights them with Q_ab = alpha_a alpha_b - K^-1_ab (off-diagonal elements
 // counted twice) and reduces to one partial per tile and parameter; a second kernel sums the
@@ -31,7 +33,8 @@ __device__ inline double block_sum(double v, double* red) {
 __global__ __launch_bounds__(256) void lml_grad_kernel(KParams p, int n_theta,
                                                        const double* __restrict__ x, int64_t n,
                                                        const double* __restrict__ iK, int64_t ld,
-                                                       const double* __restrict__ alpha,
+                                                       const double* __restrict__ uvec,
+                                                       const double* __restrict__ vvec,
                                                        double* __restrict__ ws) {
   const int ti = blockIdx.y, tj = blockIdx.x;
   if (tj > ti) return;
@@ -69,13 +72,14 @@ __global__ __launch_bounds__(256) void lml_grad_kernel(KParams p, int n_theta,
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t ga = i0 + ty * 4 + r;
-    const double aa = (ga < n) ? alpha[ga] : 0.0;
+    const double ua = (ga < n) ? uvec[ga] : 0.0;
+    const double va = (ga < n) ? vvec[ga] : 0.0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int64_t gb = j0 + tx * 4 + c;
       double w = 0.0;
       if (ga < n && gb <= ga) {
-        const double q = aa * alpha[gb] - iK[ga * ld + gb];
+        const double q = 0.5 * (ua * vvec[gb] + va * uvec[gb]) - iK[ga * ld + gb];
         w = (ga == gb) ? 0.5 * q : q;
         if (ga == gb) tq += q;
       }
@@ -134,7 +138,65 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restri
   if (threadIdx.x == 0) out[j] = v;
 }
 
+// A[j][i] = A[i][j] for j > i (tile-wise through LDS so that both sides are coalesced)
+__global__ __launch_bounds__(256) void mirror_lower_kernel(double* __restrict__ A, int64_t ld) {
+  __shared__ double t[64][65];
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (tj > ti) return;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) t[r][tx] = A[((int64_t)ti * 64 + r) * ld + (int64_t)tj * 64 + tx];
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int64_t row = (int64_t)tj * 64 + r, col = (int64_t)ti * 64 + tx;
+    if (col > row) A[row * ld + col] = t[tx][r];
+  }
+}
+
+// G[b][a] = A[b][a] * s[a]
+__global__ void scale_columns_kernel(const double* __restrict__ A, const double* __restrict__ s,
+                                     double* __restrict__ G, int64_t ld, int64_t np) {
+  const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  const int64_t i = blockIdx.y;
+  if (j >= np) return;
+  const d2_t a = *reinterpret_cast<const d2_t*>(A + i * ld + j);
+  *reinterpret_cast<d2_t*>(G + i * ld + j) = d2_t{a[0] * s[j], a[1] * s[j + 1]};
+}
+
+// leave-one-out vectors (regression.py:505-510): var = 1 / diag(K^-1), c1 = alpha var,
+// sqrt(c2) with c2 = 1/2 var (1 + var alpha^2); zero in the padding
+__global__ void loo_vectors_kernel(const double* __restrict__ alpha, const double* __restrict__ ikdiag,
+                                   double* __restrict__ c1, double* __restrict__ sc2, int64_t n,
+                                   int64_t np) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  double a = 0.0, b = 0.0;
+  if (i < n) {
+    const double var = 1.0 / ikdiag[i];
+    a = alpha[i] * var;
+    b = sqrt(0.5 * var * (1.0 + var * alpha[i] * alpha[i]));
+  }
+  c1[i] = a;
+  sc2[i] = b;
+}
+
 }  // namespace
+
+void launch_mirror_lower(hipStream_t s, double* A, int64_t ld, int64_t np) {
+  dim3 grid((unsigned)(np / 64), (unsigned)(np / 64));
+  hipLaunchKernelGGL(mirror_lower_kernel, grid, dim3(256), 0, s, A, ld);
+}
+
+void launch_scale_columns(hipStream_t s, const double* A, const double* sc, double* G, int64_t ld,
+                          int64_t np) {
+  dim3 grid((unsigned)((np / 2 + 255) / 256), (unsigned)np);
+  hipLaunchKernelGGL(scale_columns_kernel, grid, dim3(256), 0, s, A, sc, G, ld, np);
+}
+
+void launch_loo_vectors(hipStream_t s, const double* alpha, const double* ikdiag, double* c1,
+                        double* sc2, int64_t n, int64_t np) {
+  hipLaunchKernelGGL(loo_vectors_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, alpha,
+                     ikdiag, c1, sc2, n, np);
+}
 
 int64_t grad_ws_doubles(int64_t np, int n_theta) {
   const int64_t t = np / KT;
@@ -142,11 +204,11 @@ int64_t grad_ws_doubles(int64_t np, int n_theta) {
 }
 
 void launch_lml_grad(hipStream_t s, const KParams& p, int n_theta, const double* x, int64_t n,
-                     int64_t np, const double* iK, int64_t ld, const double* alpha, double* ws,
-                     double* out) {
+                     int64_t np, const double* iK, int64_t ld, const double* u, const double* v,
+                     double* ws, double* out) {
   const int64_t t = np / KT;
   dim3 grid((unsigned)t, (unsigned)t);
-  hipLaunchKernelGGL(lml_grad_kernel, grid, dim3(256), 0, s, p, n_theta, x, n, iK, ld, alpha, ws);
+  hipLaunchKernelGGL(lml_grad_kernel, grid, dim3(256), 0, s, p, n_theta, x, n, iK, ld, u, v, ws);
   hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(n_theta + 1)), dim3(256), 0, s, ws,
                      t * (t + 1) / 2, n_theta + 1, out);
 }

@@ -105,26 +105,58 @@ __device__ inline void factor16(double* S, double* Wl, double* __restrict__ invD
 // row-blocks are read back through L2).
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A, int64_t ld,
                                                          double* __restrict__ invD,
-                                                         int* __restrict__ info, int col0) {
+                                                         int* __restrict__ info, int col0,
+                                                         unsigned long long* __restrict__ dbg) {
+  // dbg != nullptr (tools only): cycle stamps of the phases, accumulated by wave 0
+  unsigned long long t_prev = 0, acc_t[6] = {0, 0, 0, 0, 0, 0};
+  auto lap = [&](int slot) {
+    if (dbg) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      acc_t[slot] += t - t_prev;
+      t_prev = t;
+    }
+  };
+  if (dbg) t_prev = __builtin_amdgcn_s_memtime();
   __shared__ double S[S_DOUBLES];
   __shared__ double Wl[BS * WP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int r = idx >> 7, c = idx & 127;
-    if ((c >> 4) <= (r >> 4)) {
-      // the upper part of a diagonal 16-block is mirrored from the lower triangle of A
-      const double v = (c <= r) ? A[(int64_t)r * ld + c] : A[(int64_t)c * ld + r];
-      S[prow(r) + c] = v;
-    } else {
-      invD[idx] = 0.0;
+  {
+    // coalesced 16-byte loads, all 32 of a thread in flight before the first LDS store: row = (tid >> 6) + 4 i,
+    // columns 2 (tid & 63) .. + 1.  Only the block-lower part is needed; the upper part of a diagonal
+    // 16-block is mirrored from the lower triangle of A (both copies written from the lower element).
+    const int cc = (tid & 63) * 2;
+    d2_t v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int r = (tid >> 6) + 4 * i;
+      v[i] = (cc <= r) ? *reinterpret_cast<const d2_t*>(A + (int64_t)r * ld + cc) : d2_t{0.0, 0.0};
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int r = (tid >> 6) + 4 * i;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = cc + e;
+        if (c <= r) {
+          S[prow(r) + c] = v[i][e];
+          if ((c >> 4) == (r >> 4)) S[prow(c) + r] = v[i][e];  // mirror inside the diagonal block
+        }
+      }
+    }
+    // zero the strictly-upper blocks of the inverse
+    for (int idx = tid; idx < NB * NB / 2; idx += 256) {
+      const int r = idx >> 6, c = (idx & 63) * 2;
+      if ((c >> 4) > (r >> 4)) *reinterpret_cast<d2_t*>(invD + r * NB + c) = d2_t{0.0, 0.0};
     }
   }
   __syncthreads();
+  lap(0);
   for (int kb = 0; kb < NBLK; ++kb) {
     const int base = kb * BS;
     if (wave == 0) factor16(S, Wl, invD, kb, info, col0, lane);
     __syncthreads();
+    lap(1);
     // panel: A[ib][kb] <- A[ib][kb] * W^T
     for (int ib = kb + 1 + wave; ib < NBLK; ib += 4) {
       d4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -139,6 +171,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
       for (int r = 0; r < 4; ++r) S[prow(ib * BS + fk + 4 * r) + base + fr] = acc[r];
     }
     __syncthreads();
+    lap(2);
     // trailing: A[ib][jb] -= P_ib P_jb^T for ib >= jb > kb (diagonal tiles computed in full: symmetric)
     const int m = NBLK - 1 - kb;
     const int ntile = m * (m + 1) / 2;
@@ -162,45 +195,64 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
       for (int r = 0; r < 4; ++r) S[rc[r]] = acc[r];
     }
     __syncthreads();
+    lap(3);
   }
   // L back to global memory (lower triangle incl. diagonal; the upper triangle of A is untouched)
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int r = idx >> 7, c = idx & 127;
-    if (c <= r) A[(int64_t)r * ld + c] = S[prow(r) + c];
+  for (int idx = tid; idx < NB * NB / 2; idx += 256) {
+    const int r = idx >> 6, c = (idx & 63) * 2;
+    if (c + 1 <= r)
+      *reinterpret_cast<d2_t*>(A + (int64_t)r * ld + c) = d2_t{S[prow(r) + c], S[prow(r) + c + 1]};
+    else if (c == r)
+      A[(int64_t)r * ld + c] = S[prow(r) + c];
   }
+  __syncthreads();
+  lap(4);
   // inverse, row-block by row-block (the barrier orders the global writes of one row-block before
-  // the reads of the next: same CU, lines never read before they are written)
+  // the reads of the next: same CU, lines never read before they are written).  All the operands a
+  // tile needs from global memory are requested up front so that their L2 latency overlaps.
   for (int ib = 1; ib < NBLK; ++ib) {
     for (int jb = wave; jb < ib; jb += 4) {
+      double bx[NBLK - 1][4], wv[4];
+#pragma unroll
+      for (int kk = 0; kk < NBLK - 1; ++kk) {
+        const int kb = jb + kk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          bx[kk][q] = (kb < ib) ? invD[(kb * BS + fk + 4 * q) * NB + jb * BS + fr] : 0.0;  // X[kb][jb]
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wv[q] = -invD[(ib * BS + fr) * NB + ib * BS + fk + 4 * q];  // -W_ib
       d4_t T = {0.0, 0.0, 0.0, 0.0};
       const int ra = prow(ib * BS + fr) + fk;
-      for (int kb = jb; kb < ib; ++kb) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const double av = S[ra + kb * BS + 4 * q];                                    // L[ib][kb]
-          const double bv = invD[(kb * BS + fk + 4 * q) * NB + jb * BS + fr];           // X[kb][jb]
-          T = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, T, 0, 0, 0);
+      for (int kk = 0; kk < NBLK - 1; ++kk) {
+        const int kb = jb + kk;
+        if (kb < ib) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            T = __builtin_amdgcn_mfma_f64_16x16x4f64(S[ra + kb * BS + 4 * q], bx[kk][q], T, 0, 0, 0);
         }
       }
       // the D layout of T (row = fk + 4 r) is exactly the B-operand layout of k-step q = r
       d4_t X = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double av = -invD[(ib * BS + fr) * NB + ib * BS + fk + 4 * q];            // W_ib
-        X = __builtin_amdgcn_mfma_f64_16x16x4f64(av, T[q], X, 0, 0, 0);
-      }
+      for (int q = 0; q < 4; ++q) X = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q], T[q], X, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) invD[(ib * BS + fk + 4 * r) * NB + jb * BS + fr] = X[r];
     }
     __threadfence_block();
     __syncthreads();
   }
+  lap(5);
+  if (dbg && tid == 0)
+    for (int i = 0; i < 6; ++i) dbg[i] = acc_t[i];
 }
 
 }  // namespace
 
-void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0) {
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, s, Ablk, ld, invD, info, col0);
+void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0,
+                       unsigned long long* dbg) {
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, s, Ablk, ld, invD, info, col0, dbg);
 }
 
 namespace {

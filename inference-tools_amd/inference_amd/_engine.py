@@ -140,6 +140,17 @@ class GpEngine:
                     dptr(alpha), dptr(ikdiag), C.byref(info))
         return alpha, ikdiag, info.value
 
+    def loo_grad(self, kernel, theta_cov, extra_diag, mu):
+        theta = as_f64(theta_cov)
+        mu = as_f64(mu)
+        alpha, ikdiag, pvec = np.empty(self.n), np.empty(self.n), np.empty(self.n)
+        grad = np.empty(theta.size)
+        trq = C.c_double(0.0)
+        info = C.c_int(0)
+        self.h.call("gpmi_loo_grad", kernel, dptr(theta), theta.size, float(extra_diag), dptr(mu),
+                    dptr(alpha), dptr(ikdiag), dptr(pvec), dptr(grad), C.byref(trq), C.byref(info))
+        return alpha, ikdiag, pvec, grad, trq.value, info.value
+
     # -- multi-GPU gather (RCCL) -----------------------------------------------------------
     @staticmethod
     def comm_unique_id() -> bytes:

@@ -381,7 +381,24 @@ class GpRegressor:
         return float(-0.5 * (var * alpha**2 + np.log(var)).sum())
 
     def loo_likelihood_gradient(self, theta: ndarray):
-        raise NotImplementedError("loo_likelihood_gradient: device path not built yet")
+        """LOO log-likelihood and its gradient, R&W eqs. 5.10-5.14 (regression.py:489-526)."""
+        theta = np.asarray(theta, dtype=float)
+        theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
+        mu, grad_mu = self.mean.mean_and_gradients(theta[self.mean_slice])
+        alpha, ikdiag, pvec, g_stat, trace_q, info = self.engine.loo_grad(self._kernel_id, theta_stat, extra, mu)
+        if info != 0:
+            raise LinAlgError("Matrix is not positive definite")  # regression.py:501 has no guard
+        var = 1.0 / ikdiag
+        LOO = float(-0.5 * (var * alpha**2 + np.log(var)).sum())
+        grad = zeros(self.n_hyperpars)
+        # sum(c1 * (iK @ dmu)) = (iK @ c1) . dmu   (regression.py:516-520)
+        grad[self.mean_slice] = array([(pvec * dmu).sum() for dmu in grad_mu])
+        g_cov = zeros(self.cov.n_params)
+        g_cov[self._stat_slice] = g_stat
+        if self._wn_index is not None:
+            g_cov[self._wn_index] = 2.0 * extra * trace_q  # dK = 2 sigma^2 I (covariance.py:171-175)
+        grad[self.cov_slice] = g_cov
+        return LOO, grad
 
     def marginal_likelihood(self, theta: ndarray) -> float:
         """Log-marginal likelihood, R&W eq. 5.8 without the 2 pi constant (regression.py:528-542)."""

@@ -426,3 +426,29 @@ def test_sweep_single_rank(gp_mod):
     check(vals, want, what="64-point RQ sweep")
     # a checksum of the sweep is invariant under the order in which streams finish
     assert vals.sum() == sharding.marginal_likelihood_sweep(gp, grid).sum()
+
+
+def test_t32_loo_gradient_vs_reference(golden, gp_mod):
+    """loo_likelihood_gradient (regression.py:489-526) and cross_val=True hyper-parameter selection."""
+    g = golden("t32")
+    for name, kid in (("se_", wl.SE), ("rq_", wl.RQ)):
+        th = g[name + "thetas"]
+        gp = gp_mod.GpRegressor(g["x"], g["y"], y_err=g["y_err"], hyperpars=th[0], kernel=kernel_cls(gp_mod, kid))
+        res = [gp.loo_likelihood_gradient(t) for t in th]
+        check([r[0] for r in res], g[name + "loo_g_val"], what="LOO value")
+        for r, ref in zip(res, g[name + "loo_g_grad"]):
+            check(r[1], ref, 1e-9, what="LOO gradient")
+    # finite-difference property of the reference's own test (tests/gp/test_GpRegressor.py:79-94)
+    theta = g["se_thetas"][2]
+    gp = gp_mod.GpRegressor(g["x"], g["y"], y_err=g["y_err"], hyperpars=theta)
+    _, grad = gp.loo_likelihood_gradient(theta)
+    for i in range(theta.size):
+        dx = theta[i] * 1e-5
+        t1, t2 = theta.copy(), theta.copy()
+        t1[i] -= dx
+        t2[i] += dx
+        fd = 0.5 * (gp.loo_likelihood(t2) - gp.loo_likelihood(t1)) / dx
+        assert abs(fd / grad[i] - 1.0) < 1e-5
+    np.random.seed(2)
+    gp_cv = gp_mod.GpRegressor(g["x"], g["y"], y_err=g["y_err"], cross_val=True, n_starts=3)
+    assert gp_cv.loo_likelihood(gp_cv.hyperpars) >= gp_cv.loo_likelihood(theta) - 1e-6
