@@ -41,7 +41,7 @@ int lane_streams(gpmi_ctx* c, Lane& L) {
   if (ncu >= 64 && ncu % 32 == 0) {
     std::vector<uint32_t> panel((size_t)ncu / 32, 0u), upd((size_t)ncu / 32, 0xffffffffu);
     panel[0] = 0xffffffffu;
-    upd[0] = 0u;
+    upd[0] = std::getenv("GPMI_UPD_FULL") ? 0xffffffffu : 0u;  // experiment: let the update stream use every CU
     if (hipExtStreamCreateWithCUMask(&L.stream2, (uint32_t)panel.size(), panel.data()) != hipSuccess ||
         hipExtStreamCreateWithCUMask(&L.stream_upd, (uint32_t)upd.size(), upd.data()) != hipSuccess) {
       if (L.stream2) (void)hipStreamDestroy(L.stream2);
@@ -119,6 +119,20 @@ void free_data(gpmi_ctx* c) {
   fr(c->Q2);
   fr(c->pts);
   fr(c->pvec);
+  fr(c->bA);
+  fr(c->bInv);
+  fr(c->bVec);
+  fr(c->bRed);
+  fr(c->bMu);
+  if (c->bInfo) (void)hipFree(c->bInfo);
+  c->bInfo = nullptr;
+  if (c->bParams) (void)hipFree(c->bParams);
+  c->bParams = nullptr;
+  if (c->h_bRed) (void)hipHostFree(c->h_bRed);
+  c->h_bRed = nullptr;
+  if (c->h_bInfo) (void)hipHostFree(c->h_bInfo);
+  c->h_bInfo = nullptr;
+  c->bcap = 0;
   c->mq_cap = 0;
   c->fitted = false;
   c->n = c->d = c->np = c->ld = 0;
@@ -179,6 +193,46 @@ int ensure_second_matrix(gpmi_ctx* c, Lane& L) {
 void enqueue_inverse_factor(gpmi_ctx* c, Lane& L, const double* Lmat, const double* invD) {
   launch_set_identity(L.stream, L.B2, c->ld, c->np);
   trsm_rows_forward(c, L.stream, Lmat, c->np, c->ld, invD, L.B2, c->np, true);
+}
+
+// workspace for `want` small problems advancing in lockstep (capped by a 6 GiB budget)
+int ensure_batch_ws(gpmi_ctx* c, int want) {
+  const int64_t per = c->np * c->ld * (int64_t)sizeof(double);
+  int cap = (int)((6LL << 30) / per);
+  if (cap > 256) cap = 256;
+  if (cap < 1) cap = 1;
+  if (want > cap) want = cap;
+  if (want <= c->bcap) return GPMI_OK;
+  auto fr = [](double*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  };
+  fr(c->bA);
+  fr(c->bInv);
+  fr(c->bVec);
+  fr(c->bRed);
+  fr(c->bMu);
+  if (c->bInfo) (void)hipFree(c->bInfo);
+  if (c->bParams) (void)hipFree(c->bParams);
+  if (c->h_bRed) (void)hipHostFree(c->h_bRed);
+  if (c->h_bInfo) (void)hipHostFree(c->h_bInfo);
+  c->bInfo = nullptr;
+  c->bParams = nullptr;
+  c->h_bRed = nullptr;
+  c->h_bInfo = nullptr;
+  c->bcap = 0;
+  const int64_t nt = c->np / GPMI_NB;
+  HIPCHK(c, hipMalloc(&c->bA, sizeof(double) * want * c->np * c->ld));
+  HIPCHK(c, hipMalloc(&c->bInv, sizeof(double) * want * nt * GPMI_NB * GPMI_NB));
+  HIPCHK(c, hipMalloc(&c->bVec, sizeof(double) * want * 4 * c->np));
+  HIPCHK(c, hipMalloc(&c->bRed, sizeof(double) * 2 * want));
+  HIPCHK(c, hipMalloc(&c->bMu, sizeof(double) * want * c->np));
+  HIPCHK(c, hipMalloc(&c->bInfo, sizeof(int) * want));
+  HIPCHK(c, hipMalloc(&c->bParams, sizeof(KParams) * want));
+  HIPCHK(c, hipHostMalloc(&c->h_bRed, sizeof(double) * 2 * want));
+  HIPCHK(c, hipHostMalloc(&c->h_bInfo, sizeof(int) * want));
+  c->bcap = want;
+  return GPMI_OK;
 }
 
 int ensure_query_ws(gpmi_ctx* c, int64_t mp) {
@@ -417,6 +471,40 @@ int gpmi_lml_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int
     if (int rc = make_params(c, kernel, thetas + t * n_theta, n_theta, extra ? extra[t] : 0.0,
                              ps[(size_t)t]))
       return rc;
+  if (T >= 2 && c->np <= 4096 && !c->ycov) {
+    // small problems: all evaluations of a chunk advance in lockstep, one launch per step for the
+    // whole chunk (blockIdx.z), instead of one latency-bound launch sequence per evaluation
+    if (int rc = ensure_batch_ws(c, (int)(T < 256 ? T : 256))) return rc;
+    hipStream_t s = c->lanes[1].stream;
+    const BatchShape shape0{1, c->np * c->ld, (c->np / GPMI_NB) * GPMI_NB * GPMI_NB, 4 * c->np};
+    for (int64_t t0 = 0; t0 < T; t0 += c->bcap) {
+      const int B = (int)((T - t0 < c->bcap) ? T - t0 : c->bcap);
+      BatchShape bs = shape0;
+      bs.count = B;
+      HIPCHK(c, hipMemcpyAsync(c->bParams, ps.data() + t0, sizeof(KParams) * B, hipMemcpyHostToDevice, s));
+      if (mus)
+        HIPCHK(c, hipMemcpyAsync(c->bMu, mus + t0 * c->n, sizeof(double) * B * c->n, hipMemcpyHostToDevice, s));
+      else
+        HIPCHK(c, hipMemcpyAsync(c->bMu, mu_const + t0, sizeof(double) * B, hipMemcpyHostToDevice, s));
+      HIPCHK(c, hipMemsetAsync(c->bInfo, 0, sizeof(int) * B, s));
+      launch_kbuild_square_batched(s, c->bParams, B, c->x, c->n, c->np, c->noise, c->bA, c->ld, bs.sMat);
+      potrf_lower_batched(c, s, c->bA, c->np, c->ld, c->bInv, c->bInfo, bs);
+      launch_residual_batched(s, c->y, mus ? c->bMu : nullptr, mus ? nullptr : c->bMu,
+                              c->bVec + 2 * c->np, c->n, c->np, bs);
+      trsv_forward(c, s, c->bA, c->np, c->ld, c->bInv, c->bVec + 2 * c->np, c->bVec, bs);
+      launch_lml_reduce(s, c->bVec, c->bA, c->ld, c->np, c->bRed, bs);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipMemcpyAsync(c->h_bRed, c->bRed, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipMemcpyAsync(c->h_bInfo, c->bInfo, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipStreamSynchronize(s));
+      for (int b = 0; b < B; ++b) {
+        const int inf = c->h_bInfo[b];
+        lml[t0 + b] = (inf == 0) ? (-0.5 * c->h_bRed[2 * b] - c->h_bRed[2 * b + 1]) : -1e50;
+        if (info) info[t0 + b] = inf;
+      }
+    }
+    return GPMI_OK;
+  }
   std::vector<int> slot_of((size_t)T);
   std::vector<int> used((size_t)S, 0);
   for (int64_t t = 0; t < T; ++t) {

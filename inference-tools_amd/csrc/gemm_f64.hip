@@ -36,6 +36,7 @@ struct GemmArgs {
   // durations for the roofline without HIP events in the stream (event records between the look-ahead
   // streams slowed the factorisation 2x)
   unsigned long long* stamp;
+  int64_t sC, sA, sB;  // batch strides (doubles): problem blockIdx.z works on C + z sC, A + z sA, B + z sB
 };
 
 // B stored k-major: 16 rows of BN + 16 pad (rows 16 doubles apart mod 32)
@@ -102,9 +103,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int kbeg = g.kskip ? ti * BM : 0;
-  const double* __restrict__ Ag = g.A + (int64_t)ti * BM * g.lda + kbeg;
-  const double* __restrict__ Bg =
-      BKN ? g.B + (int64_t)kbeg * g.ldb + (int64_t)tj * BN : g.B + (int64_t)tj * BN * g.ldb + kbeg;
+  const int64_t bz = blockIdx.z;
+  const double* __restrict__ Ag = g.A + bz * g.sA + (int64_t)ti * BM * g.lda + kbeg;
+  const double* __restrict__ Bg = BKN ? g.B + bz * g.sB + (int64_t)kbeg * g.ldb + (int64_t)tj * BN
+                                      : g.B + bz * g.sB + (int64_t)tj * BN * g.ldb + kbeg;
 
   // global -> register staging: 4 x 16-byte chunks per operand per thread (8 threads cover a row)
   const int lrow = tid >> 3, lkc = (tid & 7) * 2;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     double* sb = sa + A_DOUBLES;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
-      *reinterpret_cast<d2_t*>(sa + (lrow + 32 * i) * LDS_STRIDE + lkc_sw) = ra[i];
+      *reinterpret_cast<d2_t*>(sa + (lrow + 32 * i) * LDS_STRIDE + lkc_sw) = (OP == OP_SUB) ? -ra[i] : ra[i];
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
       if (BKN)
@@ -141,13 +143,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     }
   };
 
+  const int fr = lane & 15, fk = lane >> 4;
+  double* Cg = g.C + bz * g.sC + ((int64_t)ti * BM + wr * (BM / 2)) * g.ldc + (int64_t)tj * BN + wc * (BN / 2);
+  // OP_SUB: the accumulators start from the C tile and the A operand is negated on its way into LDS,
+  // so C - A B^T comes out of the MFMA chain itself and the epilogue is stores only.  The 64 loads are
+  // issued together with the first operand slab (one memory latency per tile instead of a
+  // load-wait-store epilogue: ~20 k of a workgroup's ~310 k cycles at K = 512).
   d4_t acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < TN; ++j) {
+      if (OP == OP_SUB) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = Cg[(int64_t)(i * 16 + fk + 4 * r) * g.ldc + j * 16 + fr];
+      } else {
+        acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+      }
+    }
 
-  const int fr = lane & 15, fk = lane >> 4;
   const int sw = (fr >= 4 && fr < 12) ? 1 : 0;
   const int a_off = (wr * (BM / 2) + fr) * LDS_STRIDE + ((fk ^ sw) << 2);
   const int b_off = BKN ? 4 * fk * LDS_STRIDE_KN + wc * (BN / 2) + fr
@@ -189,32 +203,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // epilogue: each access covers 4 rows x 128 contiguous bytes.  The 16 loads of one row-tile are
-  // issued together before any store (a load-subtract-store chain per element serialises on memory
-  // latency: 64 round trips per tile, measured 27 % of a workgroup's lifetime at K = 512).
-  double* Cg = g.C + ((int64_t)ti * BM + wr * (BM / 2)) * g.ldc + (int64_t)tj * BN + wc * (BN / 2);
+  // epilogue: stores only; each instruction covers 4 rows x 128 contiguous bytes
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    double* rowp[4];
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rowp[r] = Cg + (int64_t)(i * 16 + fk + 4 * r) * g.ldc + fr;
-    if (OP == OP_SUB) {
-      double cv[TN][4];
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cv[j][r] = rowp[r][j * 16];
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rowp[r][j * 16] = cv[j][r] - acc[i][j][r];
-    } else {
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rowp[r][j * 16] = acc[i][j][r];
-    }
-  }
+      for (int r = 0; r < 4; ++r) Cg[(int64_t)(i * 16 + fk + 4 * r) * g.ldc + j * 16 + fr] = acc[i][j][r];
   if (g.stamp && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);  // stores issued; the stamp marks the end of this workgroup's work
     atomicMax(g.stamp + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
@@ -225,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 
 void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, bool kskip, double* C,
                  int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb, int ntr,
-                 int ntc, int k, unsigned long long* stamp) {
+                 int ntc, int k, unsigned long long* stamp, const GemmBatch& bt) {
   // ntr, ntc are in units of 128 rows / columns
   if (ntr <= 0 || ntc <= 0 || k <= 0) return;
   if (tiles == TILES_LOWER && ntc > ntr) ntc = ntr;
@@ -235,7 +230,7 @@ void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, bool 
   // 64-row tiles for one-tile-column products (in place: a workgroup must own whole rows),
   // 64 x 64 tiles for the remaining short / small launches
   int bm = 128, bn = 128;
-  const bool small = (k <= 128) || (big < 384);
+  const bool small = (k <= 128) || (big * bt.count < 384);
   if (small && !kskip) {
     if (ntc == 1 && tiles == TILES_RECT && op == OP_ASSIGN) {
       bm = 64;
@@ -244,13 +239,14 @@ void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, bool 
       bn = 64;
     }
   }
-  GemmArgs g{C, A, B, ldc, lda, ldb, ntr * (128 / bm), ntc * (128 / bn), k, kskip ? 1 : 0, stamp};
+  GemmArgs g{C, A, B, ldc, lda, ldb, ntr * (128 / bm), ntc * (128 / bn), k, kskip ? 1 : 0, stamp,
+             bt.sC, bt.sA, bt.sB};
   int64_t nwg;
   if (tiles == TILES_RECT)
     nwg = (int64_t)g.ntr * g.ntc;
   else
     nwg = (int64_t)g.ntc * (g.ntc + 1) / 2 + (int64_t)(g.ntr - g.ntc) * g.ntc;
-  dim3 grid((unsigned)nwg), block(256);
+  dim3 grid((unsigned)nwg, 1, (unsigned)bt.count), block(256);
 #define GPMI_LAUNCH(T, O, B, M, N) \
   hipLaunchKernelGGL((gemm_nt_kernel<T, O, B, M, N>), grid, block, 0, s, g)
   if (bm == 128) {
@@ -281,6 +277,6 @@ void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, bool 
 
 void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc,
                     const double* A, int64_t lda, const double* B, int64_t ldb, int ntr, int ntc,
-                    int k, unsigned long long* stamp) {
-  launch_gemm(s, tiles, op, false, false, C, ldc, A, lda, B, ldb, ntr, ntc, k, stamp);
+                    int k, unsigned long long* stamp, const GemmBatch& bt) {
+  launch_gemm(s, tiles, op, false, false, C, ldc, A, lda, B, ldb, ntr, ntc, k, stamp, bt);
 }

@@ -74,6 +74,17 @@ struct gpmi_ctx {
   // host staging (pinned)
   double* h_stage = nullptr;
   int64_t h_stage_bytes = 0;
+  // batched small-problem workspace (gpmi_lml_batch for np <= 4096): `bcap` matrices side by side
+  int bcap = 0;
+  double* bA = nullptr;
+  double* bInv = nullptr;
+  double* bVec = nullptr;
+  double* bRed = nullptr;
+  double* bMu = nullptr;
+  int* bInfo = nullptr;
+  KParams* bParams = nullptr;
+  double* h_bRed = nullptr;
+  int* h_bInfo = nullptr;
   // RCCL result gather (comm.hip)
   void* comm = nullptr;
   int comm_rank = 0, comm_world = 1;
@@ -129,22 +140,40 @@ void launch_scale_columns(hipStream_t s, const double* A, const double* sc, doub
 void launch_loo_vectors(hipStream_t s, const double* alpha, const double* ikdiag, double* c1,
                         double* sc2, int64_t n, int64_t np);
 
+// batch of independent equal-shape problems in one launch (blockIdx.z): strides in doubles
+struct GemmBatch {
+  int count = 1;
+  int64_t sC = 0, sA = 0, sB = 0;
+};
+struct BatchShape {
+  int count = 1;
+  int64_t sMat = 0;   // between the np x ld matrices
+  int64_t sInv = 0;   // between the invD arrays
+  int64_t sVec = 0;   // between the work-vector sets
+};
+
 // gemm_f64.hip  (all dims multiples of 128, k multiple of 16)
 enum GemmTiles { TILES_RECT = 0, TILES_LOWER = 1 };
 enum GemmOp { OP_SUB = 0, OP_ASSIGN = 1 };
 // C(ntr*128 x ntc*128) op= A(rows x k) * B(cols x k)^T ; TILES_LOWER visits tiles ti >= tj only
 void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc,
                     const double* A, int64_t lda, const double* B, int64_t ldb, int ntr, int ntc,
-                    int k, unsigned long long* stamp = nullptr);
+                    int k, unsigned long long* stamp = nullptr, const GemmBatch& bt = GemmBatch());
 
 // general form: b_kmajor -> B is (k x cols) row-major; kskip (TILES_LOWER) -> contraction starts at ti*128
 void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, bool kskip, double* C,
                  int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb, int ntr,
-                 int ntc, int k, unsigned long long* stamp = nullptr);
+                 int ntc, int k, unsigned long long* stamp = nullptr, const GemmBatch& bt = GemmBatch());
 
 // potrf.hip
 void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0,
-                       unsigned long long* dbg = nullptr);
+                       unsigned long long* dbg = nullptr, const BatchShape& bs = BatchShape());
+// batched, in-order factorisation of bs.count matrices (small problems: no look-ahead)
+void potrf_lower_batched(gpmi_ctx* c, hipStream_t s, double* A, int64_t np, int64_t ld, double* invD,
+                         int* info, const BatchShape& bs);
+void launch_kbuild_square_batched(hipStream_t s, const KParams* pdev, int batch, const double* x,
+                                  int64_t n, int64_t np, const double* noise, double* A, int64_t ld,
+                                  int64_t stride);
 // blocked right-looking Cholesky, in place, lower; invD receives the inverses of the diagonal blocks
 void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t ld, double* invD,
                  int* info);
@@ -152,7 +181,7 @@ void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t l
 // solve.hip
 // forward substitution  L v = r : r is consumed as scratch, the solution goes to `out` (no aliasing)
 void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                  const double* invD, double* r, double* out);
+                  const double* invD, double* r, double* out, const BatchShape& bs = BatchShape());
 // backward substitution  L^T a = v : v (in r) is consumed as scratch, the solution goes to `out`
 void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
                    const double* invD, double* r, double* out);
@@ -165,9 +194,12 @@ void launch_copy(hipStream_t s, const double* src, double* dst, int64_t n);
 // r = y - mu (padded with zeros)
 void launch_residual(hipStream_t s, const double* y, const double* mu, double mu_const, double* r,
                      int64_t n, int64_t np);
+// batched: r_z = y - mu_consts[z]  (or mus + z * n when mus != nullptr), r_z at r + z * sVec
+void launch_residual_batched(hipStream_t s, const double* y, const double* mus, const double* mu_consts,
+                             double* r, int64_t n, int64_t np, const BatchShape& bs);
 // red[0] = sum v^2, red[1] = sum log diag(L)
 void launch_lml_reduce(hipStream_t s, const double* v, const double* L, int64_t ld, int64_t np,
-                       double* red);
+                       double* red, const BatchShape& bs = BatchShape());
 // out[m] = sum_n Q[m][n] * a[n]
 void launch_rows_dot(hipStream_t s, const double* Q, int64_t ld, int64_t mp, int64_t np,
                      const double* a, double* out);

@@ -18,11 +18,34 @@ __device__ inline double kfun(const KParams& p, double s) {
 
 // SQUARE: U == V, jitter + noise on the diagonal, identity in the padding (rows/cols >= n).
 template <bool SQUARE>
+__device__ inline void kbuild_body(const KParams& p, const double* __restrict__ U, int64_t nu,
+                                   const double* __restrict__ V, int64_t nv,
+                                   const double* __restrict__ noise, double* __restrict__ out,
+                                   int64_t ld, int lower_only);
+
+template <bool SQUARE>
 __global__ __launch_bounds__(256) void kbuild_kernel(KParams p, const double* __restrict__ U,
                                                      int64_t nu, const double* __restrict__ V,
                                                      int64_t nv, const double* __restrict__ noise,
                                                      double* __restrict__ out, int64_t ld,
                                                      int lower_only) {
+  kbuild_body<SQUARE>(p, U, nu, V, nv, noise, out, ld, lower_only);
+}
+
+// batched square build: problem z uses hyper-parameters pdev[z] and writes matrix out + z * stride
+__global__ __launch_bounds__(256) void kbuild_batched_kernel(const KParams* __restrict__ pdev,
+                                                             const double* __restrict__ x, int64_t n,
+                                                             const double* __restrict__ noise,
+                                                             double* __restrict__ out, int64_t ld,
+                                                             int64_t stride) {
+  kbuild_body<true>(pdev[blockIdx.z], x, n, x, n, noise, out + (int64_t)blockIdx.z * stride, ld, 1);
+}
+
+template <bool SQUARE>
+__device__ inline void kbuild_body(const KParams& p, const double* __restrict__ U, int64_t nu,
+                                   const double* __restrict__ V, int64_t nv,
+                                   const double* __restrict__ noise, double* __restrict__ out,
+                                   int64_t ld, int lower_only) {
   const int ti = blockIdx.y, tj = blockIdx.x;
   if (SQUARE && lower_only && tj > ti) return;
   __shared__ double su[GPMI_MAX_D * KT];
@@ -102,6 +125,13 @@ void launch_kbuild_square(hipStream_t s, const KParams& p, const double* x, int6
   dim3 grid((unsigned)(np / KT), (unsigned)(np / KT));
   hipLaunchKernelGGL(kbuild_kernel<true>, grid, dim3(256), 0, s, p, x, n, x, n, noise, A, ld,
                      lower_only ? 1 : 0);
+}
+
+void launch_kbuild_square_batched(hipStream_t s, const KParams* pdev, int batch, const double* x,
+                                  int64_t n, int64_t np, const double* noise, double* A, int64_t ld,
+                                  int64_t stride) {
+  dim3 grid((unsigned)(np / KT), (unsigned)(np / KT), (unsigned)batch);
+  hipLaunchKernelGGL(kbuild_batched_kernel, grid, dim3(256), 0, s, pdev, x, n, noise, A, ld, stride);
 }
 
 void launch_kbuild_cross(hipStream_t s, const KParams& p, const double* U, int64_t mu, int64_t mp,

@@ -106,7 +106,11 @@ __device__ inline void factor16(double* S, double* Wl, double* __restrict__ invD
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A, int64_t ld,
                                                          double* __restrict__ invD,
                                                          int* __restrict__ info, int col0,
-                                                         unsigned long long* __restrict__ dbg) {
+                                                         unsigned long long* __restrict__ dbg,
+                                                         int64_t strideA, int64_t strideInv) {
+  A += (int64_t)blockIdx.z * strideA;
+  invD += (int64_t)blockIdx.z * strideInv;
+  info += blockIdx.z;
   // dbg != nullptr (tools only): cycle stamps of the phases, accumulated by wave 0
   unsigned long long t_prev = 0, acc_t[6] = {0, 0, 0, 0, 0, 0};
   auto lap = [&](int slot) {
@@ -251,8 +255,9 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
 }  // namespace
 
 void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0,
-                       unsigned long long* dbg) {
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, s, Ablk, ld, invD, info, col0, dbg);
+                       unsigned long long* dbg, const BatchShape& bs) {
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, 1, (unsigned)bs.count), dim3(256), 0, s, Ablk, ld, invD,
+                     info, col0, dbg, bs.sMat, bs.sInv);
 }
 
 namespace {
@@ -360,5 +365,28 @@ void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t l
     (void)hipStreamWaitEvent(sf, lane.ev_join, 0);
     (void)hipEventRecord(lane.ev_panel, sp);
     (void)hipStreamWaitEvent(sf, lane.ev_panel, 0);
+  }
+}
+
+void potrf_lower_batched(gpmi_ctx* c, hipStream_t s, double* A, int64_t np, int64_t ld, double* invD,
+                         int* info, const BatchShape& bs) {
+  // Many small factorisations advance in lockstep: every launch carries all of them in blockIdx.z, so
+  // a step that is latency-bound for one matrix fills the chip across the batch.
+  (void)c;
+  const int nt = (int)(np / NB);
+  const GemmBatch inplace{bs.count, bs.sMat, bs.sMat, bs.sInv};
+  const GemmBatch upd{bs.count, bs.sMat, bs.sMat, bs.sMat};
+  for (int j = 0; j < nt; ++j) {
+    double* Ajj = A + (int64_t)j * NB * ld + (int64_t)j * NB;
+    double* invDj = invD + (int64_t)j * NB * NB;
+    const int below = nt - j - 1;
+    launch_potrf_diag(s, Ajj, ld, invDj, info, j * NB, nullptr, bs);
+    if (below > 0) {
+      double* A21 = Ajj + (int64_t)NB * ld;
+      launch_gemm_nt(s, TILES_RECT, OP_ASSIGN, A21, ld, A21, ld, invDj, NB, below, 1, NB, nullptr, inplace);
+      // right-looking update of the whole trailing matrix with K = 128 (small matrices: the 512-wide
+      // outer panels of the large-N driver would leave too few tiles per launch)
+      launch_gemm_nt(s, TILES_LOWER, OP_SUB, A21 + NB, ld, A21, ld, A21, ld, below, below, NB, nullptr, upd);
+    }
   }
 }

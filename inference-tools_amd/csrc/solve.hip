@@ -29,7 +29,13 @@ __global__ __launch_bounds__(256) void trsv_fwd_step_kernel(const double* __rest
                                                             const double* __restrict__ invD,
                                                             const double* __restrict__ rk,
                                                             double* __restrict__ vout,
-                                                            double* __restrict__ rbelow, int64_t rows) {
+                                                            double* __restrict__ rbelow, int64_t rows,
+                                                            int64_t sMat, int64_t sInv, int64_t sVec) {
+  Lp += (int64_t)blockIdx.z * sMat;
+  invD += (int64_t)blockIdx.z * sInv;
+  rk += (int64_t)blockIdx.z * sVec;
+  vout += (int64_t)blockIdx.z * sVec;
+  rbelow += (int64_t)blockIdx.z * sVec;
   __shared__ double rin[NB];
   __shared__ double v[NB];
   const int tid = threadIdx.x;
@@ -119,6 +125,16 @@ __global__ void copy_kernel(const double* __restrict__ src, double* __restrict__
   if (i < n) dst[i] = src[i];
 }
 
+__global__ void residual_batched_kernel(const double* __restrict__ y, const double* __restrict__ mus,
+                                        const double* __restrict__ mu_consts, double* __restrict__ r,
+                                        int64_t n, int64_t np, int64_t sVec) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  const int64_t z = blockIdx.z;
+  const double m = mus ? mus[z * n + (i < n ? i : 0)] : mu_consts[z];
+  r[z * sVec + i] = (i < n) ? y[i] - m : 0.0;
+}
+
 __global__ void residual_kernel(const double* __restrict__ y, const double* __restrict__ mu,
                                 double mu_const, double* __restrict__ r, int64_t n, int64_t np) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,7 +145,11 @@ __global__ void residual_kernel(const double* __restrict__ y, const double* __re
 // deterministic two-value reduction: red[0] = sum v^2, red[1] = sum ln L_ii  (fixed tree order)
 __global__ __launch_bounds__(1024) void lml_reduce_kernel(const double* __restrict__ v,
                                                           const double* __restrict__ L, int64_t ld,
-                                                          int64_t np, double* __restrict__ red) {
+                                                          int64_t np, double* __restrict__ red,
+                                                          int64_t sMat, int64_t sVec) {
+  v += (int64_t)blockIdx.z * sVec;
+  L += (int64_t)blockIdx.z * sMat;
+  red += 2 * blockIdx.z;
   __shared__ double s0[16], s1[16];
   double a = 0.0, b = 0.0;
   for (int64_t i = threadIdx.x; i < np; i += 1024) {
@@ -196,15 +216,16 @@ __global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restric
 }  // namespace
 
 void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                  const double* invD, double* r, double* out) {
+                  const double* invD, double* r, double* out, const BatchShape& bs) {
   const int nt = (int)(np / NB);
   ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)np * np, 4.0 * np * np);
   for (int k = 0; k < nt; ++k) {
     const int64_t rows = np - (int64_t)(k + 1) * NB;
     const unsigned blocks = rows > 0 ? (unsigned)((rows + 63) / 64) : 1u;
-    hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(blocks), dim3(256), 0, s,
+    hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(blocks, 1, (unsigned)bs.count), dim3(256), 0, s,
                        L + (int64_t)(k + 1) * NB * ld + (int64_t)k * NB, ld, invD + (int64_t)k * NB * NB,
-                       r + (int64_t)k * NB, out + (int64_t)k * NB, r + (int64_t)(k + 1) * NB, rows);
+                       r + (int64_t)k * NB, out + (int64_t)k * NB, r + (int64_t)(k + 1) * NB, rows,
+                       bs.sMat, bs.sInv, bs.sVec);
   }
 }
 
@@ -272,8 +293,15 @@ void launch_residual(hipStream_t s, const double* y, const double* mu, double mu
 }
 
 void launch_lml_reduce(hipStream_t s, const double* v, const double* L, int64_t ld, int64_t np,
-                       double* red) {
-  hipLaunchKernelGGL(lml_reduce_kernel, dim3(1), dim3(1024), 0, s, v, L, ld, np, red);
+                       double* red, const BatchShape& bs) {
+  hipLaunchKernelGGL(lml_reduce_kernel, dim3(1, 1, (unsigned)bs.count), dim3(1024), 0, s, v, L, ld, np, red,
+                     bs.sMat, bs.sVec);
+}
+
+void launch_residual_batched(hipStream_t s, const double* y, const double* mus, const double* mu_consts,
+                             double* r, int64_t n, int64_t np, const BatchShape& bs) {
+  hipLaunchKernelGGL(residual_batched_kernel, dim3((unsigned)((np + 255) / 256), 1, (unsigned)bs.count),
+                     dim3(256), 0, s, y, mus, mu_consts, r, n, np, bs.sVec);
 }
 
 void launch_rows_dot(hipStream_t s, const double* Q, int64_t ld, int64_t mp, int64_t np,

@@ -1,0 +1,58 @@
+"""Timings of the BASELINE.json configurations other than the headline (single GPU), through the public classes.
+usage: python tools/config_bench.py [cfg2] [cfg3] [cfg4] [cfg5]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "inference-tools_amd")]
+import numpy as np
+import workloads as wl
+from inference_amd.gp import GpRegressor, RationalQuadratic, ExpectedImprovement
+
+which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4", "cfg5"]
+
+def t(fn, reps=3):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    return (time.perf_counter() - t0) / reps, out
+
+if "cfg2" in which:
+    x, y, e = wl.synthetic_dataset(2, 8192, 8)
+    th = wl.timing_theta(wl.SE, y, 8)
+    pts = wl.query_points(2, 1024, 8)
+    gp = GpRegressor(x, y, y_err=e, hyperpars=th)
+    dt_fit, _ = t(lambda: gp.set_hyperparameters(th))
+    dt_pred, _ = t(lambda: gp(pts))
+    dt_lml, _ = t(lambda: gp.marginal_likelihood(th))
+    dt_g, _ = t(lambda: gp.marginal_likelihood_gradient(th), reps=2)
+    fl = 8192**3 / 3
+    print(f"cfg2 SE N=8192 d=8: fit {dt_fit*1e3:.1f} ms ({fl/dt_fit/1e12:.1f} TFLOP/s potrf-equivalent) | predict M=1024 {dt_pred*1e3:.1f} ms | "
+          f"LML {dt_lml*1e3:.1f} ms | LML+grad {dt_g*1e3:.1f} ms")
+if "cfg3" in which:
+    x, y, e = wl.synthetic_dataset(3, 16384, 16)
+    grid = wl.theta_grid_cfg3(y, 16)
+    gp = GpRegressor(x, y, y_err=e, hyperpars=grid[0], kernel=RationalQuadratic)
+    gp.engine.set_streams(2)
+    dt, vals = t(lambda: gp.marginal_likelihood_batch(grid[:8]), reps=1)
+    print(f"cfg3 RQ N=16384 d=16: 8 LML evaluations (one GPU's share of the 64-point grid) {dt*1e3:.1f} ms = {dt/8*1e3:.1f} ms each, "
+          f"{8*16384**3/3/dt/1e12:.1f} TFLOP/s; 64-grid on 1 GPU ~ {dt*8:.2f} s")
+if "cfg4" in which:
+    x, y, e = wl.synthetic_dataset(4, 4096, 4)
+    th = wl.timing_theta(wl.SE, y, 4)
+    cand = wl.query_points(4004, 1000, 4)
+    gp = GpRegressor(x, y, y_err=e, hyperpars=th)
+    ei = ExpectedImprovement(); ei.update_gp(gp)
+    dt_v, _ = t(lambda: ei.call_batch(cand))
+    dt_g, _ = t(lambda: ei.opt_func_gradient_batch(cand))
+    print(f"cfg4 SE N=4096 d=4: EI at 1000 candidates {dt_v*1e3:.2f} ms | -ln EI + gradient at 1000 candidates {dt_g*1e3:.2f} ms")
+if "cfg5" in which:
+    x, y, e = wl.synthetic_dataset(5, 2048, 4)
+    th = wl.timing_theta(wl.SE, y, 4)
+    gp = GpRegressor(x, y, y_err=e, hyperpars=th)
+    rng = np.random.default_rng(0)
+    thetas = th + 0.05 * rng.standard_normal((512, th.size))
+    for S in (1, 4, 16, 64):
+        gp.engine.set_streams(S)
+        dt, _ = t(lambda: gp.marginal_likelihood_batch(thetas), reps=2)
+        print(f"cfg5 SE N=2048 d=4: 512 LML evaluations on {S:2d} streams: {dt*1e3:.1f} ms = {512/dt:.0f} evals/s "
+              f"({512*2048**3/3/dt/1e12:.2f} TFLOP/s)")
