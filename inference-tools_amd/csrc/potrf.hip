@@ -302,8 +302,12 @@ void trailing_update(gpmi_ctx* c, hipStream_t s, double* A, int64_t ld, int nt, 
   double* P = A + (int64_t)(Je + c0) * NB * ld + (int64_t)J * NB;
   double* C = A + (int64_t)(Je + c0) * NB * ld + (int64_t)(Je + c0) * NB;
   const double tiles = cols * (cols + 1) / 2.0 + (double)(rows - cols) * cols;
+  // per-launch timing (bench roofline) of the 128 x 128-tile kernel only: launches with fewer than
+  // 384 tiles run the 64 x 64 variant (launch_gemm) and are a different kernel in rocprof's tables
   unsigned long long* stamp =
-      prof_stamp_slot(c, tiles * 2.0 * NB * NB * kw, tiles * 16.0 * NB * NB + 8.0 * rows * NB * kw);
+      tiles >= 384.0 ? prof_stamp_slot(c, tiles * 2.0 * NB * NB * kw,
+                                       tiles * 16.0 * NB * NB + 8.0 * rows * NB * kw)
+                     : nullptr;
   launch_gemm_nt(s, TILES_LOWER, OP_SUB, C, ld, P, ld, P, ld, rows, cols, kw, stamp);
 }
 
