@@ -243,21 +243,30 @@ void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int6
 
 void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
                        const double* invD, double* Q, int64_t mp, bool upper_rhs) {
+  // Two-level right-looking sweep, like the factorisation: inside an outer block of 512 columns the
+  // 128-wide steps only touch the block (K = 128, few tiles, latency bound), then ONE update with
+  // K = 512 carries the block's contribution to all remaining columns (throughput bound, 4x less
+  // traffic on Q than 128-wide updates).
   const int nt = (int)(np / NB), mt_all = (int)(mp / NB);
+  const int OBT = 4;
   ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)mp * np * np, 4.0 * np * np);
-  for (int k = 0; k < nt; ++k) {
-    // upper_rhs: Q is upper triangular (e.g. the identity): rows below block k are still zero in column k
-    const int mt = upper_rhs ? (k + 1 < mt_all ? k + 1 : mt_all) : mt_all;
-    double* Qk = Q + (int64_t)k * NB;
-    // Q[:, k] <- Q[:, k] * invD_k^T   (in place, one tile column)
-    launch_gemm_nt(s, TILES_RECT, OP_ASSIGN, Qk, ld, Qk, ld, invD + (int64_t)k * NB * NB, NB, mt, 1,
-                   NB);
-    const int rem = nt - k - 1;
-    if (rem > 0) {
-      // Q[:, k+1:] -= Q[:, k] * L[k+1:, k]^T
-      launch_gemm_nt(s, TILES_RECT, OP_SUB, Qk + NB, ld, Qk, ld,
-                     L + (int64_t)(k + 1) * NB * ld + (int64_t)k * NB, ld, mt, rem, NB);
+  for (int J = 0; J < nt; J += OBT) {
+    const int Je = (J + OBT < nt) ? J + OBT : nt;
+    // upper_rhs: Q is upper triangular (e.g. the identity): rows below block Je - 1 are still zero here
+    const int mt = upper_rhs ? (Je < mt_all ? Je : mt_all) : mt_all;
+    for (int k = J; k < Je; ++k) {
+      double* Qk = Q + (int64_t)k * NB;
+      // Q[:, k] <- Q[:, k] * invD_k^T   (in place, one tile column)
+      launch_gemm_nt(s, TILES_RECT, OP_ASSIGN, Qk, ld, Qk, ld, invD + (int64_t)k * NB * NB, NB, mt, 1, NB);
+      const int rem = Je - k - 1;
+      if (rem > 0)  // Q[:, k+1:Je] -= Q[:, k] * L[k+1:Je, k]^T
+        launch_gemm_nt(s, TILES_RECT, OP_SUB, Qk + NB, ld, Qk, ld,
+                       L + (int64_t)(k + 1) * NB * ld + (int64_t)k * NB, ld, mt, rem, NB);
     }
+    const int rest = nt - Je;
+    if (rest > 0)  // Q[:, Je:] -= Q[:, J:Je] * L[Je:, J:Je]^T
+      launch_gemm_nt(s, TILES_RECT, OP_SUB, Q + (int64_t)Je * NB, ld, Q + (int64_t)J * NB, ld,
+                     L + (int64_t)Je * NB * ld + (int64_t)J * NB, ld, mt, rest, (Je - J) * NB);
   }
 }
 

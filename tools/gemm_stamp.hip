@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <algorithm>
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef double d4_t __attribute__((ext_vector_type(4)));
 constexpr int BM = 128, BK = 16, LDS_STRIDE = 18, TILE_DOUBLES = BM * LDS_STRIDE;
@@ -19,7 +20,9 @@ __device__ inline unsigned long long stamp() {
 
 template <int STAMP>
 __global__ __launch_bounds__(256, 2) void gemm_diag(const double* A, const double* B, double* C, long lda, long ldc,
-                                                    int k, int ntc, unsigned long long* dbg) {
+                                                    int k, int ntc, unsigned long long* dbg, unsigned long long* wgt) {
+  unsigned long long wg_t0 = 0;
+  if (STAMP && threadIdx.x == 0) wg_t0 = __builtin_amdgcn_s_memrealtime();
   __shared__ double smem[2 * 2 * TILE_DOUBLES];
   const int ti = blockIdx.x / ntc, tj = blockIdx.x % ntc;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
@@ -99,6 +102,13 @@ __global__ __launch_bounds__(256, 2) void gemm_diag(const double* A, const doubl
 #pragma unroll
       for (int r = 0; r < 4; ++r) rowp[r][j * 16] = cv[j][r] - acc[i][j][r];
   }
+  if (STAMP && threadIdx.x == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+    wgt[blockIdx.x * 3] = wg_t0; wgt[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime();
+    wgt[blockIdx.x * 3 + 2] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+  }
   if (STAMP && lane == 0) {
     unsigned long long te = stamp();
     unsigned long long* d = dbg + ((long)blockIdx.x * 4 + wave) * 6;
@@ -111,6 +121,7 @@ int main() {
   double *A, *C; unsigned long long* dbg;
   hipMalloc(&A, sizeof(double) * n * lda); hipMalloc(&C, sizeof(double) * n * ld);
   hipMalloc(&dbg, 8 * 6 * 4 * nt * nt);
+  unsigned long long* wgt; hipMalloc(&wgt, 8 * 3 * nt * nt);
   hipMemset(A, 0, sizeof(double) * n * lda); hipMemset(C, 0, sizeof(double) * n * ld);
   // non-trivial data
   std::vector<double> h((size_t)n * lda); for (size_t i = 0; i < h.size(); ++i) h[i] = 1e-3 * ((i * 2654435761u) % 1000) - 0.5;
@@ -119,8 +130,8 @@ int main() {
   for (int variant = 0; variant < 2; ++variant) {
     for (int rep = 0; rep < 3; ++rep) {
       hipEventRecord(e0);
-      if (variant == 0) hipLaunchKernelGGL(gemm_diag<0>, dim3(nt * nt), dim3(256), 0, 0, A, A, C, lda, ld, k, nt, dbg);
-      else hipLaunchKernelGGL(gemm_diag<1>, dim3(nt * nt), dim3(256), 0, 0, A, A, C, lda, ld, k, nt, dbg);
+      if (variant == 0) hipLaunchKernelGGL(gemm_diag<0>, dim3(nt * nt), dim3(256), 0, 0, A, A, C, lda, ld, k, nt, dbg, wgt);
+      else hipLaunchKernelGGL(gemm_diag<1>, dim3(nt * nt), dim3(256), 0, 0, A, A, C, lda, ld, k, nt, dbg, wgt);
       hipEventRecord(e1); hipDeviceSynchronize();
       float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("variant %d (stamps %s): %.3f ms  %.2f TFLOP/s\n", variant, variant ? "on" : "off", ms, 2.0 * n * n * k / ms / 1e9);
@@ -134,5 +145,23 @@ int main() {
   double ep = 0; for (size_t w = 0; w < nw; ++w) ep += (double)d[w * 6 + 5];
   printf("per k-step per wave (cycles): read %.0f  mfma %.0f  stage %.0f  barrier %.0f ; wave lifetime (loop+epilogue) %.0f, gload-issue per k-step %.0f\n",
          s[0] / nw / nk, s[1] / nw / nk, s[2] / nw / nk, s[3] / nw / nk, s[4] / nw, ep / nw / nk);
+  {
+    std::vector<unsigned long long> w((size_t)3 * nt * nt);
+    hipMemcpy(w.data(), wgt, w.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long tmin = ~0ull, tmax = 0; double dsum = 0, dmin = 1e30, dmax = 0;
+    size_t nwg = (size_t)nt * nt;
+    for (size_t b = 0; b < nwg; ++b) { tmin = std::min(tmin, w[b*3]); tmax = std::max(tmax, w[b*3+1]); double d = (double)(w[b*3+1]-w[b*3]); dsum += d; dmin = std::min(dmin, d); dmax = std::max(dmax, d); }
+    printf("kernel span %.1f us; WG duration avg %.1f us min %.1f max %.1f (10 ns ticks); sum of WG durations / (512 slots * span) = %.3f\n",
+           (tmax - tmin) * 0.01, dsum / nwg * 0.01, dmin * 0.01, dmax * 0.01, dsum / (512.0 * (tmax - tmin)));
+    // finish-time profile: how many WGs end in each 10% bucket of the kernel span; start-time of the first 512
+    int hist[10] = {0}; for (size_t b = 0; b < nwg; ++b) { int q = (int)(10.0 * (w[b*3+1] - tmin) / (double)(tmax - tmin + 1)); hist[q]++; }
+    printf("WG end-time histogram (10 buckets):"); for (int q = 0; q < 10; ++q) printf(" %d", hist[q]); printf("\n");
+    double late = 0; int nl = 0; for (size_t b = 0; b < 512; ++b) { late += (double)(w[b*3] - tmin); ++nl; }
+    printf("mean start delay of the first 512 WGs: %.1f us\n", late / nl * 0.01);
+    // per XCD: last end time
+    unsigned long long xend[8] = {0}; int xcnt[8] = {0};
+    for (size_t b = 0; b < nwg; ++b) { int x = (int)((w[b*3+2] >> 32) & 7); xend[x] = std::max(xend[x], w[b*3+1]); xcnt[x]++; }
+    printf("per-XCD tiles / last end (us):"); for (int x = 0; x < 8; ++x) printf(" %d/%.0f", xcnt[x], (xend[x] - tmin) * 0.01); printf("\n");
+  }
   return 0;
 }
