@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   constexpr int BUF_DOUBLES = A_DOUBLES + B_DOUBLES;
   __shared__ double smem[2 * BUF_DOUBLES];  // [buffer][A | B]
   int ti, tj;
-  tile_of<TILES>(xcd_remap(blockIdx.x, gridDim.x), g.ntr, g.ntc, ti, tj);
+  // k-skipped launches have tiles of very different length (128 (ntr - ti) k-steps): deal them out
+  // round-robin over the XCDs instead of in contiguous chunks, or the XCD holding the long tiles ends last
+  tile_of<TILES>(g.kskip ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x), g.ntr, g.ntc, ti, tj);
 
   const int tid = threadIdx.x;
   if (g.stamp && tid == 0) atomicMin(g.stamp, (unsigned long long)__builtin_amdgcn_s_memrealtime());
