@@ -452,3 +452,37 @@ def test_t32_loo_gradient_vs_reference(golden, gp_mod):
     np.random.seed(2)
     gp_cv = gp_mod.GpRegressor(g["x"], g["y"], y_err=g["y_err"], cross_val=True, n_starts=3)
     assert gp_cv.loo_likelihood(gp_cv.hyperpars) >= gp_cv.loo_likelihood(theta) - 1e-6
+
+
+def test_batched_lockstep_equals_single_evaluations(gp_mod):
+    """gpmi_lml_batch's lockstep path (blockIdx.z batch, N <= 4096) against one-at-a-time evaluations:
+    different kernels / tile shapes, same numbers to 1e-12; ragged batch sizes."""
+    x, y, e = wl.synthetic_dataset(12, 300, 3)
+    thetas = wl.theta_set(wl.RQ, y, 3, 37)
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=thetas[0], kernel=gp_mod.RationalQuadratic)
+    single = np.array([gp.marginal_likelihood(t) for t in thetas])
+    for b in (37, 5, 2):
+        check(gp.marginal_likelihood_batch(thetas[:b]), single[:b], 1e-12, f"batch of {b}")
+    # a failing member does not disturb its neighbours
+    bad = thetas.copy()
+    bad[3, 1] = 800.0  # amplitude overflow -> non-finite pivot
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vals = gp.marginal_likelihood_batch(bad[:6])
+    assert vals[3] == -1e50
+    check(np.delete(vals, 3), np.delete(single[:6], 3), 1e-12)
+
+
+def test_rccl_gather_single_rank(gp_mod):
+    """gpmi_comm_* with world = 1 (the only RCCL configuration a 1-GPU box offers): unique id,
+    communicator, all-gather through the library's own stream."""
+    from inference_amd import sharding
+
+    x, y, e = wl.synthetic_dataset(13, 64, 2)
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=wl.timing_theta(wl.SE, y, 2))
+    eng = gp.engine
+    eng.comm_init(0, 1, eng.comm_unique_id())
+    out = eng.comm_allgather(np.array([1.5, -2.0, 3.25]))
+    assert out.shape == (1, 3) and np.array_equal(out[0], [1.5, -2.0, 3.25])
+    vals = sharding.sharded_map(lambda th: gp.marginal_likelihood_batch(th), wl.theta_set(wl.SE, y, 2, 5), engine=eng)
+    assert vals.shape == (5, 1)
