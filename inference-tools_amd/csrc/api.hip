@@ -168,7 +168,7 @@ int set_device(gpmi_ctx* c) {
 // Leaves: lane.A = L, lane.invD, vec[0:np] = v = L^-1 (y - mu), red[2*slot..] = {v.v, sum ln L_ii},
 // info[slot].  `mu_dev` may be null (then mu_const is used).
 int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const double* mu_dev,
-                               double mu_const, int slot) {
+                               double mu_const, int slot, bool allow_lookahead = true) {
   hipStream_t s = L.stream;
   HIPCHK(c, hipMemsetAsync(L.info + slot, 0, sizeof(int), s));
   {
@@ -176,7 +176,7 @@ int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const dou
     launch_kbuild_square(s, p, c->x, c->n, c->np, c->noise, L.A, c->ld, true);
   }
   if (c->ycov) launch_add_full(s, L.A, c->ld, c->ycov, c->n);
-  potrf_lower(c, L, L.A, c->np, c->ld, L.invD, L.info + slot);
+  potrf_lower(c, L, L.A, c->np, c->ld, L.invD, L.info + slot, allow_lookahead);
   launch_residual(s, c->y, mu_dev, mu_const, L.vec + 2 * c->np, c->n, c->np);
   trsv_forward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, L.vec);
   launch_lml_reduce(s, L.vec, L.A, c->ld, c->np, L.red + 2 * slot);
@@ -519,7 +519,7 @@ int gpmi_lml_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int
                                hipMemcpyHostToDevice, L.stream));
     }
     if (int rc = enqueue_factor_and_forward(c, L, ps[(size_t)t], mu_dev,
-                                            mu_const ? mu_const[t] : 0.0, slot))
+                                            mu_const ? mu_const[t] : 0.0, slot, S == 1 || T == 1))
       return rc;
   }
   for (int li = 0; li < S; ++li) {

@@ -175,8 +175,10 @@ void launch_kbuild_square_batched(hipStream_t s, const KParams* pdev, int batch,
                                   int64_t n, int64_t np, const double* noise, double* A, int64_t ld,
                                   int64_t stride);
 // blocked right-looking Cholesky, in place, lower; invD receives the inverses of the diagonal blocks
+// allow_lookahead = false keeps everything on the lane's full-chip stream (several lanes running
+// concurrently already fill the chip, and their masked stream pairs would only fight for HW queues)
 void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t ld, double* invD,
-                 int* info);
+                 int* info, bool allow_lookahead = true);
 
 // solve.hip
 // forward substitution  L v = r : r is consumed as scratch, the solution goes to `out` (no aliasing)

@@ -324,7 +324,7 @@ void trailing_update(gpmi_ctx* c, hipStream_t s, double* A, int64_t ld, int nt, 
 }  // namespace
 
 void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t ld, double* invD,
-                 int* info) {
+                 int* info, bool allow_lookahead) {
   // Two regimes (GPMI_LOOKAHEAD_MIN=<tile rows> moves the switch, 0 disables the look-ahead).
   // While the trailing matrix is large, look-ahead over two CU-masked streams: the
   // panel stream (32 CUs, 4 per XCD) factors outer panel J+1 while the update stream (the other 224
@@ -345,7 +345,7 @@ void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t l
   for (int J = 0; J < nt; J += OBT) {
     const int Je = (J + OBT < nt) ? J + OBT : nt;
     const int rem = nt - Je;
-    const bool want = (sp != nullptr) && (rem >= LOOKAHEAD_MIN);
+    const bool want = allow_lookahead && (sp != nullptr) && (rem >= LOOKAHEAD_MIN);
     if (want && !overlapped) {
       // enter the look-ahead regime: both masked streams start after everything queued so far
       (void)hipEventRecord(lane.ev_join, sf);
