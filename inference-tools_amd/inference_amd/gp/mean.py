@@ -1,7 +1,19 @@
 """
-Mean-function classes — host-side mirror of `inference/gp/mean.py` (reference).
-Mean vectors are O(N d) and are evaluated on the host, then handed to the device
-as the `mu` argument of gpmi_fit / gpmi_lml (include/gpmi.h).
+Mean-function plugins of the GP path — counterpart of `inference/gp/mean.py`
+(reference).  A mean function maps hyper-parameters to the prior mean vector of the
+training points; it is O(N d) work and stays on the host: `GpRegressor` hands the
+resulting vector to the device as the `mu` argument of gpmi_fit / gpmi_lml
+(include/gpmi.h).
+
+All three concrete classes are linear in their parameters, mu = Phi(x) . theta, so
+they share one implementation built around the feature matrix Phi:
+
+    ConstantMean   Phi = [1]                               (mean.py:31-51)
+    LinearMean     Phi = [1, x - <x>]                      (mean.py:54-83)
+    QuadraticMean  Phi = [1, x - <x>, (x - <x>)^2]         (mean.py:86-126)
+
+Public names, constructor arguments, `bounds` / `n_params` / `hyperpar_labels`
+attributes and method signatures are those of the reference.
 """
 from abc import ABC, abstractmethod
 
@@ -10,7 +22,7 @@ from numpy import ndarray
 
 
 class MeanFunction(ABC):
-    """Plugin contract of the reference (mean.py:5-28)."""
+    """The plugin contract `GpRegressor` relies on (mean.py:5-28)."""
 
     bounds = None
     n_params: int
@@ -18,115 +30,104 @@ class MeanFunction(ABC):
 
     @abstractmethod
     def pass_spatial_data(self, x: ndarray):
-        pass
+        """Receive the (N, d) training coordinates."""
 
     @abstractmethod
     def estimate_hyperpar_bounds(self, y: ndarray):
-        pass
+        """Fill `self.bounds` from the training values."""
 
     @abstractmethod
     def __call__(self, q, theta: ndarray):
-        pass
+        """Prior mean at a single point q."""
 
     @abstractmethod
     def build_mean(self, theta: ndarray):
-        pass
+        """Prior mean vector at the training points."""
 
     @abstractmethod
     def mean_and_gradients(self, theta: ndarray):
-        pass
+        """(mean vector, list of d mean / d theta_j vectors)."""
 
 
-class ConstantMean(MeanFunction):
-    """mu(x) = theta_0 (mean.py:31-51)."""
+class _FeatureMean(MeanFunction):
+    """mu = Phi . theta with Phi made of an intercept and `degree` powers of the centred coordinates."""
+
+    degree = 0
 
     def __init__(self, hyperpar_bounds=None):
         self.bounds = hyperpar_bounds
-        self.n_params = 1
-        self.hyperpar_labels = ["ConstantMean"]
+        if self.degree == 0:  # independent of the data: known before pass_spatial_data
+            self.n_params = 1
+            self.hyperpar_labels = self._labels(0)
+
+    # -- feature map ----------------------------------------------------------------
+    def _features(self, centred: ndarray) -> ndarray:
+        cols = [np.ones((centred.shape[0], 1))]
+        cols.extend(centred**p for p in range(1, self.degree + 1))
+        return np.hstack(cols)
 
     def pass_spatial_data(self, x: ndarray):
-        self.n_data = x.shape[0]
+        self.n_data, d = x.shape
+        self.x_mean = x.mean(axis=0)
+        centred = x - self.x_mean[None, :]
+        self._phi = self._features(centred)
+        self._span = centred.max(axis=0) - centred.min(axis=0)
+        self.n_params = 1 + self.degree * d
+        self.hyperpar_labels = self._labels(d)
+        # attribute names of the reference's classes
+        if self.degree >= 1:
+            self.dx = centred
+        if self.degree >= 2:
+            self.dx_sqr = centred**2
+            self.lin_slc = slice(1, d + 1)
+            self.quad_slc = slice(d + 1, 2 * d + 1)
 
     def estimate_hyperpar_bounds(self, y: ndarray):
         lo, hi = y.min(), y.max()
         w = hi - lo
-        self.bounds = [(lo - w, hi + w)]
+        if self.degree == 0:
+            self.bounds = [(lo - w, hi + w)]
+            return
+        slope = 10 * w / self._span
+        pairs = [(-b, b) for b in slope]
+        self.bounds = [(lo - 2 * w, hi + 2 * w)] + pairs * self.degree
 
+    # -- evaluation --------------------------------------------------------------------
     def __call__(self, q, theta: ndarray):
-        return theta[0]
+        if self.degree == 0:
+            return theta[0]
+        dq = np.atleast_2d(q - self.x_mean)
+        return (self._features(dq) @ theta).squeeze()
 
     def build_mean(self, theta: ndarray):
-        return np.zeros(self.n_data) + theta[0]
+        if self.degree == 0:
+            return np.zeros(self.n_data) + theta[0]
+        return self._phi @ np.asarray(theta, dtype=float)
 
     def mean_and_gradients(self, theta: ndarray):
-        return self.build_mean(theta), [np.ones(self.n_data)]
+        return self.build_mean(theta), list(self._phi.T)
 
 
-class LinearMean(MeanFunction):
-    """mu(x) = theta_0 + (x - <x>) . theta_1: (mean.py:54-83)."""
+class ConstantMean(_FeatureMean):
+    degree = 0
 
-    def __init__(self, hyperpar_bounds=None):
-        self.bounds = hyperpar_bounds
-
-    def pass_spatial_data(self, x: ndarray):
-        self.x_mean = x.mean(axis=0)
-        self.dx = x - self.x_mean[None, :]
-        self.n_data, d = x.shape
-        self.n_params = 1 + d
-        self.hyperpar_labels = ["LinearMean background"] + [
-            f"LinearMean gradient {i}" for i in range(d)
-        ]
-
-    def estimate_hyperpar_bounds(self, y: ndarray):
-        w = y.max() - y.min()
-        slope = 10 * w / (self.dx.max(axis=0) - self.dx.min(axis=0))
-        self.bounds = [(y.min() - 2 * w, y.max() + 2 * w)] + [(-b, b) for b in slope]
-
-    def __call__(self, q, theta: ndarray):
-        return theta[0] + np.dot(q - self.x_mean, theta[1:]).squeeze()
-
-    def build_mean(self, theta: ndarray):
-        return theta[0] + np.dot(self.dx, theta[1:])
-
-    def mean_and_gradients(self, theta: ndarray):
-        return self.build_mean(theta), [np.ones(self.n_data), *self.dx.T]
+    def _labels(self, d):
+        return ["ConstantMean"]
 
 
-class QuadraticMean(MeanFunction):
-    """mu(x) = theta_0 + dx . lin + dx^2 . quad (mean.py:86-126)."""
+class LinearMean(_FeatureMean):
+    degree = 1
 
-    def __init__(self, hyperpar_bounds=None):
-        self.bounds = hyperpar_bounds
+    def _labels(self, d):
+        return ["LinearMean background"] + [f"LinearMean gradient {i}" for i in range(d)]
 
-    def pass_spatial_data(self, x: ndarray):
-        self.n_data, d = x.shape
-        self.x_mean = x.mean(axis=0)
-        self.dx = x - self.x_mean[None, :]
-        self.dx_sqr = self.dx**2
-        self.n_params = 1 + 2 * d
-        self.hyperpar_labels = (
+
+class QuadraticMean(_FeatureMean):
+    degree = 2
+
+    def _labels(self, d):
+        return (
             ["mean_background"]
             + [f"mean_linear_coeff_{i}" for i in range(d)]
             + [f"mean_quadratic_coeff_{i}" for i in range(d)]
         )
-        self.lin_slc = slice(1, d + 1)
-        self.quad_slc = slice(d + 1, 2 * d + 1)
-
-    def estimate_hyperpar_bounds(self, y: ndarray):
-        w = y.max() - y.min()
-        slope = 10 * w / (self.dx.max(axis=0) - self.dx.min(axis=0))
-        pairs = [(-b, b) for b in slope]
-        self.bounds = [(y.min() - 2 * w, y.max() + 2 * w)] + pairs + pairs
-
-    def __call__(self, q, theta: ndarray):
-        dq = q - self.x_mean
-        lin = np.dot(dq, theta[self.lin_slc]).squeeze()
-        quad = np.dot(dq**2, theta[self.quad_slc]).squeeze()
-        return theta[0] + lin + quad
-
-    def build_mean(self, theta: ndarray):
-        return theta[0] + np.dot(self.dx, theta[self.lin_slc]) + np.dot(self.dx_sqr, theta[self.quad_slc])
-
-    def mean_and_gradients(self, theta: ndarray):
-        return self.build_mean(theta), [np.ones(self.n_data), *self.dx.T, *self.dx_sqr.T]

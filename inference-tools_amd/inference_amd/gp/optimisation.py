@@ -5,17 +5,28 @@ device-backed `GpRegressor`, proposes the next evaluation by maximising an
 acquisition function (multi-start L-BFGS-B or differential evolution on the host,
 every objective evaluation on the device) and re-fits when an evaluation is added.
 `plot_results` (matplotlib) is out of scope.
+
+Same constructor arguments, public attributes (`x, y, y_err, bounds, gp, acquisition,
+acquisition_max_history, convergence_metric_history, iteration_history`) and methods as the
+reference; the regressor is (re)built in one place, `_fit_gp`, so every re-fit goes through the
+same device path: one K-build + blocked Cholesky per hyper-parameter evaluation.
 """
 from collections.abc import Sequence
 from inspect import isclass
 
-from numpy import append, array, ndarray
+import numpy as np
+from numpy import ndarray
 from scipy.optimize import differential_evolution, fmin_l_bfgs_b
 
+from inference_amd.gp import _messages as msg
 from inference_amd.gp.acquisition import AcquisitionFunction, ExpectedImprovement
 from inference_amd.gp.covariance import CovarianceFunction, SquaredExponential
 from inference_amd.gp.mean import ConstantMean, MeanFunction
 from inference_amd.gp.regression import GpRegressor
+
+
+def _optional_array(value):
+    return None if value is None else np.asarray(value)
 
 
 class GpOptimiser:
@@ -43,37 +54,38 @@ class GpOptimiser:
         optimizer: str = "bfgs",
         n_processes: int = 1,
     ):
-        self.x = x if isinstance(x, ndarray) else array(x)
-        if self.x.ndim == 1:
-            self.x = self.x.reshape([self.x.size, 1])
-        self.y = y if isinstance(y, ndarray) else array(y)
-        self.y_err = y_err if isinstance(y_err, (ndarray, type(None))) else array(y_err)
-
+        coords = np.asarray(x)
+        self.x = coords.reshape([coords.size, 1]) if coords.ndim == 1 else coords
+        self.y = np.asarray(y)
+        self.y_err = _optional_array(y_err)
         self.bounds = bounds
-        self.kernel = kernel
-        self.mean = mean
-        self.cross_val = cross_val
-        self.n_processes = n_processes
-        self.optimizer = optimizer
 
-        self.gp = GpRegressor(
-            x=x,
-            y=y,
-            y_err=y_err,
-            hyperpars=hyperpars,
-            kernel=kernel,
-            mean=mean,
-            cross_val=cross_val,
-            optimizer=self.optimizer,
-            n_processes=self.n_processes,
-        )
+        # everything a re-fit needs (optimisation.py:117-127, 178-188)
+        self.kernel, self.mean = kernel, mean
+        self.cross_val = cross_val
+        self.optimizer = optimizer
+        self.n_processes = n_processes
 
         self.acquisition = acquisition() if isclass(acquisition) else acquisition
-        self.acquisition.update_gp(self.gp)
-
         self.acquisition_max_history = []
         self.convergence_metric_history = []
         self.iteration_history = []
+        self._fit_gp(hyperpars)
+
+    def _fit_gp(self, hyperpars=None):
+        """(Re)build the regressor on the current evaluations and point the acquisition at it."""
+        self.gp = GpRegressor(
+            self.x,
+            self.y,
+            y_err=self.y_err,
+            hyperpars=hyperpars,
+            kernel=self.kernel,
+            mean=self.mean,
+            cross_val=self.cross_val,
+            optimizer=self.optimizer,
+            n_processes=self.n_processes,
+        )
+        self.acquisition.update_gp(self.gp)
 
     def __call__(self, x):
         return self.gp(x)
@@ -81,52 +93,29 @@ class GpOptimiser:
     def add_evaluation(self, new_x: ndarray, new_y: ndarray, new_y_err: ndarray = None):
         """Append an evaluation and re-fit from scratch, hyper-parameter search included
         (optimisation.py:136-190)."""
-        new_x = new_x if isinstance(new_x, ndarray) else array(new_x)
-        if new_x.shape != (1, self.x.shape[1]):
-            new_x = new_x.reshape((1, self.x.shape[1]))
-        new_y = new_y if isinstance(new_y, ndarray) else array(new_y)
-        good_type = isinstance(new_y_err, (ndarray, type(None)))
-        new_y_err = new_y_err if good_type else array(new_y_err)
+        point = np.asarray(new_x).reshape((1, self.x.shape[1]))
+        value = np.asarray(new_y)
+        error = _optional_array(new_y_err)
 
-        self.acquisition_max_history.append(self.acquisition(new_x))
-        self.convergence_metric_history.append(self.acquisition.convergence_metric(new_x))
+        # the record of how promising this point looked under the *previous* model
+        self.acquisition_max_history.append(self.acquisition(point))
+        self.convergence_metric_history.append(self.acquisition.convergence_metric(point))
         self.iteration_history.append(self.y.size + 1)
 
-        self.x = append(self.x, new_x, axis=0)
-        self.y = append(self.y, new_y)
-
+        self.x = np.append(self.x, point, axis=0)
+        self.y = np.append(self.y, value)
         if self.y_err is not None:
-            if new_y_err is not None:
-                self.y_err = append(self.y_err, new_y_err)
-            else:
-                raise ValueError(
-                    """\n
-                    \r[ GpOptimiser error ]
-                    \r>> 'new_y_err' argument of the 'add_evaluation' method must be
-                    \r>> specified if the 'y_err' argument was specified when the
-                    \r>> instance of GpOptimiser was initialised.
-                    """
-                )
+            if error is None:
+                raise ValueError(msg.NEW_Y_ERR_REQUIRED)
+            self.y_err = np.append(self.y_err, error)
 
-        self.gp = GpRegressor(
-            x=self.x,
-            y=self.y,
-            y_err=self.y_err,
-            kernel=self.kernel,
-            mean=self.mean,
-            cross_val=self.cross_val,
-            optimizer=self.optimizer,
-            n_processes=self.n_processes,
-        )
+        self._fit_gp()
         self.mu_max = self.y.max()
-        self.acquisition.update_gp(self.gp)
 
+    # -- acquisition maximisers (optimisation.py:192-223) ------------------------------------
     def diff_evo(self):
-        opt_result = differential_evolution(self.acquisition.opt_func, self.bounds, popsize=30)
-        funcval = opt_result.fun
-        if hasattr(funcval, "__len__"):
-            funcval = funcval[0]
-        return opt_result.x, funcval
+        found = differential_evolution(self.acquisition.opt_func, self.bounds, popsize=30)
+        return found.x, float(np.ravel(found.fun)[0])
 
     def launch_bfgs(self, x0: ndarray):
         return fmin_l_bfgs_b(
@@ -134,19 +123,15 @@ class GpOptimiser:
         )
 
     def multistart_bfgs(self):
-        starting_positions = self.acquisition.starting_positions(self.bounds)
-        results = [self.launch_bfgs(x0) for x0 in starting_positions]
-        best = sorted(results, key=lambda r: float(r[1]))[0]
-        return best[0], float(best[1])
+        runs = [self.launch_bfgs(x0) for x0 in self.acquisition.starting_positions(self.bounds)]
+        where, lowest, _ = min(runs, key=lambda run: float(run[1]))
+        return where, float(lowest)
 
     def propose_evaluation(self, optimizer=None):
         """Location of the next evaluation: the maximiser of the acquisition function
         (optimisation.py:225-249)."""
-        opt = optimizer if optimizer is not None else self.optimizer
-        if opt == "bfgs":
-            proposed_ev, max_acq = self.multistart_bfgs()
-        else:
-            proposed_ev, max_acq = self.diff_evo()
-        if hasattr(proposed_ev, "__len__") and len(proposed_ev) == 1:
-            proposed_ev = proposed_ev[0]
-        return proposed_ev
+        method = self.optimizer if optimizer is None else optimizer
+        proposal, _ = self.multistart_bfgs() if method == "bfgs" else self.diff_evo()
+        if np.ndim(proposal) > 0 and len(proposal) == 1:
+            return proposal[0]
+        return proposal

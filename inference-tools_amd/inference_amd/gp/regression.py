@@ -24,6 +24,7 @@ from numpy.random import random
 from scipy.optimize import differential_evolution, fmin_l_bfgs_b
 
 from inference_amd._engine import GpEngine
+from inference_amd.gp import _messages as msg
 from inference_amd.gp.covariance import CovarianceFunction, SquaredExponential, device_plan
 from inference_amd.gp.mean import ConstantMean, MeanFunction
 
@@ -66,42 +67,9 @@ class GpRegressor:
         n_starts: int = None,
         device: int = None,
     ):
-        self.x = x if isinstance(x, ndarray) else array(x)
-        self.y = y if isinstance(y, ndarray) else array(y)
-        self.y = self.y.squeeze()
-
-        if self.y.ndim != 1:
-            raise ValueError(
-                f"""\n
-                \r[ GpRegressor error ]
-                \r>> 'y' argument must be a 1D array, but instead has shape {self.y.shape}
-                """
-            )
-
+        self.x, self.y = self._coerce_training_data(x, y)
         self.n_points = self.y.size
-        if self.x.ndim == 2:
-            self.n_dimensions = self.x.shape[1]
-        elif self.x.ndim <= 1:
-            self.n_dimensions = 1
-            self.x = self.x.reshape([self.x.size, self.n_dimensions])
-        else:
-            raise ValueError(
-                f"""\n
-                \r[ GpRegressor Error ]
-                \r>> 'x' argument must be a 2D array, but instead has
-                \r>> {self.x.ndim} dimensions and shape {self.x.shape}.
-                """
-            )
-
-        if self.x.shape[0] != self.n_points:
-            raise ValueError(
-                f"""\n
-                \r[ GpRegressor Error ]
-                \r>> The first dimension of the 'x' array must be equal in size
-                \r>> to the 'y' array.
-                \r>> 'x' has shape {self.x.shape}, but 'y' has size {self.y.size}.
-                """
-            )
+        self.n_dimensions = self.x.shape[1]
 
         # data-error covariance: kept as a variance vector or the dense matrix the user gave
         self._noise_var, self._y_cov = self.check_error_data(y_err, y_cov)
@@ -124,13 +92,7 @@ class GpRegressor:
 
         plan = device_plan(self.cov)
         if plan is None:
-            raise NotImplementedError(
-                f"""\n
-                \r[ GpRegressor error ]
-                \r>> The covariance function {type(self.cov)} has no MI355X device kernel.
-                \r>> Supported: SquaredExponential, RationalQuadratic, each optionally + WhiteNoise().
-                """
-            )
+            raise NotImplementedError(msg.no_device_kernel(type(self.cov)))
         self._kernel_id, self._stat, self._stat_slice, self._wn_index = plan
         self._device = device
         self._engine = None
@@ -147,19 +109,29 @@ class GpRegressor:
         if hyperpars is None:
             if optimizer not in ["bfgs", "diffev"]:
                 optimizer = "bfgs"
-                warn(
-                    """
-                    An invalid option was passed to the 'optimizer' keyword argument.
-                    The default option 'bfgs' was used instead.
-                    Valid options are 'bfgs' and 'diffev'.
-                    """
-                )
+                warn(msg.BAD_OPTIMIZER)
             if optimizer == "diffev":
                 hyperpars = self.differential_evo()
             else:
                 hyperpars = self.multistart_bfgs(n_processes=n_processes, starts=n_starts)
 
         self.set_hyperparameters(hyperpars)
+
+    @staticmethod
+    def _coerce_training_data(x, y):
+        """Array conversion and shape checks of the constructor (regression.py:94-130): y must be
+        one-dimensional, x (N, d) or — for d = 1 — anything that flattens to N values."""
+        xa = np.asarray(x)
+        ya = np.asarray(y).squeeze()
+        if ya.ndim != 1:
+            raise ValueError(msg.y_not_1d(ya.shape))
+        if xa.ndim > 2:
+            raise ValueError(msg.x_not_2d(xa.ndim, xa.shape))
+        if xa.ndim < 2:
+            xa = xa.reshape([xa.size, 1])
+        if xa.shape[0] != ya.size:
+            raise ValueError(msg.xy_mismatch(xa.shape, ya.size))
+        return xa, ya
 
     # ---------------------------------------------------------------------------------
     # device plumbing
@@ -224,14 +196,7 @@ class GpRegressor:
     def set_hyperparameters(self, hyperpars: ndarray):
         """Update the hyper-parameters and re-fit (regression.py:218-244)."""
         if len(hyperpars) != self.n_hyperpars:
-            raise ValueError(
-                f"""\n
-                [ GpRegressor error ]
-                >> An incorrect number of hyper-parameter values were passed via the
-                >> 'hyperpars' keyword argument:
-                >> There are {self.n_hyperpars} hyper-parameters but {len(hyperpars)} values were given.
-                """
-            )
+            raise ValueError(msg.wrong_hyperpar_count(self.n_hyperpars, len(hyperpars)))
         self.hyperpars = hyperpars
         self.mean_hyperpars = self.hyperpars[self.mean_slice]
         self.cov_hyperpars = self.hyperpars[self.cov_slice]
@@ -246,94 +211,48 @@ class GpRegressor:
         self._logdet = logdet
 
     def check_error_data(self, y_err, y_cov):
-        """Validation of regression.py:246-322; returns (variance vector | None, dense matrix | None)."""
-        if y_cov is not None:
-            if type(y_cov) in (list, tuple):
-                y_cov = array(y_cov).squeeze()
-            elif type(y_cov) is not ndarray:
-                raise TypeError(
-                    f"""\n
-                    [ GpRegressor error ]
-                    >> The 'y_cov' keyword argument should be given as a numpy array:
-                    >> Expected type {ndarray} but type {type(y_cov)} was given.
-                    """
-                )
-            if y_cov.shape != (self.n_points, self.n_points):
-                raise ValueError(
-                    """\n
-                    [ GpRegressor error ]
-                    >> The 'y_cov' keyword argument was passed an array with an incorrect
-                    >> shape. 'y_cov' must be a 2D array of shape (N,N), where 'N' is the
-                    >> number of given y-data values.
-                    """
-                )
-            if not (y_cov == y_cov.T).all():
-                raise ValueError(
-                    """\n
-                    [ GpRegressor error ]
-                    >> The covariance matrix passed to the 'y_cov' keyword argument
-                    >> is not symmetric.
-                    """
-                )
-            if y_err is not None:
-                warn(
-                    """\n
-                    [ GpRegressor warning ]
-                    >> Only one of the 'y_err' and 'y_cov' keyword arguments should
-                    >> be specified. Only the input to 'y_cov' will be used - the
-                    >> input to 'y_err' will be ignored.
-                    """
-                )
-            return None, np.ascontiguousarray(y_cov, dtype=float)
+        """Validate the data-error arguments (regression.py:246-322).  Returns
+        (variance vector | None, dense covariance matrix | None) — the dense N x N `sig` of the
+        reference is only materialised on request (the `sig` property)."""
 
+        def as_array(value, keyword):
+            if isinstance(value, (list, tuple)):
+                return array(value).squeeze()
+            if type(value) is not ndarray:
+                raise TypeError(msg.not_an_array(keyword, ndarray, type(value)))
+            return value
+
+        n = self.n_points
+        if y_cov is not None:
+            y_cov = as_array(y_cov, "y_cov")
+            if y_cov.shape != (n, n):
+                raise ValueError(msg.Y_COV_SHAPE)
+            if not (y_cov == y_cov.T).all():
+                raise ValueError(msg.Y_COV_ASYMMETRIC)
+            if y_err is not None:
+                warn(msg.Y_ERR_AND_Y_COV)
+            return None, np.ascontiguousarray(y_cov, dtype=float)
         if y_err is not None:
-            if type(y_err) in (list, tuple):
-                y_err = array(y_err).squeeze()
-            elif type(y_err) is not ndarray:
-                raise TypeError(
-                    f"""\n
-                    [ GpRegressor error ]
-                    >> The 'y_err' keyword argument should be given as a numpy array:
-                    >> Expected type {ndarray} but type {type(y_err)} was given.
-                    """
-                )
-            if y_err.shape != (self.n_points,):
-                raise ValueError(
-                    """\n
-                    [ GpRegressor error ]
-                    >> The 'y_err' keyword argument was passed an array with an
-                    >> incorrect shape. 'y_err' must be a 1D array of length 'N',
-                    >> where 'N' is the number of given y-data values.
-                    """
-                )
+            y_err = as_array(y_err, "y_err")
+            if y_err.shape != (n,):
+                raise ValueError(msg.Y_ERR_SHAPE)
             return np.asarray(y_err, dtype=float) ** 2, None
         return None, None
 
     def process_points(self, points: ndarray) -> ndarray:
-        """Shape handling of regression.py:324-349."""
-        x = points if isinstance(points, ndarray) else array(points)
-        if x.ndim <= 1 and self.n_dimensions == 1:
-            x = x.reshape([x.size, 1])
-        elif x.ndim == 1 and x.size == self.n_dimensions:
-            x = x.reshape([1, x.size])
-        elif x.ndim > 2:
-            raise ValueError(
-                f"""\n
-                [ GpRegressor error ]
-                >> 'points' argument must be a 2D array, but given array
-                >> has {x.ndim} dimensions and shape {x.shape}.
-                """
-            )
-        if x.shape[1] != self.n_dimensions:
-            raise ValueError(
-                f"""\n
-                [ GpRegressor error ]
-                >> The second dimension of the 'points' array must have size
-                >> equal to the number of dimensions of the input data.
-                >> The input data have {self.n_dimensions} dimensions but 'points' has shape {x.shape}.
-                """
-            )
-        return x
+        """Bring query points to shape (M, d) (regression.py:324-349)."""
+        q = np.asarray(points)
+        d = self.n_dimensions
+        if q.ndim > 2:
+            raise ValueError(msg.points_not_2d(q.ndim, q.shape))
+        if q.ndim <= 1:
+            if d == 1:
+                q = q.reshape([q.size, 1])  # a vector (or scalar) of 1-D positions
+            elif q.ndim == 1 and q.size == d:
+                q = q.reshape([1, d])       # one d-dimensional position
+        if q.shape[1] != d:
+            raise ValueError(msg.points_wrong_width(d, q.shape))
+        return q
 
     def _require_gradient_terms(self):
         if self._kernel_id != 0:
