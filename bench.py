@@ -172,7 +172,7 @@ def main():
     if rank == 0:
         ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
         line = {
-            "metric": "GpRegressor fit+predict GFLOP/s at N=16384, d=8 (fp64)",
+            "metric": "GpRegressor fit+predict wall-time and GFLOP/s at N=16384, d=8; % fp64 MFMA peak",
             "value": value,
             "unit": "GFLOP/s",
             "n_gpus": world,

@@ -44,6 +44,7 @@ extern "C" {
 #define GPMI_ERR_HIP (-2)     /* HIP runtime error */
 #define GPMI_ERR_NOMEM (-3)   /* device allocation failed */
 #define GPMI_ERR_NODEVICE (-4)/* no usable gfx950 device */
+#define GPMI_ERR_INTERNAL (-5) /* internal consistency check failed (a bug: please report) */
 
 typedef struct gpmi_ctx gpmi_ctx;
 

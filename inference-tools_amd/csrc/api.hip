@@ -29,6 +29,15 @@ thread_local std::string g_create_err;
     }                          \
   } while (0)
 
+// a negative `info` is written by the single-launch triangular sweeps when their polling timed out
+#define INFOCHK(ctx, inf)                                                              \
+  do {                                                                                 \
+    if ((inf) < 0) {                                                                   \
+      (ctx)->err = "internal error: a triangular sweep timed out waiting for a block"; \
+      return GPMI_ERR_INTERNAL;                                                        \
+    }                                                                                  \
+  } while (0)
+
 constexpr int RED_SLOTS = 8192;  // per-lane result slots for batched evaluations
 
 int lane_streams(gpmi_ctx* c, Lane& L) {
@@ -178,7 +187,7 @@ int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const dou
   if (c->ycov) launch_add_full(s, L.A, c->ld, c->ycov, c->n);
   potrf_lower(c, L, L.A, c->np, c->ld, L.invD, L.info + slot, allow_lookahead);
   launch_residual(s, c->y, mu_dev, mu_const, L.vec + 2 * c->np, c->n, c->np);
-  trsv_forward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, L.vec);
+  trsv_forward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, L.vec, L.info + slot);
   launch_lml_reduce(s, L.vec, L.A, c->ld, c->np, L.red + 2 * slot);
   HIPCHK(c, hipGetLastError());
   return GPMI_OK;
@@ -425,7 +434,7 @@ int gpmi_fit(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double e
   const auto h1 = std::chrono::steady_clock::now();
   // alpha = L^-T v
   launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
-  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, c->alpha);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, c->alpha, L.info);
   HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
   if (alpha_out)
@@ -439,6 +448,7 @@ int gpmi_fit(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double e
                  ms(h0, h1), ms(h1, h2), ms(h2, h3));
   }
   if (logdet_out) *logdet_out = L.h_red[1];
+  INFOCHK(c, L.h_info[0]);
   if (info) *info = L.h_info[0];
   c->fit_params = p;
   c->fitted = (L.h_info[0] == 0);
@@ -491,7 +501,7 @@ int gpmi_lml_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int
       potrf_lower_batched(c, s, c->bA, c->np, c->ld, c->bInv, c->bInfo, bs);
       launch_residual_batched(s, c->y, mus ? c->bMu : nullptr, mus ? nullptr : c->bMu,
                               c->bVec + 2 * c->np, c->n, c->np, bs);
-      trsv_forward(c, s, c->bA, c->np, c->ld, c->bInv, c->bVec + 2 * c->np, c->bVec, bs);
+      trsv_forward(c, s, c->bA, c->np, c->ld, c->bInv, c->bVec + 2 * c->np, c->bVec, c->bInfo, bs);
       launch_lml_reduce(s, c->bVec, c->bA, c->ld, c->np, c->bRed, bs);
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipMemcpyAsync(c->h_bRed, c->bRed, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, s));
@@ -499,6 +509,7 @@ int gpmi_lml_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int
       HIPCHK(c, hipStreamSynchronize(s));
       for (int b = 0; b < B; ++b) {
         const int inf = c->h_bInfo[b];
+        INFOCHK(c, inf);
         lml[t0 + b] = (inf == 0) ? (-0.5 * c->h_bRed[2 * b] - c->h_bRed[2 * b + 1]) : -1e50;
         if (info) info[t0 + b] = inf;
       }
@@ -536,6 +547,7 @@ int gpmi_lml_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int
     Lane& L = c->lanes[1 + (int)(t % S)];
     const int slot = slot_of[(size_t)t];
     const int inf = L.h_info[slot];
+    INFOCHK(c, inf);
     // -1/2 v.v - sum ln L_ii (regression.py:539); sentinel on failure (regression.py:540-542)
     lml[t] = (inf == 0) ? (-0.5 * L.h_red[2 * slot] - L.h_red[2 * slot + 1]) : -1e50;
     if (info) info[t] = inf;
@@ -569,7 +581,7 @@ int gpmi_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
   if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
   launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
-  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev, L.info);
   // K^-1 = L^-T L^-1 (regression.py:556-557), lower tiles, overwriting L
   enqueue_inverse_factor(c, L, L.A, L.invD);
   launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, true, L.A, c->ld, L.B2, c->ld, L.B2, c->ld,
@@ -586,6 +598,7 @@ int gpmi_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
   *lml = -0.5 * L.h_red[0] - L.h_red[1];
   for (int j = 0; j < n_theta; ++j) grad_theta[j] = L.h_red[16 + j];
   if (trace_q) *trace_q = L.h_red[16 + n_theta];
+  INFOCHK(c, L.h_info[0]);
   if (info) *info = L.h_info[0];
   return GPMI_OK;
 }
@@ -762,7 +775,7 @@ int gpmi_loo_terms(gpmi_ctx* c, int kernel, const double* theta, int n_theta, do
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
   if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
   launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
-  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev, L.info);
   enqueue_inverse_factor(c, L, L.A, L.invD);
   launch_rows_sumsq(s, L.B2, c->ld, c->np, c->np, 0.0, diag_dev);
   HIPCHK(c, hipGetLastError());
@@ -771,6 +784,7 @@ int gpmi_loo_terms(gpmi_ctx* c, int kernel, const double* theta, int n_theta, do
   HIPCHK(c, hipMemcpyAsync(ikdiag, diag_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   for (int64_t i = 0; i < c->n; ++i) ikdiag[i] = -ikdiag[i];
+  INFOCHK(c, L.h_info[0]);
   if (info) *info = L.h_info[0];
   return GPMI_OK;
 }
@@ -807,7 +821,7 @@ int gpmi_loo_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
   if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
   launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
-  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev, L.info);
   // K^-1 (full, both triangles) in A
   enqueue_inverse_factor(c, L, L.A, L.invD);
   launch_rows_sumsq(s, L.B2, c->ld, c->np, c->np, 0.0, diag_dev);  // = -diag(K^-1)
@@ -835,6 +849,7 @@ int gpmi_loo_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
   // the contraction returns 1/2 sum Q o dK; the LOO gradient has no 1/2 (regression.py:513)
   for (int j = 0; j < n_theta; ++j) grad_theta[j] = 2.0 * L.h_red[16 + j];
   if (trace_q) *trace_q = L.h_red[16 + n_theta];
+  INFOCHK(c, L.h_info[0]);
   if (info) *info = L.h_info[0];
   return GPMI_OK;
 }

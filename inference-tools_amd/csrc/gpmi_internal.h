@@ -181,12 +181,14 @@ void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t l
                  int* info, bool allow_lookahead = true);
 
 // solve.hip
-// forward substitution  L v = r : r is consumed as scratch, the solution goes to `out` (no aliasing)
+// forward substitution  L v = r : the solution goes to `out` (no aliasing; `r` may be used as scratch).
+// `err` (device int, may be null) receives GPMI_ERR_INTERNAL if the sweep's polling ever times out.
 void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                  const double* invD, double* r, double* out, const BatchShape& bs = BatchShape());
-// backward substitution  L^T a = v : v (in r) is consumed as scratch, the solution goes to `out`
+                  const double* invD, double* r, double* out, int* err = nullptr,
+                  const BatchShape& bs = BatchShape());
+// backward substitution  L^T a = v : the solution goes to `out` (no aliasing; `r` may be used as scratch)
 void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                   const double* invD, double* r, double* out);
+                   const double* invD, double* r, double* out, int* err = nullptr);
 // Q (mp x np, row-major, ld) <- Q L^-T   (forward solve of mp right-hand sides stored as rows)
 void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
                        const double* invD, double* Q, int64_t mp, bool upper_rhs = false);

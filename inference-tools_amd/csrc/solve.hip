@@ -5,6 +5,8 @@
 // produced by potrf_diag, so every step is a matrix-vector / matrix-matrix product:
 //   single right-hand side  -> HBM-bound GEMV sweeps (L is read exactly once per solve)
 //   many right-hand sides    -> the fp64 MFMA GEMM (right-hand sides stored as rows, "NT" form)
+#include <cstdlib>
+
 #include "gpmi_internal.h"
 
 namespace {
@@ -113,6 +115,212 @@ __global__ __launch_bounds__(256) void trsv_bwd_step_kernel(const double* __rest
   if (tid < 64 && j < cols) r[j] -= red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
 }
 
+// ---- single-launch sweeps (dataflow over the 128-blocks) ----------------------------------------
+// The per-block launches above are bound by the kernel boundary (~10 us per step, 2.6 ms for the two
+// sweeps of a fit at N = 16384, although L is only 1 GB).  Here ONE launch does a whole sweep:
+// workgroup k owns block row k (forward) / block column k (backward), accumulates the contributions
+// of the blocks whose solution is already published, and publishes its own 128 values.  The output
+// vector doubles as the flag array: it is pre-filled with a NaN payload no computation produces and a
+// consumer polls the elements it needs (agent-scope loads, which bypass the per-XCD L2; the
+// producer's agent-scope stores write through), so one memory round trip per step is all that is
+// left on the critical path.  Workgroup k only ever waits for workgroups with a lower index, which
+// the dispatcher starts first: no deadlock whatever the number of resident workgroups.  The
+// summation order is fixed, so results are bit-reproducible.
+constexpr unsigned long long FLOW_SENTINEL = 0xFFF8DEADBEEF0000ull;
+constexpr int FLOW_THREADS = 512;
+constexpr int FLOW_SPIN_LIMIT = 1 << 24;  // > 1 s of polling: a bug, not a wait; bail out instead of hanging the GPU
+
+__device__ inline double flow_poll(const double* p, int* err) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  unsigned long long bits = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int spins = 0;
+  while (bits == FLOW_SENTINEL) {
+    __builtin_amdgcn_s_sleep(1);
+    bits = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (++spins > FLOW_SPIN_LIMIT) {
+      if (err) atomicCAS(err, 0, GPMI_ERR_INTERNAL);
+      return 0.0;
+    }
+  }
+  return __longlong_as_double((long long)bits);
+}
+
+__device__ inline void flow_publish(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void flow_fill_kernel(double* __restrict__ v, int64_t np, int64_t sVec) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < np)
+    reinterpret_cast<unsigned long long*>(v + (int64_t)blockIdx.z * sVec)[i] = FLOW_SENTINEL;
+}
+
+// forward  L v = r.  Workgroup k: u = r_k - sum_{j<k} L_kj v_j ;  v_k = invD_k u.
+// Wave w streams rows 16 w .. 16 w + 15 of the block row, lane l columns 2 l, 2 l + 1 of every block (1 KiB
+// coalesced per row, requested before the block's v_j is polled: L is static); the partial sums stay in
+// the lane across blocks and are folded once through LDS.  invD_k is preloaded four threads per row, so
+// after v_{k-1} arrives 32 + 32 FMAs per thread, the fold, two barriers and the store remain.
+__global__ __launch_bounds__(FLOW_THREADS) void trsv_fwd_flow_kernel(
+    const double* __restrict__ L, int64_t ld, const double* __restrict__ invD,
+    const double* __restrict__ r, double* __restrict__ v, int* __restrict__ err, int64_t sMat,
+    int64_t sInv, int64_t sVec) {
+  const int k = blockIdx.x;
+  L += (int64_t)blockIdx.z * sMat;
+  invD += (int64_t)blockIdx.z * sInv + (int64_t)k * NB * NB;
+  r += (int64_t)blockIdx.z * sVec;
+  v += (int64_t)blockIdx.z * sVec;
+  if (err) err += blockIdx.z;
+  __shared__ double part[NB][65];
+  __shared__ double u[NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row4 = tid >> 2, q4 = tid & 3;  // four threads per row, 32 columns each
+  // invD_k, requested first (static data: no dependence on the sweep), four threads per row
+  double xi[32];
+  {
+    const double* p = invD + row4 * NB + q4 * 32;
+#pragma unroll
+    for (int c = 0; c < 32; c += 2) {
+      const d2_t a = *reinterpret_cast<const d2_t*>(p + c);
+      xi[c] = a[0];
+      xi[c + 1] = a[1];
+    }
+  }
+  const double rk = r[(int64_t)k * NB + row4];
+  double acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+  const int nmain = k;  // blocks 0 .. k - 1; only the last one is on the critical path
+  if (nmain > 0) {
+    // two 8-row buffers per lane, alternating: half A (rows 0..7 of the wave) of block j is consumed while
+    // half B is in flight, then half A of block j + 1 is requested before half B is consumed
+    const double* base = L + (int64_t)(k * NB + wave * 16) * ld + 2 * lane;
+    d2_t ha[8], hb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ha[i] = *reinterpret_cast<const d2_t*>(base + (int64_t)i * ld);
+    for (int j = 0; j < nmain; ++j) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        hb[i] = *reinterpret_cast<const d2_t*>(base + (int64_t)(8 + i) * ld + (int64_t)j * NB);
+      const double v0 = flow_poll(v + (int64_t)j * NB + 2 * lane, err);
+      const double v1 = flow_poll(v + (int64_t)j * NB + 2 * lane + 1, err);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = fma(ha[i][0], v0, fma(ha[i][1], v1, acc[i]));
+      if (j + 1 < nmain) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          ha[i] = *reinterpret_cast<const d2_t*>(base + (int64_t)i * ld + (int64_t)(j + 1) * NB);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[8 + i] = fma(hb[i][0], v0, fma(hb[i][1], v1, acc[8 + i]));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) part[wave * 16 + i][lane] = acc[i];
+  __syncthreads();
+  {
+    // fold the 64 lane partials of every row: 4 threads per row, 16 each, fixed order
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s += part[row4][q4 * 16 + c];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (q4 == 0) u[row4] = rk - s;
+  }
+  __syncthreads();
+  {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) s = fma(xi[c], u[q4 * 32 + c], s);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (q4 == 0) flow_publish(v + (int64_t)k * NB + row4, s);
+  }
+}
+
+// backward  L^T a = w.  Workgroup b owns block column k = nt - 1 - b:
+// u = w_k - sum_{j>k} L_jk^T a_j ;  a_k = invD_k^T u.  Wave w takes rows i = w, w + 8, .. of every block,
+// lane l the columns 2 l, 2 l + 1 (1 KiB coalesced per row); the partial sums of a lane's two columns
+// persist across blocks and the eight waves are folded once through LDS.
+__global__ __launch_bounds__(FLOW_THREADS) void trsv_bwd_flow_kernel(
+    const double* __restrict__ L, int64_t ld, const double* __restrict__ invD,
+    const double* __restrict__ w, double* __restrict__ a, int* __restrict__ err, int nt) {
+  const int k = nt - 1 - (int)blockIdx.x;
+  invD += (int64_t)k * NB * NB;
+  __shared__ double part[8][NB];
+  __shared__ double u[NB];
+  __shared__ double ain[2][NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = tid & 127, rg = tid >> 7;  // last step: thread = (column, group of 32 rows)
+  double xi[32];
+  {
+    const double* p = invD + (rg * 32) * NB + col;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) xi[i] = p[i * NB];
+  }
+  const double wk = w[(int64_t)k * NB + col];
+  d2_t acc = d2_t{0.0, 0.0};
+  const int nmain = nt - k - 1;  // blocks j = nt - 1 .. k + 1; only the last one is on the critical path
+  if (nmain > 0) {
+    // rows wave + 8 i of a block: i = 0..7 in buffer ha, i = 8..15 in hb (alternating as in the forward sweep)
+    const double* base = L + (int64_t)wave * ld + (int64_t)k * NB + 2 * lane;
+    d2_t ha[8], hb[8];
+    {
+      const double* pj = base + (int64_t)(nt - 1) * NB * ld;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ha[i] = *reinterpret_cast<const d2_t*>(pj + (int64_t)(8 * i) * ld);
+    }
+    for (int t = 0; t < nmain; ++t) {
+      const int j = nt - 1 - t;
+      {
+        const double* pj = base + (int64_t)j * NB * ld;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hb[i] = *reinterpret_cast<const d2_t*>(pj + (int64_t)(64 + 8 * i) * ld);
+      }
+      // a_j into LDS (double-buffered: a slow wave may still read the previous block's values)
+      double* aj = ain[t & 1];
+      if (tid < NB) aj[tid] = flow_poll(a + (int64_t)j * NB + tid, err);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const double x = aj[wave + 8 * i];
+        acc[0] = fma(ha[i][0], x, acc[0]);
+        acc[1] = fma(ha[i][1], x, acc[1]);
+      }
+      if (t + 1 < nmain) {
+        const double* pj = base + (int64_t)(j - 1) * NB * ld;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ha[i] = *reinterpret_cast<const d2_t*>(pj + (int64_t)(8 * i) * ld);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const double x = aj[wave + 64 + 8 * i];
+        acc[0] = fma(hb[i][0], x, acc[0]);
+        acc[1] = fma(hb[i][1], x, acc[1]);
+      }
+    }
+  }
+  part[wave][2 * lane] = acc[0];
+  part[wave][2 * lane + 1] = acc[1];
+  __syncthreads();
+  if (tid < NB) {
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += part[g][tid];
+    u[tid] = wk - s;
+  }
+  __syncthreads();
+  {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s = fma(xi[i], u[rg * 32 + i], s);
+    part[4 + rg][col] = s;
+    __syncthreads();
+    if (tid < NB)
+      flow_publish(a + (int64_t)k * NB + tid, (part[4][tid] + part[5][tid]) + (part[6][tid] + part[7][tid]));
+  }
+}
+
 __global__ void set_identity_kernel(double* __restrict__ Q, int64_t ld, int64_t np) {
   const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
   const int64_t i = blockIdx.y;
@@ -215,10 +423,26 @@ __global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restric
 
 }  // namespace
 
+// GPMI_TRSV_STEPS=1 selects the per-block launches (A/B measurements)
+static bool trsv_use_steps() {
+  static const bool v = [] {
+    const char* e = std::getenv("GPMI_TRSV_STEPS");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
+
 void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                  const double* invD, double* r, double* out, const BatchShape& bs) {
+                  const double* invD, double* r, double* out, int* err, const BatchShape& bs) {
   const int nt = (int)(np / NB);
   ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)np * np, 4.0 * np * np);
+  if (!trsv_use_steps()) {
+    hipLaunchKernelGGL(flow_fill_kernel, dim3((unsigned)((np + 255) / 256), 1, (unsigned)bs.count), dim3(256), 0,
+                       s, out, np, bs.sVec);
+    hipLaunchKernelGGL(trsv_fwd_flow_kernel, dim3((unsigned)nt, 1, (unsigned)bs.count), dim3(FLOW_THREADS), 0,
+                       s, L, ld, invD, r, out, err, bs.sMat, bs.sInv, bs.sVec);
+    return;
+  }
   for (int k = 0; k < nt; ++k) {
     const int64_t rows = np - (int64_t)(k + 1) * NB;
     const unsigned blocks = rows > 0 ? (unsigned)((rows + 63) / 64) : 1u;
@@ -230,9 +454,16 @@ void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64
 }
 
 void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                   const double* invD, double* r, double* out) {
+                   const double* invD, double* r, double* out, int* err) {
   const int nt = (int)(np / NB);
   ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)np * np, 4.0 * np * np);
+  if (!trsv_use_steps()) {
+    hipLaunchKernelGGL(flow_fill_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, out, np,
+                       (int64_t)0);
+    hipLaunchKernelGGL(trsv_bwd_flow_kernel, dim3((unsigned)nt), dim3(FLOW_THREADS), 0, s, L, ld, invD, r,
+                       out, err, nt);
+    return;
+  }
   for (int k = nt - 1; k >= 0; --k) {
     const int64_t cols = (int64_t)k * NB;
     const unsigned blocks = cols > 0 ? (unsigned)((cols + 63) / 64) : 1u;
