@@ -88,6 +88,8 @@ void lane_free(Lane& L) {
   if (L.stream_upd) (void)hipStreamDestroy(L.stream_upd);
   if (L.A) (void)hipFree(L.A);
   if (L.B2) (void)hipFree(L.B2);
+  if (L.inv2) (void)hipFree(L.inv2);
+  if (L.inv2_t) (void)hipFree(L.inv2_t);
   if (L.gws) (void)hipFree(L.gws);
   if (L.invD) (void)hipFree(L.invD);
   if (L.vec) (void)hipFree(L.vec);
@@ -179,6 +181,7 @@ int set_device(gpmi_ctx* c) {
 int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const double* mu_dev,
                                double mu_const, int slot, bool allow_lookahead = true) {
   hipStream_t s = L.stream;
+  L.inv2_valid = false;
   HIPCHK(c, hipMemsetAsync(L.info + slot, 0, sizeof(int), s));
   {
     ProfScope ps(c, s, GPMI_PROF_KBUILD, 0.0, 4.0 * c->np * c->np);
@@ -198,10 +201,36 @@ int ensure_second_matrix(gpmi_ctx* c, Lane& L) {
   return GPMI_OK;
 }
 
-// B2 <- L^-T (row j = column j of L^-1), by forward substitution on the identity
-void enqueue_inverse_factor(gpmi_ctx* c, Lane& L, const double* Lmat, const double* invD) {
+// inverses of the 512-wide diagonal blocks of the factor held by lane F, built on stream s (which must
+// be ordered after the factorisation); cached until the lane is factorised again
+int ensure_inv2(gpmi_ctx* c, Lane& F, hipStream_t s) {
+  if (F.inv2_valid) return GPMI_OK;
+  const int64_t nob = (c->np / GPMI_NB + 3) / 4;
+  if (!F.inv2) HIPCHK(c, hipMalloc(&F.inv2, sizeof(double) * nob * GPMI_OB * GPMI_OB));
+  if (!F.inv2_t) HIPCHK(c, hipMalloc(&F.inv2_t, sizeof(double) * nob * 256 * 256));
+  build_inv2(s, F.A, c->np, c->ld, F.invD, F.inv2, F.inv2_t);
+  HIPCHK(c, hipGetLastError());
+  F.inv2_valid = true;
+  return GPMI_OK;
+}
+
+int ensure_trsm_panel(gpmi_ctx* c, int64_t rows) {
+  if (rows <= c->trsm_panel_rows) return GPMI_OK;
+  if (c->trsm_panel) (void)hipFree(c->trsm_panel);
+  c->trsm_panel = nullptr;
+  c->trsm_panel_rows = 0;
+  HIPCHK(c, hipMalloc(&c->trsm_panel, sizeof(double) * rows * (GPMI_OB + 32)));
+  c->trsm_panel_rows = rows;
+  return GPMI_OK;
+}
+
+// L.B2 <- F^-T (row j = column j of the inverse of lane F's factor), by forward substitution on the identity
+int enqueue_inverse_factor(gpmi_ctx* c, Lane& L, Lane& F) {
+  if (int rc = ensure_inv2(c, F, L.stream)) return rc;
+  if (int rc = ensure_trsm_panel(c, c->np)) return rc;
   launch_set_identity(L.stream, L.B2, c->ld, c->np);
-  trsm_rows_forward(c, L.stream, Lmat, c->np, c->ld, invD, L.B2, c->np, true);
+  trsm_rows_forward(c, L.stream, F.A, c->np, c->ld, F.inv2, L.B2, c->np, true, nullptr, c->trsm_panel);
+  return GPMI_OK;
 }
 
 // workspace for `want` small problems advancing in lockstep (capped by a 6 GiB budget)
@@ -356,6 +385,7 @@ int gpmi_destroy(gpmi_ctx* c) {
     (void)hipEventDestroy(sl.e1);
   }
   if (c->stamp_pool) (void)hipFree(c->stamp_pool);
+  if (c->trsm_panel) (void)hipFree(c->trsm_panel);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->t0) (void)hipEventDestroy(c->t0);
   if (c->t1) (void)hipEventDestroy(c->t1);
@@ -583,7 +613,7 @@ int gpmi_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
   launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
   trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev, L.info);
   // K^-1 = L^-T L^-1 (regression.py:556-557), lower tiles, overwriting L
-  enqueue_inverse_factor(c, L, L.A, L.invD);
+  if (int rc = enqueue_inverse_factor(c, L, L)) return rc;
   launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, true, L.A, c->ld, L.B2, c->ld, L.B2, c->ld,
               (int)(c->np / GPMI_NB), (int)(c->np / GPMI_NB), (int)c->np);
   launch_lml_grad(s, p, n_theta, c->x, c->n, c->np, L.A, c->ld, alpha_dev, alpha_dev, L.gws, gout);
@@ -626,8 +656,9 @@ int gpmi_predict(gpmi_ctx* c, const double* pts, int64_t m, double* mu_out, doub
     double* var_dev = c->pvec + mp;
     if (mu_out) launch_rows_dot(s, c->Q, c->ld, mp, c->np, c->alpha, mu_dev);
     if (var_out) {
-      trsm_rows_forward(c, s, L.A, c->np, c->ld, L.invD, c->Q, mp);
-      launch_rows_sumsq(s, c->Q, c->ld, mp, c->np, p.a2, var_dev);  // K_qq[0,0] = a^2 (regression.py:210)
+      if (int rc = ensure_inv2(c, L, s)) return rc;
+      trsm_rows_forward(c, s, L.A, c->np, c->ld, L.inv2, c->Q, mp, false, c->Q2, nullptr);
+      launch_rows_sumsq(s, c->Q2, c->ld, mp, c->np, p.a2, var_dev);  // K_qq[0,0] = a^2 (regression.py:210)
     }
     HIPCHK(c, hipGetLastError());
     if (mu_out)
@@ -658,10 +689,14 @@ int gpmi_posterior(gpmi_ctx* c, const double* pts, int64_t m, double* mu_out, do
     double* Kqq = nullptr;
     const int64_t ldq = mp + 32;
     HIPCHK(c, hipMalloc(&Kqq, sizeof(double) * mp * ldq));
-    trsm_rows_forward(c, s, L.A, c->np, c->ld, L.invD, c->Q, mp);
+    if (int rc = ensure_inv2(c, L, s)) {
+      (void)hipFree(Kqq);
+      return rc;
+    }
+    trsm_rows_forward(c, s, L.A, c->np, c->ld, L.inv2, c->Q, mp, false, c->Q2, nullptr);
     launch_kbuild_cross(s, p, c->pts, m, mp, c->pts, m, mp, Kqq, ldq);  // no jitter (regression.py:441)
-    // Sigma = K_qq - Q^T Q with Q = L^-1 K_qx^T, i.e. rows of c->Q dotted pairwise
-    launch_gemm_nt(s, TILES_RECT, OP_SUB, Kqq, ldq, c->Q, c->ld, c->Q, c->ld, (int)(mp / GPMI_NB),
+    // Sigma = K_qq - Q^T Q with Q = L^-1 K_qx^T, i.e. rows of c->Q2 dotted pairwise
+    launch_gemm_nt(s, TILES_RECT, OP_SUB, Kqq, ldq, c->Q2, c->ld, c->Q2, c->ld, (int)(mp / GPMI_NB),
                    (int)(mp / GPMI_NB), (int)c->np);
     hipError_t e = hipMemcpy2DAsync(cov_out, sizeof(double) * m, Kqq, sizeof(double) * ldq,
                                     sizeof(double) * m, m, hipMemcpyDeviceToHost, s);
@@ -692,7 +727,9 @@ int gpmi_spatial_derivatives(gpmi_ctx* c, const double* pts, int64_t m, double* 
     launch_kbuild_cross(s, p, c->pts, mc, mp, c->x, c->n, c->np, c->Q, c->ld);
     launch_copy(s, c->Q, c->Q2, mp * c->ld);
     // Z = K^-1 k per row: forward then backward solve (regression.py:410)
-    trsm_rows_forward(c, s, L.A, c->np, c->ld, L.invD, c->Q2, mp);
+    if (int rc = ensure_inv2(c, L, s)) return rc;
+    if (int rc = ensure_trsm_panel(c, mp)) return rc;
+    trsm_rows_forward(c, s, L.A, c->np, c->ld, L.inv2, c->Q2, mp, false, nullptr, c->trsm_panel);
     trsm_rows_backward(c, s, L.A, c->np, c->ld, L.invD, c->Q2, mp);
     double* dmu_dev = c->pvec;
     double* dvar_dev = c->pvec + mp * d;
@@ -728,8 +765,9 @@ int gpmi_gradient(gpmi_ctx* c, const double* pts, int64_t m, double* gmu_out, do
     double* gcov_dev = c->pvec + rp;
     launch_sd_reduce(s, p, c->x, c->n, c->pts, mc, c->Q, c->ld, c->alpha, 0, 1.0, gmu_dev);
     launch_grad_rhs(s, p, c->x, c->n, c->np, c->pts, mc * d, rp, c->Q, c->ld, c->Q2);
-    trsm_rows_forward(c, s, L.A, c->np, c->ld, L.invD, c->Q2, rp);
-    launch_grad_cov(s, p, c->Q2, c->ld, c->np, mc, gcov_dev);
+    if (int rc = ensure_inv2(c, L, s)) return rc;
+    trsm_rows_forward(c, s, L.A, c->np, c->ld, L.inv2, c->Q2, rp, false, c->Q, nullptr);  // c->Q is free again
+    launch_grad_cov(s, p, c->Q, c->ld, c->np, mc, gcov_dev);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(gmu_out + m0 * d, gmu_dev, sizeof(double) * mc * d, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(gcov_out + m0 * d * d, gcov_dev, sizeof(double) * mc * d * d,
@@ -749,7 +787,7 @@ int gpmi_loo_diag(gpmi_ctx* c, double* ikdiag) {
   if (int rc = ensure_second_matrix(c, L)) return rc;
   HIPCHK(c, hipStreamSynchronize(F.stream));
   // diag(K^-1)_a = sum_i (L^-1)_ia^2 = squared norm of row a of L^-T   (regression.py:460-462)
-  enqueue_inverse_factor(c, L, F.A, F.invD);
+  if (int rc = enqueue_inverse_factor(c, L, F)) return rc;
   launch_rows_sumsq(L.stream, L.B2, c->ld, c->np, c->np, 0.0, L.vec);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(ikdiag, L.vec, sizeof(double) * c->n, hipMemcpyDeviceToHost, L.stream));
@@ -776,7 +814,7 @@ int gpmi_loo_terms(gpmi_ctx* c, int kernel, const double* theta, int n_theta, do
   if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
   launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
   trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev, L.info);
-  enqueue_inverse_factor(c, L, L.A, L.invD);
+  if (int rc = enqueue_inverse_factor(c, L, L)) return rc;
   launch_rows_sumsq(s, L.B2, c->ld, c->np, c->np, 0.0, diag_dev);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -823,7 +861,7 @@ int gpmi_loo_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
   launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
   trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev, L.info);
   // K^-1 (full, both triangles) in A
-  enqueue_inverse_factor(c, L, L.A, L.invD);
+  if (int rc = enqueue_inverse_factor(c, L, L)) return rc;
   launch_rows_sumsq(s, L.B2, c->ld, c->np, c->np, 0.0, diag_dev);  // = -diag(K^-1)
   launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, true, L.A, c->ld, L.B2, c->ld, L.B2, c->ld, nt, nt,
               (int)c->np);

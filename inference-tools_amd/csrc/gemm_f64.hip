@@ -31,7 +31,9 @@ struct GemmArgs {
   const double* B;
   int64_t ldc, lda, ldb;
   int ntr, ntc, k;
-  int kskip;  // TILES_LOWER only: contraction starts at k = ti * 128 (operands are zero before it)
+  // 1 (TILES_LOWER): contraction starts at k = ti * BM (operands are zero before it);
+  // 2: contraction ends at k = (tj + 1) * BN (B is lower triangular: B[j][k] = 0 for k > j)
+  int kskip;
   // optional {min start, max end} wall-clock stamps of this launch (s_memrealtime, 100 MHz): per-launch
   // durations for the roofline without HIP events in the stream (event records between the look-ahead
   // streams slowed the factorisation 2x)
@@ -104,7 +106,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   if (g.stamp && tid == 0) atomicMin(g.stamp, (unsigned long long)__builtin_amdgcn_s_memrealtime());
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int kbeg = g.kskip ? ti * BM : 0;
+  const int kbeg = (g.kskip == 1) ? ti * BM : 0;
+  const int kend = (g.kskip == 2 && (tj + 1) * BN < g.k) ? (tj + 1) * BN : g.k;
   const int64_t bz = blockIdx.z;
   const double* __restrict__ Ag = g.A + bz * g.sA + (int64_t)ti * BM * g.lda + kbeg;
   const double* __restrict__ Bg = BKN ? g.B + bz * g.sB + (int64_t)kbeg * g.ldb + (int64_t)tj * BN
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   gload(0);
   sstore(0);
   __syncthreads();
-  const int nk = (g.k - kbeg) / BK;
+  const int nk = (kend - kbeg) / BK;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * BK);
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 
 }  // namespace
 
-void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, bool kskip, double* C,
+void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, int kskip, double* C,
                  int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb, int ntr,
                  int ntc, int k, unsigned long long* stamp, const GemmBatch& bt) {
   // ntr, ntc are in units of 128 rows / columns
@@ -233,7 +236,7 @@ void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, bool 
   // 64 x 64 tiles for the remaining short / small launches
   int bm = 128, bn = 128;
   const bool small = (k <= 128) || (big * bt.count < 384);
-  if (small && !kskip) {
+  if (small && kskip != 1) {
     if (ntc == 1 && tiles == TILES_RECT && op == OP_ASSIGN) {
       bm = 64;
     } else if (!b_kmajor || op == OP_SUB) {
@@ -241,7 +244,7 @@ void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, bool 
       bn = 64;
     }
   }
-  GemmArgs g{C, A, B, ldc, lda, ldb, ntr * (128 / bm), ntc * (128 / bn), k, kskip ? 1 : 0, stamp,
+  GemmArgs g{C, A, B, ldc, lda, ldb, ntr * (128 / bm), ntc * (128 / bn), k, kskip, stamp,
              bt.sC, bt.sA, bt.sB};
   int64_t nwg;
   if (tiles == TILES_RECT)

@@ -42,6 +42,10 @@ struct Lane {
   double* A = nullptr;      // np x ld scratch (K then L)
   double* invD = nullptr;   // (np/128) x 128 x 128 inverses of the diagonal blocks
   double* B2 = nullptr;     // second np x ld matrix (L^-T for the gradient / LOO paths), allocated lazily
+  // inverses of the 512 x 512 diagonal blocks of L (many-right-hand-side solves), built lazily from invD
+  double* inv2 = nullptr;    // ceil(nt / 4) x 512 x 512
+  double* inv2_t = nullptr;  // scratch: ceil(nt / 4) x 256 x 256
+  bool inv2_valid = false;
   double* gws = nullptr;    // gradient partial sums
   int64_t gws_doubles = 0;
   double* vec = nullptr;    // 4 x np work vectors
@@ -71,6 +75,8 @@ struct gpmi_ctx {
   int64_t mq_cap = 0;
   double* pts = nullptr;    // mq_cap x d
   double* pvec = nullptr;   // vectors of length mq_cap * (2 + 2 d)
+  double* trsm_panel = nullptr;  // rows x 544 scratch of the in-place many-right-hand-side solve
+  int64_t trsm_panel_rows = 0;
   // host staging (pinned)
   double* h_stage = nullptr;
   int64_t h_stage_bytes = 0;
@@ -160,8 +166,9 @@ void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_
                     const double* A, int64_t lda, const double* B, int64_t ldb, int ntr, int ntc,
                     int k, unsigned long long* stamp = nullptr, const GemmBatch& bt = GemmBatch());
 
-// general form: b_kmajor -> B is (k x cols) row-major; kskip (TILES_LOWER) -> contraction starts at ti*128
-void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, bool kskip, double* C,
+// general form: b_kmajor -> B is (k x cols) row-major; kskip = 1 (TILES_LOWER) -> contraction starts at
+// the tile row's first column, kskip = 2 -> it ends with the tile column (B lower triangular)
+void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, int kskip, double* C,
                  int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb, int ntr,
                  int ntc, int k, unsigned long long* stamp = nullptr, const GemmBatch& bt = GemmBatch());
 
@@ -189,9 +196,17 @@ void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64
 // backward substitution  L^T a = v : the solution goes to `out` (no aliasing; `r` may be used as scratch)
 void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
                    const double* invD, double* r, double* out, int* err = nullptr);
-// Q (mp x np, row-major, ld) <- Q L^-T   (forward solve of mp right-hand sides stored as rows)
+// inverses of the 512-wide diagonal blocks of L from the 128-wide ones: inv2 (slots of 512 x 512, ld 512),
+// tmp: slots of 256 x 256
+constexpr int GPMI_OB = 512;
+void build_inv2(hipStream_t s, const double* L, int64_t np, int64_t ld, const double* invD, double* inv2,
+                double* tmp);
+// X = Q L^-T  (forward solve of mp right-hand sides stored as rows of Q, mp x np, ld).  Q is consumed.
+// Qout != nullptr: X goes to Qout (same shape / ld).  Qout == nullptr: X replaces Q, staged through
+// `panel` (mp x 544).  upper_rhs: Q is upper triangular (rows below the current block still zero).
 void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                       const double* invD, double* Q, int64_t mp, bool upper_rhs = false);
+                       const double* inv2, double* Q, int64_t mp, bool upper_rhs, double* Qout,
+                       double* panel);
 void launch_set_identity(hipStream_t s, double* Q, int64_t ld, int64_t np);
 // device-to-device vector copy as a kernel (a runtime D2D memcpy stalled the stream for tens of ms)
 void launch_copy(hipStream_t s, const double* src, double* dst, int64_t n);

@@ -321,6 +321,23 @@ __global__ __launch_bounds__(FLOW_THREADS) void trsv_bwd_flow_kernel(
   }
 }
 
+// inv2 slot b (512 x 512, ld 512) <- blockdiag(invD_{4b}, .., invD_{4b+3}), zeros elsewhere
+__global__ void inv2_seed_kernel(const double* __restrict__ invD, double* __restrict__ inv2, int nt) {
+  const int b = blockIdx.z, r = blockIdx.y, cpair = (blockIdx.x * 64 + threadIdx.x) * 2;
+  const int t = r >> 7;
+  d2_t v = d2_t{0.0, 0.0};
+  if ((cpair >> 7) == t && 4 * b + t < nt)
+    v = *reinterpret_cast<const d2_t*>(invD + ((int64_t)(4 * b + t) * NB + (r & 127)) * NB + (cpair & 127));
+  *reinterpret_cast<d2_t*>(inv2 + ((int64_t)b * GPMI_OB + r) * GPMI_OB + cpair) = v;
+}
+
+__global__ void copy_panel_kernel(const double* __restrict__ src, int64_t lds, double* __restrict__ dst,
+                                  int64_t ldd) {
+  const int64_t r = blockIdx.y;
+  const int c = (blockIdx.x * 64 + threadIdx.x) * 2;
+  *reinterpret_cast<d2_t*>(dst + r * ldd + c) = *reinterpret_cast<const d2_t*>(src + r * lds + c);
+}
+
 __global__ void set_identity_kernel(double* __restrict__ Q, int64_t ld, int64_t np) {
   const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
   const int64_t i = blockIdx.y;
@@ -472,32 +489,74 @@ void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int6
   }
 }
 
+void build_inv2(hipStream_t s, const double* L, int64_t np, int64_t ld, const double* invD, double* inv2,
+                double* tmp) {
+  // inv([[A, 0], [C, B]]) = [[A^-1, 0], [-B^-1 C A^-1, B^-1]], applied twice: 128 -> 256 -> 512.
+  // Every product is one batched launch over the outer blocks (uniform strides).
+  const int nt = (int)(np / NB);
+  const int nob = (nt + 3) / 4;
+  const int64_t slot = (int64_t)GPMI_OB * GPMI_OB, tslot = 256 * 256;
+  hipLaunchKernelGGL(inv2_seed_kernel, dim3(GPMI_OB / 2 / 64, GPMI_OB, (unsigned)nob), dim3(64), 0, s, invD, inv2,
+                     nt);
+  auto offdiag = [&](int r0, int c0, int h2, int h1, int count) {
+    // X[r0.., c0..] = -X[r0.., r0..] * L[r0.., c0..] * X[c0.., c0..]   (h2 x h1 tiles), `count` outer blocks
+    if (count <= 0 || h2 <= 0) return;
+    const GemmBatch b1{count, tslot, 4 * NB * ld + 4 * NB, slot};
+    launch_gemm(s, TILES_RECT, OP_ASSIGN, true, 0, tmp, 256, L + (int64_t)r0 * NB * ld + (int64_t)c0 * NB, ld,
+                inv2 + (int64_t)c0 * NB * GPMI_OB + (int64_t)c0 * NB, GPMI_OB, h2, h1, h1 * NB, nullptr, b1);
+    const GemmBatch b2{count, slot, slot, tslot};
+    launch_gemm(s, TILES_RECT, OP_SUB, true, 0, inv2 + (int64_t)r0 * NB * GPMI_OB + (int64_t)c0 * NB, GPMI_OB,
+                inv2 + (int64_t)r0 * NB * GPMI_OB + (int64_t)r0 * NB, GPMI_OB, tmp, 256, h2, h1, h2 * NB, nullptr,
+                b2);
+  };
+  // outer blocks b with tile 4 b + t inside the matrix: (nt - t + 3) / 4
+  offdiag(1, 0, 1, 1, (nt - 1 + 3) / 4);
+  offdiag(3, 2, 1, 1, (nt - 3 + 3) / 4);
+  const int full = nt / 4;
+  offdiag(2, 0, 2, 2, full);
+  if (nt % 4 == 3) {  // last outer block has three tiles: a 1 x 2 corner
+    const int64_t b = full;
+    const GemmBatch one{};
+    const double* Lb = L + (b * 4 * NB) * ld + b * 4 * NB;
+    double* Xb = inv2 + b * slot;
+    double* Tb = tmp + b * tslot;
+    launch_gemm(s, TILES_RECT, OP_ASSIGN, true, 0, Tb, 256, Lb + (int64_t)2 * NB * ld, ld, Xb, GPMI_OB, 1, 2, 2 * NB,
+                nullptr, one);
+    launch_gemm(s, TILES_RECT, OP_SUB, true, 0, Xb + (int64_t)2 * NB * GPMI_OB, GPMI_OB,
+                Xb + (int64_t)2 * NB * GPMI_OB + 2 * NB, GPMI_OB, Tb, 256, 1, 2, NB, nullptr, one);
+  }
+}
+
 void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                       const double* invD, double* Q, int64_t mp, bool upper_rhs) {
-  // Two-level right-looking sweep, like the factorisation: inside an outer block of 512 columns the
-  // 128-wide steps only touch the block (K = 128, few tiles, latency bound), then ONE update with
-  // K = 512 carries the block's contribution to all remaining columns (throughput bound, 4x less
-  // traffic on Q than 128-wide updates).
+                       const double* inv2, double* Q, int64_t mp, bool upper_rhs, double* Qout,
+                       double* panel) {
+  // Right-looking sweep over the 512-wide outer blocks: the block's solution is ONE product with the
+  // inverted diagonal block (K <= 512, cut at the diagonal: the inverse is lower triangular), then
+  // ONE update with K = 512 carries it to all remaining columns (throughput bound).  32 dependent
+  // pairs of launches at N = 16384 instead of 128 x 2 + 32 with the 128-wide inverses.
   const int nt = (int)(np / NB), mt_all = (int)(mp / NB);
-  const int OBT = 4;
+  const int OBT = GPMI_OB / NB;
+  const int64_t ldp = GPMI_OB + 32;
   ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)mp * np * np, 4.0 * np * np);
   for (int J = 0; J < nt; J += OBT) {
     const int Je = (J + OBT < nt) ? J + OBT : nt;
+    const int w = Je - J;
     // upper_rhs: Q is upper triangular (e.g. the identity): rows below block Je - 1 are still zero here
     const int mt = upper_rhs ? (Je < mt_all ? Je : mt_all) : mt_all;
-    for (int k = J; k < Je; ++k) {
-      double* Qk = Q + (int64_t)k * NB;
-      // Q[:, k] <- Q[:, k] * invD_k^T   (in place, one tile column)
-      launch_gemm_nt(s, TILES_RECT, OP_ASSIGN, Qk, ld, Qk, ld, invD + (int64_t)k * NB * NB, NB, mt, 1, NB);
-      const int rem = Je - k - 1;
-      if (rem > 0)  // Q[:, k+1:Je] -= Q[:, k] * L[k+1:Je, k]^T
-        launch_gemm_nt(s, TILES_RECT, OP_SUB, Qk + NB, ld, Qk, ld,
-                       L + (int64_t)(k + 1) * NB * ld + (int64_t)k * NB, ld, mt, rem, NB);
-    }
+    double* QJ = Q + (int64_t)J * NB;
+    double* X = Qout ? Qout + (int64_t)J * NB : panel;
+    const int64_t ldx = Qout ? ld : ldp;
+    launch_gemm(s, TILES_RECT, OP_ASSIGN, false, 2, X, ldx, QJ, ld, inv2 + (int64_t)(J / OBT) * GPMI_OB * GPMI_OB,
+                GPMI_OB, mt, w, w * NB);
     const int rest = nt - Je;
-    if (rest > 0)  // Q[:, Je:] -= Q[:, J:Je] * L[Je:, J:Je]^T
-      launch_gemm_nt(s, TILES_RECT, OP_SUB, Q + (int64_t)Je * NB, ld, Q + (int64_t)J * NB, ld,
-                     L + (int64_t)Je * NB * ld + (int64_t)J * NB, ld, mt, rest, (Je - J) * NB);
+    if (rest > 0)  // Q[:, Je:] -= X * L[Je:, J:Je]^T
+      launch_gemm_nt(s, TILES_RECT, OP_SUB, Q + (int64_t)Je * NB, ld, X, ldx,
+                     L + (int64_t)Je * NB * ld + (int64_t)J * NB, ld, mt, rest, w * NB);
+    if (!Qout) {
+      const int64_t rows = (int64_t)mt * NB;
+      hipLaunchKernelGGL(copy_panel_kernel, dim3((unsigned)(w * NB / 2 / 64), (unsigned)rows), dim3(64), 0, s, panel,
+                         ldp, QJ, ld);
+    }
   }
 }
 
