@@ -109,10 +109,15 @@ __device__ inline void factor16(double* S, double* Wl, double* __restrict__ invD
 }
 
 // One workgroup (4 waves): L = chol(A_blk) in place (lower part of A), invD = L^-1 (dense
-// 128 x 128, zero above the diagonal).  Blocked by 16 inside LDS: factor16 on one wave, panel and
-// trailing updates as 16 x 16 x 16 products on v_mfma_f64_16x16x4_f64, then the inverse row-block by
-// row-block, X[ib][jb] = -W_ib * sum_kb L[ib][kb] X[kb][jb], written straight to invD (earlier
-// row-blocks are read back through L2).
+// 128 x 128, zero above the diagonal).  Blocked by 16 inside LDS; everything except the 16 x 16
+// eliminations runs as 16 x 16 x 16 products on v_mfma_f64_16x16x4_f64.  The eliminations (factor16,
+// one wave, ~2.6 us each) are the critical path, so the rest is arranged around them.  Step kb:
+//   [A] wave 0: factor16(kb).   waves 1-3 meanwhile: the trailing tiles of step kb - 1 that step kb does not
+//       need yet (columns > kb), and T = sum_k L[kb][k] X[k][jb] for row block kb of the inverse (the X
+//       tiles of earlier row blocks are read back from invD through L2, requested up front)
+//   [B] X[kb][jb] = -W_kb T (row block kb of the inverse, to invD);  panel A[ib][kb] <- A[ib][kb] W_kb^T
+//   [C] column block kb of L goes to global memory;  trailing update of column kb + 1 only
+// so that at the end of the loop L and the inverse are already complete.
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A, int64_t ld,
                                                          double* __restrict__ invD,
                                                          int* __restrict__ info, int col0,
@@ -158,19 +163,101 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
         }
       }
     }
-    // zero the strictly-upper blocks of the inverse
-    for (int idx = tid; idx < NB * NB / 2; idx += 256) {
-      const int r = idx >> 6, c = (idx & 63) * 2;
-      if ((c >> 4) > (r >> 4)) *reinterpret_cast<d2_t*>(invD + r * NB + c) = d2_t{0.0, 0.0};
-    }
   }
   __syncthreads();
   lap(0);
+
+  // one 16 x 16 trailing tile of step kb:  A[ib][jb] -= P_ib P_jb^T  (P = column block kb after the panel step)
+  auto trailing_tile = [&](int kb, int ib, int jb) {
+    d4_t acc;
+    int rc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      rc[r] = prow(ib * BS + fk + 4 * r) + jb * BS + fr;
+      acc[r] = S[rc[r]];
+    }
+    const int ra = prow(ib * BS + fr) + kb * BS + fk, rb = prow(jb * BS + fr) + kb * BS + fk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[ra + 4 * q], S[rb + 4 * q], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[rc[r]] = acc[r];
+  };
+
   for (int kb = 0; kb < NBLK; ++kb) {
     const int base = kb * BS;
-    if (wave == 0) factor16(S, Wl, invD, kb, info, col0, lane);
+    d4_t T[3];  // this wave's tiles of inverse row block kb, before the multiplication with -W_kb
+    // ---- [A] ----
+    if (wave == 0) {
+      factor16(S, Wl, invD, kb, info, col0, lane);
+      lap(4);
+    } else {
+      // operands of the inverse row block first: their L2 latency overlaps the trailing tiles below
+      double bx[3][NBLK - 1][4];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int jb = wave - 1 + 3 * t;
+#pragma unroll
+        for (int kk = 0; kk < NBLK - 1; ++kk) {
+          const int k2 = jb + kk;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            bx[t][kk][q] = (k2 < kb) ? invD[(k2 * BS + fk + 4 * q) * NB + jb * BS + fr] : 0.0;  // X[k2][jb]
+        }
+      }
+      if (kb == 0) {
+        // zero the strictly-upper 16-blocks of the inverse (nothing else to do in the first step)
+        for (int idx = tid - 64; idx < NB * NB / 2; idx += 192) {
+          const int r = idx >> 6, c = (idx & 63) * 2;
+          if ((c >> 4) > (r >> 4)) *reinterpret_cast<d2_t*>(invD + r * NB + c) = d2_t{0.0, 0.0};
+        }
+      } else {
+        // trailing tiles of step kb - 1 in columns > kb (column kb was done in [C] of the previous step)
+        const int m = NBLK - 1 - kb;  // tiles (ib, jb) with kb < jb <= ib < NBLK
+        const int ntile = m * (m + 1) / 2;
+        for (int t = wave - 1; t < ntile; t += 3) {
+          int i = 0;
+          while ((i + 1) * (i + 2) / 2 <= t) ++i;
+          const int j = t - i * (i + 1) / 2;
+          trailing_tile(kb - 1, kb + 1 + i, kb + 1 + j);
+        }
+      }
+      const int ra = prow(base + fr) + fk;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int jb = wave - 1 + 3 * t;
+        T[t] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < NBLK - 1; ++kk) {
+          const int k2 = jb + kk;
+          if (k2 < kb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              T[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[ra + k2 * BS + 4 * q], bx[t][kk][q], T[t], 0, 0, 0);
+          }
+        }
+      }
+    }
     __syncthreads();
     lap(1);
+    // ---- [B] ----
+    if (wave > 0) {
+      double wv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wv[q] = -Wl[fr * WP + fk + 4 * q];  // A operand: -W[i = fr][k = fk + 4 q]
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int jb = wave - 1 + 3 * t;
+        if (jb < kb) {
+          // the D layout of T (row = fk + 4 r) is exactly the B-operand layout of k-step q = r
+          d4_t X = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) X = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q], T[t][q], X, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) invD[(base + fk + 4 * r) * NB + jb * BS + fr] = X[r];
+        }
+      }
+    }
     // panel: A[ib][kb] <- A[ib][kb] * W^T
     for (int ib = kb + 1 + wave; ib < NBLK; ib += 4) {
       d4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -184,80 +271,24 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
 #pragma unroll
       for (int r = 0; r < 4; ++r) S[prow(ib * BS + fk + 4 * r) + base + fr] = acc[r];
     }
+    __threadfence_block();  // row block kb of the inverse is read back (through L2) from the next step on
     __syncthreads();
     lap(2);
-    // trailing: A[ib][jb] -= P_ib P_jb^T for ib >= jb > kb (diagonal tiles computed in full: symmetric)
-    const int m = NBLK - 1 - kb;
-    const int ntile = m * (m + 1) / 2;
-    for (int t = wave; t < ntile; t += 4) {
-      int i = 0;
-      while ((i + 1) * (i + 2) / 2 <= t) ++i;
-      const int j = t - i * (i + 1) / 2;
-      const int ib = kb + 1 + i, jb = kb + 1 + j;
-      d4_t acc;
-      int rc[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        rc[r] = prow(ib * BS + fk + 4 * r) + jb * BS + fr;
-        acc[r] = S[rc[r]];
+    // ---- [C] ----
+    {
+      // column block kb of L is final: rows base .. 127, 16 columns, 8 threads x 16 bytes per row
+      const int c = base + (tid & 7) * 2;
+      for (int r = base + (tid >> 3); r < NB; r += 32) {
+        if (c + 1 <= r)
+          *reinterpret_cast<d2_t*>(A + (int64_t)r * ld + c) = d2_t{S[prow(r) + c], S[prow(r) + c + 1]};
+        else if (c == r)
+          A[(int64_t)r * ld + c] = S[prow(r) + c];
       }
-      const int ra = prow(ib * BS + fr) + base + fk, rb = prow(jb * BS + fr) + base + fk;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[ra + 4 * q], S[rb + 4 * q], acc, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) S[rc[r]] = acc[r];
     }
+    for (int ib = kb + 1 + wave; ib < NBLK; ib += 4) trailing_tile(kb, ib, kb + 1);
     __syncthreads();
     lap(3);
   }
-  // L back to global memory (lower triangle incl. diagonal; the upper triangle of A is untouched)
-  for (int idx = tid; idx < NB * NB / 2; idx += 256) {
-    const int r = idx >> 6, c = (idx & 63) * 2;
-    if (c + 1 <= r)
-      *reinterpret_cast<d2_t*>(A + (int64_t)r * ld + c) = d2_t{S[prow(r) + c], S[prow(r) + c + 1]};
-    else if (c == r)
-      A[(int64_t)r * ld + c] = S[prow(r) + c];
-  }
-  __syncthreads();
-  lap(4);
-  // inverse, row-block by row-block (the barrier orders the global writes of one row-block before
-  // the reads of the next: same CU, lines never read before they are written).  All the operands a
-  // tile needs from global memory are requested up front so that their L2 latency overlaps.
-  for (int ib = 1; ib < NBLK; ++ib) {
-    for (int jb = wave; jb < ib; jb += 4) {
-      double bx[NBLK - 1][4], wv[4];
-#pragma unroll
-      for (int kk = 0; kk < NBLK - 1; ++kk) {
-        const int kb = jb + kk;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          bx[kk][q] = (kb < ib) ? invD[(kb * BS + fk + 4 * q) * NB + jb * BS + fr] : 0.0;  // X[kb][jb]
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) wv[q] = -invD[(ib * BS + fr) * NB + ib * BS + fk + 4 * q];  // -W_ib
-      d4_t T = {0.0, 0.0, 0.0, 0.0};
-      const int ra = prow(ib * BS + fr) + fk;
-#pragma unroll
-      for (int kk = 0; kk < NBLK - 1; ++kk) {
-        const int kb = jb + kk;
-        if (kb < ib) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            T = __builtin_amdgcn_mfma_f64_16x16x4f64(S[ra + kb * BS + 4 * q], bx[kk][q], T, 0, 0, 0);
-        }
-      }
-      // the D layout of T (row = fk + 4 r) is exactly the B-operand layout of k-step q = r
-      d4_t X = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) X = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q], T[q], X, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) invD[(ib * BS + fk + 4 * r) * NB + jb * BS + fr] = X[r];
-    }
-    __threadfence_block();
-    __syncthreads();
-  }
-  lap(5);
   if (dbg && tid == 0)
     for (int i = 0; i < 6; ++i) dbg[i] = acc_t[i];
 }
