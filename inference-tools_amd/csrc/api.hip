@@ -1119,7 +1119,7 @@ int gpmi_dev_potrf(gpmi_ctx* c, double* A, int64_t n, int64_t ld, int* info) {
     unsigned long long h[6];
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
-    std::fprintf(stderr, "[potrf_diag cycles] load %llu | [A] wait for waves 1-3 after factor16 %llu | [B] inverse rows + panel %llu | [C] store + next column %llu | factor16 x8 %llu | %llu\n",
+    std::fprintf(stderr, "[potrf_diag cycles] load %llu | wave 0 waits at the barrier %llu | sub-diagonal panel + trailing tile %llu | end %llu | factor16 x8 %llu | %llu\n",
                  h[0], h[1], h[2], h[3], h[4], h[5]);
     (void)hipFree(dbg);
   } else

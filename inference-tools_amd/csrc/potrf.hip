@@ -57,9 +57,9 @@ __device__ inline int prow(int r) {
 // pivot row from the lane group that owns row c (ds_bpermute), the pivot itself through
 // v_readlane.  The same row operations applied to the identity give M^-1 (A = M D M^T); then
 // L[k][i] = U[i][k] / sqrt(p_i) and W = L^-1 = D^-1/2 M^-1 (to LDS for the panel phase and to the
-// diagonal block of invD in global memory).
-__device__ inline void factor16(double* S, double* Wl, double* __restrict__ invD, int kb, int* info,
-                                int col0, int lane) {
+// diagonal block of invD in global memory); L itself also goes straight to the matrix in global memory.
+__device__ inline void factor16(double* S, double* Wl, double* __restrict__ invD, double* __restrict__ A,
+                                int64_t ld, int kb, int* info, int col0, int lane) {
   const int k = lane & 15, g = lane >> 4;
   const int base = kb * BS;
   double a[4], e[4];
@@ -100,7 +100,11 @@ __device__ inline void factor16(double* S, double* Wl, double* __restrict__ invD
   for (int j = 0; j < 4; ++j) {
     const int i = 4 * j + g;
     const double rsi = __shfl(rs, i, 64);
-    if (i <= k) S[rowk + base + i] = a[j] * rsi;  // L[k][i] = U[i][k] / sqrt(p_i)
+    if (i <= k) {
+      const double lki = a[j] * rsi;  // L[k][i] = U[i][k] / sqrt(p_i)
+      S[rowk + base + i] = lki;
+      A[(int64_t)(base + k) * ld + base + i] = lki;
+    }
     const double w = e[j] * rsi;                    // W[i][k] (zero above the diagonal)
     Wl[i * WP + k] = w;
     invD[(base + i) * NB + base + k] = w;
@@ -108,17 +112,21 @@ __device__ inline void factor16(double* S, double* Wl, double* __restrict__ invD
   if (badcol >= 0 && lane == 0 && *info == 0) *info = col0 + base + badcol + 1;
 }
 
-// One workgroup (4 waves): L = chol(A_blk) in place (lower part of A), invD = L^-1 (dense
+// One workgroup (8 waves): L = chol(A_blk) in place (lower part of A), invD = L^-1 (dense
 // 128 x 128, zero above the diagonal).  Blocked by 16 inside LDS; everything except the 16 x 16
 // eliminations runs as 16 x 16 x 16 products on v_mfma_f64_16x16x4_f64.  The eliminations (factor16,
-// one wave, ~2.6 us each) are the critical path, so the rest is arranged around them.  Step kb:
-//   [A] wave 0: factor16(kb).   waves 1-3 meanwhile: the trailing tiles of step kb - 1 that step kb does not
-//       need yet (columns > kb), and T = sum_k L[kb][k] X[k][jb] for row block kb of the inverse (the X
-//       tiles of earlier row blocks are read back from invD through L2, requested up front)
-//   [B] X[kb][jb] = -W_kb T (row block kb of the inverse, to invD);  panel A[ib][kb] <- A[ib][kb] W_kb^T
-//   [C] column block kb of L goes to global memory;  trailing update of column kb + 1 only
-// so that at the end of the loop L and the inverse are already complete.
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A, int64_t ld,
+// one wave, ~2.7 us each) are the critical path, so wave 0 does nothing but that chain:
+//   wave 0, step kb:   factor16(kb) | barrier | panel tile (kb+1, kb), trailing tile (kb+1, kb+1)
+//   waves 1-7, step kb (one step behind, "bulk(kb - 1)"):  the other panel tiles of column kb - 1, row
+//       block kb - 1 of the inverse (X[kb-1][jb] = -W sum_k L[kb-1][k] X[k][jb], earlier X rows read back
+//       from invD through L2), the other trailing tiles of step kb - 1 | barrier
+// One barrier per step; inside bulk() the seven waves order themselves through two LDS counters
+// (panel tiles of the column finished / wave 0's sub-diagonal tile finished).  L and the inverse go to
+// global memory tile by tile as they are produced.
+constexpr int DIAG_THREADS = 512;  // wave 0: elimination chain; waves 1-7: everything else
+constexpr int DIAG_BULK = DIAG_THREADS / 64 - 1;
+
+__global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __restrict__ A, int64_t ld,
                                                          double* __restrict__ invD,
                                                          int* __restrict__ info, int col0,
                                                          unsigned long long* __restrict__ dbg,
@@ -137,23 +145,29 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
   };
   if (dbg) t_prev = __builtin_amdgcn_s_memtime();
   __shared__ double S[S_DOUBLES];
-  __shared__ double Wl[BS * WP];
+  __shared__ double Wl[2][BS * WP];
+  __shared__ int sub_ready;   // wave 0: sub-diagonal tiles (k + 1, k) finished for k < sub_ready
+  __shared__ int panel_done;  // waves 1-3: 3 (k + 1) once every one of them has finished its panel tiles of column k
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
+  if (tid == 0) {
+    sub_ready = 0;
+    panel_done = 0;
+  }
   {
-    // coalesced 16-byte loads, all 32 of a thread in flight before the first LDS store: row = (tid >> 6) + 4 i,
+    // coalesced 16-byte loads, all 16 of a thread in flight before the first LDS store: row = (tid >> 6) + 8 i,
     // columns 2 (tid & 63) .. + 1.  Only the block-lower part is needed; the upper part of a diagonal
     // 16-block is mirrored from the lower triangle of A (both copies written from the lower element).
     const int cc = (tid & 63) * 2;
-    d2_t v[32];
+    d2_t v[16];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int r = (tid >> 6) + 4 * i;
+    for (int i = 0; i < 16; ++i) {
+      const int r = (tid >> 6) + 8 * i;
       v[i] = (cc <= r) ? *reinterpret_cast<const d2_t*>(A + (int64_t)r * ld + cc) : d2_t{0.0, 0.0};
     }
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const int r = (tid >> 6) + 4 * i;
+    for (int i = 0; i < 16; ++i) {
+      const int r = (tid >> 6) + 8 * i;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int c = cc + e;
@@ -167,7 +181,21 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
   __syncthreads();
   lap(0);
 
-  // one 16 x 16 trailing tile of step kb:  A[ib][jb] -= P_ib P_jb^T  (P = column block kb after the panel step)
+  // A[ib][kb] <- A[ib][kb] * W_kb^T, to LDS and to the matrix in global memory
+  auto panel_tile = [&](int kb, int ib) {
+    const double* W = Wl[kb & 1];
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    const int ra = prow(ib * BS + fr) + kb * BS + fk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[ra + 4 * q], W[fr * WP + fk + 4 * q], acc, 0, 0, 0);  // B[k][j] = W[j][k]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      S[prow(ib * BS + fk + 4 * r) + kb * BS + fr] = acc[r];
+      A[(int64_t)(ib * BS + fk + 4 * r) * ld + kb * BS + fr] = acc[r];
+    }
+  };
+  // A[ib][jb] -= P_ib P_jb^T  (P = column block kb after the panel step); diagonal tiles in full (symmetric)
   auto trailing_tile = [&](int kb, int ib, int jb) {
     d4_t acc;
     int rc[4];
@@ -183,112 +211,95 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
 #pragma unroll
     for (int r = 0; r < 4; ++r) S[rc[r]] = acc[r];
   };
-
-  for (int kb = 0; kb < NBLK; ++kb) {
+  auto wait_for = [&](int* counter, int target) {
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+      __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  auto signal = [&](int* counter, int add) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(counter, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  // everything of step kb that is not on the elimination chain (waves 1-7)
+  auto bulk = [&](int kb) {
+    const int wb = wave - 1;
     const int base = kb * BS;
-    d4_t T[3];  // this wave's tiles of inverse row block kb, before the multiplication with -W_kb
-    // ---- [A] ----
-    if (wave == 0) {
-      factor16(S, Wl, invD, kb, info, col0, lane);
-      lap(4);
-    } else {
-      // operands of the inverse row block first: their L2 latency overlaps the trailing tiles below
-      double bx[3][NBLK - 1][4];
+    const int jb = wb;  // this wave's column of the inverse row block (tiles jb < kb)
+    // operands of the inverse row block first: their L2 latency overlaps the panel tile
+    double bx[NBLK - 1][4];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int jb = wave - 1 + 3 * t;
+    for (int kk = 0; kk < NBLK - 1; ++kk) {
+      const int k2 = jb + kk;
 #pragma unroll
-        for (int kk = 0; kk < NBLK - 1; ++kk) {
-          const int k2 = jb + kk;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            bx[t][kk][q] = (k2 < kb) ? invD[(k2 * BS + fk + 4 * q) * NB + jb * BS + fr] : 0.0;  // X[k2][jb]
-        }
-      }
-      if (kb == 0) {
-        // zero the strictly-upper 16-blocks of the inverse (nothing else to do in the first step)
-        for (int idx = tid - 64; idx < NB * NB / 2; idx += 192) {
-          const int r = idx >> 6, c = (idx & 63) * 2;
-          if ((c >> 4) > (r >> 4)) *reinterpret_cast<d2_t*>(invD + r * NB + c) = d2_t{0.0, 0.0};
-        }
-      } else {
-        // trailing tiles of step kb - 1 in columns > kb (column kb was done in [C] of the previous step)
-        const int m = NBLK - 1 - kb;  // tiles (ib, jb) with kb < jb <= ib < NBLK
-        const int ntile = m * (m + 1) / 2;
-        for (int t = wave - 1; t < ntile; t += 3) {
-          int i = 0;
-          while ((i + 1) * (i + 2) / 2 <= t) ++i;
-          const int j = t - i * (i + 1) / 2;
-          trailing_tile(kb - 1, kb + 1 + i, kb + 1 + j);
-        }
-      }
-      const int ra = prow(base + fr) + fk;
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int jb = wave - 1 + 3 * t;
-        T[t] = d4_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < NBLK - 1; ++kk) {
-          const int k2 = jb + kk;
-          if (k2 < kb) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              T[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[ra + k2 * BS + 4 * q], bx[t][kk][q], T[t], 0, 0, 0);
-          }
-        }
-      }
+      for (int q = 0; q < 4; ++q)
+        bx[kk][q] = (k2 < kb) ? invD[(k2 * BS + fk + 4 * q) * NB + jb * BS + fr] : 0.0;  // X[k2][jb]
     }
-    __syncthreads();
-    lap(1);
-    // ---- [B] ----
-    if (wave > 0) {
+    if (kb + 2 + wb < NBLK) panel_tile(kb, kb + 2 + wb);
+    signal(&panel_done, 1);
+    if (jb < kb) {
+      const double* W = Wl[kb & 1];
       double wv[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) wv[q] = -Wl[fr * WP + fk + 4 * q];  // A operand: -W[i = fr][k = fk + 4 q]
+      for (int q = 0; q < 4; ++q) wv[q] = -W[fr * WP + fk + 4 * q];  // A operand: -W[i = fr][k = fk + 4 q]
+      const int ra = prow(base + fr) + fk;
+      d4_t T = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int jb = wave - 1 + 3 * t;
-        if (jb < kb) {
-          // the D layout of T (row = fk + 4 r) is exactly the B-operand layout of k-step q = r
-          d4_t X = {0.0, 0.0, 0.0, 0.0};
+      for (int kk = 0; kk < NBLK - 1; ++kk) {
+        const int k2 = jb + kk;
+        if (k2 < kb) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) X = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q], T[t][q], X, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) invD[(base + fk + 4 * r) * NB + jb * BS + fr] = X[r];
+          for (int q = 0; q < 4; ++q)
+            T = __builtin_amdgcn_mfma_f64_16x16x4f64(S[ra + k2 * BS + 4 * q], bx[kk][q], T, 0, 0, 0);
         }
       }
-    }
-    // panel: A[ib][kb] <- A[ib][kb] * W^T
-    for (int ib = kb + 1 + wave; ib < NBLK; ib += 4) {
-      d4_t acc = {0.0, 0.0, 0.0, 0.0};
-      const int ra = prow(ib * BS + fr) + base + fk;
+      // the D layout of T (row = fk + 4 r) is exactly the B-operand layout of k-step q = r
+      d4_t X = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double av = S[ra + 4 * q];
-        const double bv = Wl[fr * WP + fk + 4 * q];  // B[k][j] = W[j][k]
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-      }
+      for (int q = 0; q < 4; ++q) X = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q], T[q], X, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) S[prow(ib * BS + fk + 4 * r) + base + fr] = acc[r];
+      for (int r = 0; r < 4; ++r) invD[(base + fk + 4 * r) * NB + jb * BS + fr] = X[r];
     }
-    __threadfence_block();  // row block kb of the inverse is read back (through L2) from the next step on
-    __syncthreads();
-    lap(2);
-    // ---- [C] ----
-    {
-      // column block kb of L is final: rows base .. 127, 16 columns, 8 threads x 16 bytes per row
-      const int c = base + (tid & 7) * 2;
-      for (int r = base + (tid >> 3); r < NB; r += 32) {
-        if (c + 1 <= r)
-          *reinterpret_cast<d2_t*>(A + (int64_t)r * ld + c) = d2_t{S[prow(r) + c], S[prow(r) + c + 1]};
-        else if (c == r)
-          A[(int64_t)r * ld + c] = S[prow(r) + c];
+    if (kb + 1 < NBLK) {
+      // trailing tiles (ib, jb), kb < jb <= ib, except (kb + 1, kb + 1) which wave 0 keeps on its chain; they
+      // read the panel tiles of the other waves and wave 0's tile (kb + 1, kb)
+      wait_for(&panel_done, DIAG_BULK * (kb + 1));
+      wait_for(&sub_ready, kb + 1);
+      const int m = NBLK - 1 - kb;
+      const int ntile = m * (m + 1) / 2;
+      for (int t = 1 + wb; t < ntile; t += DIAG_BULK) {
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= t) ++i;
+        const int j = t - i * (i + 1) / 2;
+        trailing_tile(kb, kb + 1 + i, kb + 1 + j);
       }
     }
-    for (int ib = kb + 1 + wave; ib < NBLK; ib += 4) trailing_tile(kb, ib, kb + 1);
+  };
+
+  for (int kb = 0; kb < NBLK; ++kb) {
+    if (wave == 0) {
+      factor16(S, Wl[kb & 1], invD, A, ld, kb, info, col0, lane);
+      lap(4);
+    } else if (kb > 0) {
+      bulk(kb - 1);
+    } else {
+      // zero the strictly-upper 16-blocks of the inverse (nothing else to do during the first elimination)
+      for (int idx = tid - 64; idx < NB * NB / 2; idx += DIAG_THREADS - 64) {
+        const int r = idx >> 6, c = (idx & 63) * 2;
+        if ((c >> 4) > (r >> 4)) *reinterpret_cast<d2_t*>(invD + r * NB + c) = d2_t{0.0, 0.0};
+      }
+    }
+    __threadfence_block();  // inverse rows written by bulk() are read back (through L2) in the next step
     __syncthreads();
-    lap(3);
+    lap(1);
+    if (wave == 0 && kb + 1 < NBLK) {
+      panel_tile(kb, kb + 1);
+      signal(&sub_ready, 1);
+      trailing_tile(kb, kb + 1, kb + 1);
+      lap(2);
+    }
   }
+  if (wave > 0) bulk(NBLK - 1);
+  lap(3);
   if (dbg && tid == 0)
     for (int i = 0; i < 6; ++i) dbg[i] = acc_t[i];
 }
@@ -297,7 +308,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
 
 void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0,
                        unsigned long long* dbg, const BatchShape& bs) {
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, 1, (unsigned)bs.count), dim3(256), 0, s, Ablk, ld, invD,
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, 1, (unsigned)bs.count), dim3(DIAG_THREADS), 0, s, Ablk, ld, invD,
                      info, col0, dbg, bs.sMat, bs.sInv);
 }
 
