@@ -156,10 +156,14 @@ def main():
     eng.profile_reset()
     fence()
     t0 = time.perf_counter()
+    marks = []
     for _ in range(args.steps):
         res = step()
+        marks.append(time.perf_counter())
     fence()
     dt = time.perf_counter() - t0
+    if os.environ.get("BENCH_STEP_TIMES") and rank == 0:  # debugging aid: host-side completion time of each step
+        print("step ms:", [round((b - a) * 1e3, 2) for a, b in zip([t0] + marks[:-1], marks)], file=sys.stderr)
     prof = eng.profile_read(_lib.PROF_SYRK)
     eng.profile_enable(0)
 

@@ -303,10 +303,8 @@ __global__ void negate_kernel(double* v, int64_t n) {
 
 __global__ void stamp_init_kernel(unsigned long long* pool, int slots) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < slots) {
-    pool[2 * i] = ~0ull;
-    pool[2 * i + 1] = 0ull;
-  }
+  if (i < slots)
+    for (int j = 0; j < GPMI_STAMP_WORDS; ++j) pool[(size_t)GPMI_STAMP_WORDS * i + j] = (j < 8) ? ~0ull : 0ull;
 }
 }  // namespace
 
@@ -315,7 +313,7 @@ unsigned long long* prof_stamp_slot(gpmi_ctx* c, double flops, double bytes) {
   if ((int)c->stamp_flops.size() >= GPMI_STAMP_SLOTS) return nullptr;
   c->stamp_flops.push_back(flops);
   c->stamp_bytes.push_back(bytes);
-  return c->stamp_pool + 2 * (c->stamp_flops.size() - 1);
+  return c->stamp_pool + (size_t)GPMI_STAMP_WORDS * (c->stamp_flops.size() - 1);
 }
 
 ProfScope::ProfScope(gpmi_ctx* ctx, hipStream_t st, int klass, double flops, double bytes)
@@ -1000,10 +998,13 @@ int gpmi_profile_enable(gpmi_ctx* c, int on) {
   c->prof_mask = (on == 1) ? 0xF : (unsigned)on >> 1;
   if (((c->prof_mask >> GPMI_PROF_SYRK) & 1) && !c->stamp_pool) {
     if (int rc = set_device(c)) return rc;
-    HIPCHK(c, hipMalloc(&c->stamp_pool, sizeof(unsigned long long) * 2 * GPMI_STAMP_SLOTS));
-    hipLaunchKernelGGL(stamp_init_kernel, dim3(GPMI_STAMP_SLOTS / 256), dim3(256), 0, 0, c->stamp_pool,
+    HIPCHK(c, hipMalloc(&c->stamp_pool, sizeof(unsigned long long) * GPMI_STAMP_WORDS * GPMI_STAMP_SLOTS));
+    // on the library's own stream: a kernel launched on the NULL stream left every later launch of the process
+    // with a ~10 us dispatch gap to its predecessor (1.2 ms per fit at N = 16384)
+    hipStream_t s0 = c->lanes[0].stream;
+    hipLaunchKernelGGL(stamp_init_kernel, dim3(GPMI_STAMP_SLOTS / 256), dim3(256), 0, s0, c->stamp_pool,
                        GPMI_STAMP_SLOTS);
-    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipStreamSynchronize(s0));
   }
   return GPMI_OK;
 }
@@ -1023,18 +1024,28 @@ static int profile_collect(gpmi_ctx* c) {
   // device-stamped trailing-update launches: duration = (max end - min start) / 100 MHz
   const size_t ns = c->stamp_flops.size();
   if (ns && c->stamp_pool) {
-    std::vector<unsigned long long> h(2 * ns);
-    HIPCHK(c, hipMemcpy(h.data(), c->stamp_pool, sizeof(unsigned long long) * 2 * ns, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> h((size_t)GPMI_STAMP_WORDS * ns);
+    hipStream_t s0 = c->lanes[0].stream;
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->stamp_pool, sizeof(unsigned long long) * GPMI_STAMP_WORDS * ns,
+                             hipMemcpyDeviceToHost, s0));
+    HIPCHK(c, hipStreamSynchronize(s0));
     for (size_t i = 0; i < ns; ++i) {
-      if (h[2 * i + 1] <= h[2 * i]) continue;  // launch never ran
-      c->prof_ms[GPMI_PROF_SYRK] += (double)(h[2 * i + 1] - h[2 * i]) * 1e-5;  // 10 ns ticks -> ms
+      // words 0..7: start of the launch's first eight workgroups; words 8..15: last end seen on each XCD
+      const unsigned long long* w = h.data() + (size_t)GPMI_STAMP_WORDS * i;
+      unsigned long long t0 = ~0ull, t1 = 0ull;
+      for (int j = 0; j < 8; ++j) {
+        if (w[j] < t0) t0 = w[j];
+        if (w[8 + j] > t1) t1 = w[8 + j];
+      }
+      if (t1 <= t0) continue;  // launch never ran
+      c->prof_ms[GPMI_PROF_SYRK] += (double)(t1 - t0) * 1e-5;  // 10 ns ticks -> ms
       c->prof_flops[GPMI_PROF_SYRK] += c->stamp_flops[i];
       c->prof_bytes[GPMI_PROF_SYRK] += c->stamp_bytes[i];
       c->prof_launches[GPMI_PROF_SYRK] += 1;
     }
-    hipLaunchKernelGGL(stamp_init_kernel, dim3(GPMI_STAMP_SLOTS / 256), dim3(256), 0, 0, c->stamp_pool,
+    hipLaunchKernelGGL(stamp_init_kernel, dim3(GPMI_STAMP_SLOTS / 256), dim3(256), 0, s0, c->stamp_pool,
                        GPMI_STAMP_SLOTS);
-    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipStreamSynchronize(s0));
     c->stamp_flops.clear();
     c->stamp_bytes.clear();
   }

@@ -34,7 +34,7 @@ struct GemmArgs {
   // 1 (TILES_LOWER): contraction starts at k = ti * BM (operands are zero before it);
   // 2: contraction ends at k = (tj + 1) * BN (B is lower triangular: B[j][k] = 0 for k > j)
   int kskip;
-  // optional {min start, max end} wall-clock stamps of this launch (s_memrealtime, 100 MHz): per-launch
+  // optional wall-clock stamps of this launch (s_memrealtime, 100 MHz; 16 words, see the kernel): per-launch
   // durations for the roofline without HIP events in the stream (event records between the look-ahead
   // streams slowed the factorisation 2x)
   unsigned long long* stamp;
@@ -103,7 +103,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   tile_of<TILES>(g.kskip ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x), g.ntr, g.ntc, ti, tj);
 
   const int tid = threadIdx.x;
-  if (g.stamp && tid == 0) atomicMin(g.stamp, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  // per-launch timing without atomics (16 words per launch): the first eight workgroups store their start
+  // time in words 0..7, every workgroup stores its end time in word 8 + XCC id.  Workgroups of one XCD share
+  // an L2, so the word keeps the value of whoever finished last there; the host takes min / max.  (Device-scope
+  // atomicMin / atomicMax on one address from ~8000 workgroups cost 1 ms per step, and an atomic issued
+  // at the start sat in front of the first operand loads in the wave's in-order memory queue.)
+  if (g.stamp && tid == 0 && blockIdx.x < 8 && blockIdx.z == 0)
+    g.stamp[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int kbeg = (g.kskip == 1) ? ti * BM : 0;
@@ -208,6 +214,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     __syncthreads();
   }
 
+  // End stamp (only the workgroups that can be the launch's last: dispatch is in order and tiles are uniform,
+  // so the last one to finish is among the last two rounds of 512).  s_memrealtime takes ~1.5 us to return:
+  // it is requested before the epilogue so that the stores hide it, which dates the stamp at the end of the
+  // MFMA loop; the launch's duration is under-stated by the epilogue of one tile (~2 us, 0.25 % at 800 us).
+  const bool stamp_end = g.stamp && tid == 0 && blockIdx.x + 1024 >= gridDim.x;
+  unsigned long long t_end = 0;
+  if (stamp_end) t_end = __builtin_amdgcn_s_memrealtime();
+
   // epilogue: stores only; each instruction covers 4 rows x 128 contiguous bytes
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -215,10 +229,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Cg[(int64_t)(i * 16 + fk + 4 * r) * g.ldc + j * 16 + fr] = acc[i][j][r];
-  if (g.stamp && tid == 0) {
-    __builtin_amdgcn_s_waitcnt(0);  // stores issued; the stamp marks the end of this workgroup's work
-    atomicMax(g.stamp + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-  }
+  if (stamp_end) g.stamp[8 + (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 7)] = t_end;
 }
 
 }  // namespace

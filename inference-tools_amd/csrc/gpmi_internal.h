@@ -113,7 +113,8 @@ struct gpmi_ctx {
 
 // instrumentation helpers (api.hip)
 constexpr int GPMI_STAMP_SLOTS = 16384;
-// next {start, end} stamp slot for a trailing-update launch, or nullptr when that class is not profiled
+constexpr int GPMI_STAMP_WORDS = 16;  // per launch: 8 start words + 8 end words (one per XCD), see gemm_f64.hip
+// next stamp slot (GPMI_STAMP_WORDS words) for a trailing-update launch, or nullptr when that class is not profiled
 unsigned long long* prof_stamp_slot(gpmi_ctx* c, double flops, double bytes);
 struct ProfScope {
   gpmi_ctx* c;

@@ -48,52 +48,113 @@ __device__ inline int prow(int r) {
   return 16 * (8 * ib * (ib + 1) + ib) + (r & 15) * ((ib + 1) * 16 + 1);
 }
 
+// value of lane C of the lane's own 16-lane row (DPP row_newbcast: VALU only, no LDS round trip)
+template <int C>
+__device__ inline double row_bcast(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x150 + C, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x150 + C, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// State of the 16 x 16 elimination: lane (g = lane >> 4, k = lane & 15) holds column k of the rows
+// i = 4 j + g (j = 0..3) of the block (a) and of the accumulated row operations (e).
+struct Elim16 {
+  double a[4], e[4];
+  double p, ip;        // current pivot and its reciprocal (wave-uniform)
+  double arow, erow;   // pivot row elements of this lane's column
+  double myp;          // lane (., k): pivot k
+  int badcol;
+  int k, g;
+};
+
+// Elimination step C: row_i -= (A[i][C] / p_C) row_C for the rows i > C.  Three things keep the dependency
+// chain of a step down to one LDS round trip:
+//  * the multiplier A[i][C] of a lane's row comes from lane C of its own 16-lane row through DPP;
+//  * the pivot and its reciprocal are wave-uniform scalars kept one step ahead: p_{C+1} is formed from three
+//    lane reads at the start of step C exactly as the owning lane forms it, so the Newton chain of the
+//    reciprocal overlaps the row operations;
+//  * row C + 1 is updated first and sent on its way to the other lane groups (ds_bpermute) before the
+//    remaining rows of step C are updated.
+template <int C>
+struct ElimStep {
+  static __device__ inline void run(Elim16& s) {
+    constexpr int jc = C >> 2, gc = C & 3;
+    constexpr int j1 = (C + 1) >> 2, g1 = (C + 1) & 3;  // slot / lane group of row C + 1
+    double pn = 1.0, ipn = 1.0;
+    if (C + 1 < BS) {
+      const double s1 = lane_bcast(s.a[j1 & 3], g1 * 16 + C);             // A[C+1][C]
+      const double s2 = lane_bcast(s.a[j1 & 3], g1 * 16 + ((C + 1) & 15));  // A[C+1][C+1]
+      const double s3 = lane_bcast(s.a[jc], gc * 16 + ((C + 1) & 15));      // A[C][C+1]
+      const double m1 = s1 * s.ip;
+      pn = fma(-m1, s3, s2);
+      if (!(pn > 0.0) || !(pn < 1.79e308)) {  // wave-uniform
+        if (s.badcol < 0) s.badcol = C + 1;
+        pn = 1.0;
+      }
+      ipn = rcp_newton(pn);
+    }
+    if (s.k == C) s.myp = s.p;
+    auto update = [&](int j) {
+      double m = row_bcast<C>(s.a[j]) * s.ip;  // A[i][C] / p_C for this lane's row i = 4 j + g
+      if (j == jc && s.g <= gc) m = 0.0;       // row i <= C: untouched
+      s.a[j] = fma(-m, s.arow, s.a[j]);
+      s.e[j] = fma(-m, s.erow, s.e[j]);
+    };
+    double arow_n = 0.0, erow_n = 0.0;
+    if (C + 1 < BS) {
+      update(j1 & 3);
+      arow_n = __shfl(s.a[j1 & 3], g1 * 16 + s.k, 64);
+      erow_n = __shfl(s.e[j1 & 3], g1 * 16 + s.k, 64);
+    }
+#pragma unroll
+    for (int j = jc; j < 4; ++j)
+      if (!(C + 1 < BS && j == (j1 & 3))) update(j);
+    s.arow = arow_n;
+    s.erow = erow_n;
+    s.p = pn;
+    s.ip = ipn;
+    ElimStep<C + 1>::run(s);
+  }
+};
+template <>
+struct ElimStep<BS> {
+  static __device__ inline void run(Elim16&) {}
+};
+
 // One wave: factor the symmetric 16 x 16 diagonal block `kb` of S (both triangles valid) and
-// invert the factor.  All 64 lanes work: lane (g = lane >> 4, k = lane & 15) holds column k of the
-// rows i = 4 j + g (j = 0..3), so an elimination step costs 4 row updates per lane instead of up to
-// 15 (the 16-lane version spent 8.7 k cycles per block, 42 % of the kernel).  Gaussian elimination
-// without square roots on the critical path: row_i -= (A[i][c] / p_c) row_c; the multiplier
-// A[i][c] comes from lane c of the lane's own 16-lane row (symmetry of the Schur complement), the
-// pivot row from the lane group that owns row c (ds_bpermute), the pivot itself through
-// v_readlane.  The same row operations applied to the identity give M^-1 (A = M D M^T); then
+// invert the factor.  Gaussian elimination without square roots on the critical path (ElimStep); the
+// same row operations applied to the identity give M^-1 (A = M D M^T); then
 // L[k][i] = U[i][k] / sqrt(p_i) and W = L^-1 = D^-1/2 M^-1 (to LDS for the panel phase and to the
 // diagonal block of invD in global memory); L itself also goes straight to the matrix in global memory.
 __device__ inline void factor16(double* S, double* Wl, double* __restrict__ invD, double* __restrict__ A,
                                 int64_t ld, int kb, int* info, int col0, int lane) {
   const int k = lane & 15, g = lane >> 4;
   const int base = kb * BS;
-  double a[4], e[4];
+  Elim16 s;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int i = 4 * j + g;
-    a[j] = S[prow(base + i) + base + k];
-    e[j] = (i == k) ? 1.0 : 0.0;
+    s.a[j] = S[prow(base + i) + base + k];
+    s.e[j] = (i == k) ? 1.0 : 0.0;
   }
-  double myp = 1.0;
-  int badcol = -1;
-#pragma unroll
-  for (int c = 0; c < BS; ++c) {
-    const int jc = c >> 2, gc = c & 3;
-    double p = lane_bcast(a[jc], gc * 16 + c);  // A[c][c]
-    if (!(p > 0.0) || !(p < 1.79e308)) {        // wave-uniform
-      if (badcol < 0) badcol = c;
-      p = 1.0;
-    }
-    if (k == c) myp = p;
-    // pivot row elements of this lane's column, from the group that owns row c
-    const double arow = __shfl(a[jc], gc * 16 + k, 64);
-    const double erow = __shfl(e[jc], gc * 16 + k, 64);
-    const double ip = rcp_newton(p);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j < jc) continue;  // rows 4 j + g <= c for every g
-      // A[i][c] for this lane's row i = 4 j + g: lane c of the same 16-lane row
-      double m = __shfl(a[j], (lane & 48) | c, 64) * ip;
-      if (j == jc && g <= gc) m = 0.0;  // row i <= c: untouched
-      a[j] = fma(-m, arow, a[j]);
-      e[j] = fma(-m, erow, e[j]);
-    }
+  s.k = k;
+  s.g = g;
+  s.myp = 1.0;
+  s.badcol = -1;
+  s.p = lane_bcast(s.a[0], 0);  // A[0][0]
+  if (!(s.p > 0.0) || !(s.p < 1.79e308)) {
+    s.badcol = 0;
+    s.p = 1.0;
   }
+  s.ip = rcp_newton(s.p);
+  s.arow = __shfl(s.a[0], k, 64);  // row 0
+  s.erow = __shfl(s.e[0], k, 64);
+  ElimStep<0>::run(s);
+  const double myp = s.myp;
+  const int badcol = s.badcol;
+  const double* a = s.a;
+  const double* e = s.e;
   const double rs = 1.0 / sqrt(myp);  // lane (., k): 1 / sqrt(p_k)
   const int rowk = prow(base + k);
 #pragma unroll
@@ -380,7 +441,7 @@ void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t l
   // trailing tile rows below which the look-ahead stops paying (GPMI_LOOKAHEAD_MIN overrides; 0 disables)
   static const int LOOKAHEAD_MIN = [] {
     const char* e = std::getenv("GPMI_LOOKAHEAD_MIN");
-    const int v = e ? std::atoi(e) : 60;
+    const int v = e ? std::atoi(e) : 44;
     return v > 0 ? v : (1 << 30);
   }();
   bool overlapped = false;

@@ -192,7 +192,10 @@ class GpEngine:
         return ms.value
 
     def profile_enable(self, on=True):
-        self.h.call("gpmi_profile_enable", int(bool(on)))
+        """True / 1: every class (HIP events around the launches: perturbs the overlap); 0: off;
+        `2 << klass` (or an OR of them): only those classes — the trailing-update class PROF_SYRK is timed by
+        in-kernel stamps and costs nothing."""
+        self.h.call("gpmi_profile_enable", 1 if on is True else int(on))
 
     def profile_reset(self):
         self.h.call("gpmi_profile_reset")
