@@ -47,15 +47,19 @@ int lane_streams(gpmi_ctx* c, Lane& L) {
   hipDeviceProp_t prop;
   HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
   const int ncu = prop.multiProcessorCount;
+  c->ncu = ncu;
+  c->ncu_upd = ncu;
   if (ncu >= 64 && ncu % 32 == 0) {
     std::vector<uint32_t> panel((size_t)ncu / 32, 0u), upd((size_t)ncu / 32, 0xffffffffu);
     panel[0] = 0xffffffffu;
-    upd[0] = std::getenv("GPMI_UPD_FULL") ? 0xffffffffu : 0u;  // experiment: let the update stream use every CU
+    upd[0] = 0u;
     if (hipExtStreamCreateWithCUMask(&L.stream2, (uint32_t)panel.size(), panel.data()) != hipSuccess ||
         hipExtStreamCreateWithCUMask(&L.stream_upd, (uint32_t)upd.size(), upd.data()) != hipSuccess) {
       if (L.stream2) (void)hipStreamDestroy(L.stream2);
       L.stream2 = L.stream_upd = nullptr;  // no look-ahead: everything on the full-chip stream
       (void)hipGetLastError();
+    } else {
+      c->ncu_upd = ncu - 32;
     }
   }
   HIPCHK(c, hipEventCreateWithFlags(&L.ev_la, hipEventDisableTiming));

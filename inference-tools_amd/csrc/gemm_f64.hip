@@ -39,6 +39,10 @@ struct GemmArgs {
   // streams slowed the factorisation 2x)
   unsigned long long* stamp;
   int64_t sC, sA, sB;  // batch strides (doubles): problem blockIdx.z works on C + z sC, A + z sA, B + z sB
+  // split > 0 (64 x 64 kernels only): this launch covers the 128 x 128 tiles [tile_base, ..) of the
+  // (ntr / 2) x (ntc / 2) tile grid, four workgroups per tile (the tail of a launch whose other tiles run as
+  // full 128 x 128 tiles, see launch_gemm_nt_split)
+  int split, tile_base;
 };
 
 // B stored k-major: 16 rows of BN + 16 pad (rows 16 doubles apart mod 32)
@@ -100,7 +104,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   int ti, tj;
   // k-skipped launches have tiles of very different length (128 (ntr - ti) k-steps): deal them out
   // round-robin over the XCDs instead of in contiguous chunks, or the XCD holding the long tiles ends last
-  tile_of<TILES>(g.kskip ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x), g.ntr, g.ntc, ti, tj);
+  const int wid = g.kskip ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+  if (g.split) {
+    int bi, bj;
+    tile_of<TILES>(g.tile_base + (wid >> 2), g.ntr >> 1, g.ntc >> 1, bi, bj);
+    ti = 2 * bi + ((wid >> 1) & 1);
+    tj = 2 * bj + (wid & 1);
+  } else {
+    tile_of<TILES>(wid, g.ntr, g.ntc, ti, tj);
+  }
 
   const int tid = threadIdx.x;
   // per-launch timing without atomics (16 words per launch): the first eight workgroups store their start
@@ -234,9 +246,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 
 }  // namespace
 
-void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, int kskip, double* C,
-                 int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb, int ntr,
-                 int ntc, int k, unsigned long long* stamp, const GemmBatch& bt) {
+namespace {
+// part: 0 = the whole product; 1 = only the first `nfull` 128 x 128 tiles (as 128 x 128 tiles); 2 = only the
+// tiles from `nfull` on, as 64 x 64 tiles
+void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, int kskip, double* C,
+                      int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb, int ntr,
+                      int ntc, int k, unsigned long long* stamp, const GemmBatch& bt, int part, int64_t nfull) {
   // ntr, ntc are in units of 128 rows / columns
   if (ntr <= 0 || ntc <= 0 || k <= 0) return;
   if (tiles == TILES_LOWER && ntc > ntr) ntc = ntr;
@@ -246,8 +261,11 @@ void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, int k
   // 64-row tiles for one-tile-column products (in place: a workgroup must own whole rows),
   // 64 x 64 tiles for the remaining short / small launches
   int bm = 128, bn = 128;
-  const bool small = (k <= 128) || (big * bt.count < 384);
-  if (small && kskip != 1) {
+  const bool small = part == 0 && ((k <= 128) || (big * bt.count < 384));
+  if (part == 2) {
+    bm = 64;
+    bn = 64;
+  } else if (small && kskip != 1) {
     if (ntc == 1 && tiles == TILES_RECT && op == OP_ASSIGN) {
       bm = 64;
     } else if (!b_kmajor || op == OP_SUB) {
@@ -256,12 +274,15 @@ void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, int k
     }
   }
   GemmArgs g{C, A, B, ldc, lda, ldb, ntr * (128 / bm), ntc * (128 / bn), k, kskip, stamp,
-             bt.sC, bt.sA, bt.sB};
+             bt.sC, bt.sA, bt.sB, part == 2 ? 1 : 0, part == 2 ? (int)nfull : 0};
   int64_t nwg;
   if (tiles == TILES_RECT)
     nwg = (int64_t)g.ntr * g.ntc;
   else
     nwg = (int64_t)g.ntc * (g.ntc + 1) / 2 + (int64_t)(g.ntr - g.ntc) * g.ntc;
+  if (part == 1) nwg = nfull;
+  if (part == 2) nwg = 4 * (big - nfull);
+  if (nwg <= 0) return;
   dim3 grid((unsigned)nwg, 1, (unsigned)bt.count), block(256);
 #define GPMI_LAUNCH(T, O, B, M, N) \
   hipLaunchKernelGGL((gemm_nt_kernel<T, O, B, M, N>), grid, block, 0, s, g)
@@ -289,6 +310,39 @@ void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, int k
     }
   }
 #undef GPMI_LAUNCH
+}
+}  // namespace
+
+void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, int kskip, double* C,
+                 int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb, int ntr,
+                 int ntc, int k, unsigned long long* stamp, const GemmBatch& bt) {
+  launch_gemm_part(s, tiles, op, b_kmajor, kskip, C, ldc, A, lda, B, ldb, ntr, ntc, k, stamp, bt, 0, 0);
+}
+
+// A launch of T equal tiles on `ncu` CUs runs in ceil(T / ncu) rounds of one tile time (the two workgroups
+// of a CU share its MFMA pipes, so a CU with one tile left is as slow as a CU with two): a last round that
+// is nearly empty wastes up to 70 us x ncu CUs.  When that round would be less than ~55 % full its tiles run
+// as 64 x 64 tiles instead (four times as many workgroups, spread over all CUs), in a second launch.
+int64_t gemm_split_point(int64_t T, int ncu, int k) {
+  if (k <= 128 || T < 384 || ncu <= 0) return T;  // these launches use the small tiles throughout
+  const int64_t rem = T % ncu;
+  if (rem == 0 || rem * 100 > (int64_t)ncu * 55) return T;
+  return T - rem;
+}
+
+void launch_gemm_nt_split(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc, const double* A,
+                          int64_t lda, const double* B, int64_t ldb, int ntr, int ntc, int k, int64_t nfull,
+                          unsigned long long* stamp) {
+  if (tiles == TILES_LOWER && ntc > ntr) ntc = ntr;
+  const int64_t T = (tiles == TILES_RECT) ? (int64_t)ntr * ntc
+                                          : (int64_t)ntc * (ntc + 1) / 2 + (int64_t)(ntr - ntc) * ntc;
+  const GemmBatch one{};
+  if (nfull >= T) {
+    launch_gemm_part(s, tiles, op, false, 0, C, ldc, A, lda, B, ldb, ntr, ntc, k, stamp, one, 0, 0);
+    return;
+  }
+  launch_gemm_part(s, tiles, op, false, 0, C, ldc, A, lda, B, ldb, ntr, ntc, k, stamp, one, 1, nfull);
+  launch_gemm_part(s, tiles, op, false, 0, C, ldc, A, lda, B, ldb, ntr, ntc, k, nullptr, one, 2, nfull);
 }
 
 void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc,

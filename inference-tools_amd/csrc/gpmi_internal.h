@@ -57,6 +57,8 @@ struct Lane {
 
 struct gpmi_ctx {
   int device = 0;
+  int ncu = 256;      // compute units of the device
+  int ncu_upd = 224;  // ... of the CU-masked trailing-update stream (look-ahead regime)
   std::string err;
   // data
   int64_t n = 0, d = 0, np = 0, ld = 0;
@@ -166,6 +168,14 @@ enum GemmOp { OP_SUB = 0, OP_ASSIGN = 1 };
 void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc,
                     const double* A, int64_t lda, const double* B, int64_t ldb, int ntr, int ntc,
                     int k, unsigned long long* stamp = nullptr, const GemmBatch& bt = GemmBatch());
+
+// balanced form of launch_gemm_nt for big launches (gemm_f64.hip): the first `nfull` = gemm_split_point(T, ncu, k)
+// tiles run as 128 x 128 tiles, the tiles of the nearly empty last round as 64 x 64 tiles in a second launch;
+// `stamp` times the first launch only
+int64_t gemm_split_point(int64_t T, int ncu, int k);
+void launch_gemm_nt_split(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc, const double* A,
+                          int64_t lda, const double* B, int64_t ldb, int ntr, int ntc, int k, int64_t nfull,
+                          unsigned long long* stamp = nullptr);
 
 // general form: b_kmajor -> B is (k x cols) row-major; kskip = 1 (TILES_LOWER) -> contraction starts at
 // the tile row's first column, kskip = 2 -> it ends with the tile column (B lower triangular)

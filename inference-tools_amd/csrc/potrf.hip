@@ -407,21 +407,23 @@ void factor_panel(gpmi_ctx* c, hipStream_t sp, double* A, int64_t ld, double* in
 // trailing update of tile columns [c0, c1) (relative to the trailing matrix, rows c0 .. rem):
 // A22 -= P P^T with P = A[Je.., J..Je), K = (Je - J) * 128, lower tiles only
 void trailing_update(gpmi_ctx* c, hipStream_t s, double* A, int64_t ld, int nt, int J, int Je, int c0,
-                     int c1) {
+                     int c1, int ncu) {
   const int rem = nt - Je;
   const int kw = (Je - J) * NB;
   const int rows = rem - c0, cols = c1 - c0;
   if (rows <= 0 || cols <= 0) return;
   double* P = A + (int64_t)(Je + c0) * NB * ld + (int64_t)J * NB;
   double* C = A + (int64_t)(Je + c0) * NB * ld + (int64_t)(Je + c0) * NB;
-  const double tiles = cols * (cols + 1) / 2.0 + (double)(rows - cols) * cols;
+  const int64_t tiles = (int64_t)cols * (cols + 1) / 2 + (int64_t)(rows - cols) * cols;
+  // the tiles of a nearly empty last round (of `ncu` tiles) run as 64 x 64 tiles in a second launch
+  const int64_t nfull = gemm_split_point(tiles, ncu, kw);
   // per-launch timing (bench roofline) of the 128 x 128-tile kernel only: launches with fewer than
   // 384 tiles run the 64 x 64 variant (launch_gemm) and are a different kernel in rocprof's tables
   unsigned long long* stamp =
-      tiles >= 384.0 ? prof_stamp_slot(c, tiles * 2.0 * NB * NB * kw,
-                                       tiles * 16.0 * NB * NB + 8.0 * rows * NB * kw)
-                     : nullptr;
-  launch_gemm_nt(s, TILES_LOWER, OP_SUB, C, ld, P, ld, P, ld, rows, cols, kw, stamp);
+      tiles >= 384 ? prof_stamp_slot(c, (double)nfull * 2.0 * NB * NB * kw,
+                                     (double)nfull * 16.0 * NB * NB + 8.0 * rows * NB * kw)
+                   : nullptr;
+  launch_gemm_nt_split(s, TILES_LOWER, OP_SUB, C, ld, P, ld, P, ld, rows, cols, kw, nfull, stamp);
 }
 
 }  // namespace
@@ -468,13 +470,13 @@ void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t l
       (void)hipEventRecord(lane.ev_panel, sp);
       (void)hipStreamWaitEvent(su, lane.ev_panel, 0);
       const int la = rem < OBT ? rem : OBT;
-      trailing_update(c, su, A, ld, nt, J, Je, 0, la);  // columns of the next panel first
+      trailing_update(c, su, A, ld, nt, J, Je, 0, la, c->ncu_upd);  // columns of the next panel first
       (void)hipEventRecord(lane.ev_la, su);
       (void)hipStreamWaitEvent(sp, lane.ev_la, 0);
-      trailing_update(c, su, A, ld, nt, J, Je, la, rem);
+      trailing_update(c, su, A, ld, nt, J, Je, la, rem, c->ncu_upd);
     } else {
       factor_panel(c, sf, A, ld, invD, info, nt, J, Je);
-      trailing_update(c, sf, A, ld, nt, J, Je, 0, rem);
+      trailing_update(c, sf, A, ld, nt, J, Je, 0, rem, c->ncu);
     }
   }
   if (overlapped) {

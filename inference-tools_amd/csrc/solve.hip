@@ -550,8 +550,9 @@ void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, 
                 GPMI_OB, mt, w, w * NB);
     const int rest = nt - Je;
     if (rest > 0)  // Q[:, Je:] -= X * L[Je:, J:Je]^T
-      launch_gemm_nt(s, TILES_RECT, OP_SUB, Q + (int64_t)Je * NB, ld, X, ldx,
-                     L + (int64_t)Je * NB * ld + (int64_t)J * NB, ld, mt, rest, w * NB);
+      launch_gemm_nt_split(s, TILES_RECT, OP_SUB, Q + (int64_t)Je * NB, ld, X, ldx,
+                           L + (int64_t)Je * NB * ld + (int64_t)J * NB, ld, mt, rest, w * NB,
+                           gemm_split_point((int64_t)mt * rest, c->ncu, w * NB));
     if (!Qout) {
       const int64_t rows = (int64_t)mt * NB;
       hipLaunchKernelGGL(copy_panel_kernel, dim3((unsigned)(w * NB / 2 / 64), (unsigned)rows), dim3(64), 0, s, panel,
