@@ -66,19 +66,20 @@ def cpu_baseline(n_cpu, d, m_cpu):
         "unit": "GFLOP/s",
         "cores": int(threads),
         "kind": "port",
-        "sample": f"oracle fit+predict SE N={n_cpu} d={d} M={m_cpu}, 1 run, {dt:.1f} s wall "
-        f"(NumPy/SciPy + BLAS threads={threads}); K-build included as in the reference",
+        "sample": f"oracle fit+predict SE N={n_cpu} d={d} M={m_cpu} (same generator and theta as the workload), 1 run, "
+        f"{dt:.1f} s wall (NumPy {np.__version__} / SciPy + BLAS threads={threads}); K-build included as in the reference",
     }
 
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
-    (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    (profiles/r01_pmc.json, written by tools/pmc_bench.sh + tools/make_profiles.py: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced
+    reads on gfx950); None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
     try:
         with open(path) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
+            return json.load(f)["kernels"]["update128"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -195,8 +196,8 @@ def main():
                 "parallelism": f"{world} independent hyper-parameter evaluations (one per GPU), result all-gather: {gather}",
             },
             "roofline": {
-                "kernel": "gemm_nt_kernel<1, 0, 0, 128, 128> = <TILES_LOWER, OP_SUB, NT, 128x128> (potrf trailing SYRK update, K=512)",
-                "timing": "in-kernel s_memrealtime stamps (min start / max end over the workgroups of each launch)",
+                "kernel": "gemm_nt_kernel<1, 0, 0, 128, 128> = <TILES_LOWER, OP_SUB, NT, 128x128> (potrf trailing SYRK update, K=512; the full rounds of every launch with >= 384 tiles)",
+                "timing": "in-kernel s_memrealtime stamps (first workgroups' start / last workgroup's end of each launch)",
                 "cu_mask": "launches of the look-ahead regime run on 224 of 256 CUs (the other 32 factor the next panel)",
                 "bound": "mfma",
                 "achieved": ach,
@@ -210,7 +211,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(4096, d, 256)
+            line["cpu_baseline"] = cpu_baseline(6144, d, 384)  # ~10-20 s of host work
         print(json.dumps(line), flush=True)
 
     if rdv is not None:
