@@ -997,6 +997,16 @@ int gpmi_timer_stop(gpmi_ctx* c, float* ms) {
   return GPMI_OK;
 }
 
+static int dev_stream(gpmi_ctx* c, hipStream_t* s) {
+  if (c->lanes.empty()) {
+    // a bare handle (no data yet): give it a stream-only lane
+    c->lanes.emplace_back();
+    if (int rc = lane_streams(c, c->lanes[0])) return rc;
+  }
+  *s = c->lanes[0].stream;
+  return GPMI_OK;
+}
+
 int gpmi_profile_enable(gpmi_ctx* c, int on) {
   if (!c) return GPMI_ERR_ARG;
   c->prof_mask = (on == 1) ? 0xF : (unsigned)on >> 1;
@@ -1005,7 +1015,8 @@ int gpmi_profile_enable(gpmi_ctx* c, int on) {
     HIPCHK(c, hipMalloc(&c->stamp_pool, sizeof(unsigned long long) * GPMI_STAMP_WORDS * GPMI_STAMP_SLOTS));
     // on the library's own stream: a kernel launched on the NULL stream left every later launch of the process
     // with a ~10 us dispatch gap to its predecessor (1.2 ms per fit at N = 16384)
-    hipStream_t s0 = c->lanes[0].stream;
+    hipStream_t s0;
+    if (int rc = dev_stream(c, &s0)) return rc;
     hipLaunchKernelGGL(stamp_init_kernel, dim3(GPMI_STAMP_SLOTS / 256), dim3(256), 0, s0, c->stamp_pool,
                        GPMI_STAMP_SLOTS);
     HIPCHK(c, hipStreamSynchronize(s0));
@@ -1029,7 +1040,8 @@ static int profile_collect(gpmi_ctx* c) {
   const size_t ns = c->stamp_flops.size();
   if (ns && c->stamp_pool) {
     std::vector<unsigned long long> h((size_t)GPMI_STAMP_WORDS * ns);
-    hipStream_t s0 = c->lanes[0].stream;
+    hipStream_t s0;
+    if (int rc = dev_stream(c, &s0)) return rc;
     HIPCHK(c, hipMemcpyAsync(h.data(), c->stamp_pool, sizeof(unsigned long long) * GPMI_STAMP_WORDS * ns,
                              hipMemcpyDeviceToHost, s0));
     HIPCHK(c, hipStreamSynchronize(s0));
@@ -1102,16 +1114,6 @@ int gpmi_dev_download(gpmi_ctx* c, void* dst, const void* src, int64_t bytes) {
   if (int rc = set_device(c)) return rc;
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
-  return GPMI_OK;
-}
-
-static int dev_stream(gpmi_ctx* c, hipStream_t* s) {
-  if (c->lanes.empty()) {
-    // a bare handle (no data yet): give it a stream-only lane
-    c->lanes.emplace_back();
-    if (int rc = lane_streams(c, c->lanes[0])) return rc;
-  }
-  *s = c->lanes[0].stream;
   return GPMI_OK;
 }
 
