@@ -486,3 +486,57 @@ def test_rccl_gather_single_rank(gp_mod):
     assert out.shape == (1, 3) and np.array_equal(out[0], [1.5, -2.0, 3.25])
     vals = sharding.sharded_map(lambda th: gp.marginal_likelihood_batch(th), wl.theta_set(wl.SE, y, 2, 5), engine=eng)
     assert vals.shape == (5, 1)
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE.json's full sizes: the oracle needs minutes there, so the checks are identities
+# that hold at any size, with every right-hand side formed on the host from the oracle's kernels
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,n,d,kid", [(2, 16384, 8, wl.SE), (3, 16384, 16, wl.RQ)])
+def test_full_size_identities(gp_mod, cfg, n, d, kid):
+    """Headline workload (SE, N = 16384, d = 8) and config 3 (RQ, N = 16384, d = 16):
+    (i) K alpha = y - mu with K rebuilt row-chunk by row-chunk by the oracle's kernel functions;
+    (ii) LML = -1/2 (y - mu).alpha - sum ln L_ii with the diagonal of the downloaded factor;
+    (iii) 64 rows of L L^T against the oracle's K;
+    (iv) the predictive mean at training inputs: mu*(x_i) = y_i - D_ii alpha_i, D = y_err^2 + 1e-12 a^2;
+    (v) the predictive variance there: var*(x_i) = D_ii - D_ii^2 (K^-1)_ii, with (K^-1)_ii from the
+        leave-one-out path (a different chain of kernels: L^-T by TRSM on the identity + row norms)."""
+    from oracle import gp_oracle as orc
+
+    x, y, e = wl.synthetic_dataset(cfg, n, d)
+    th = wl.timing_theta(kid, y, d)
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=th, kernel=kernel_cls(gp_mod, kid))
+    alpha = gp.alpha.copy()
+    r = y - th[0]
+    a2 = np.exp(2.0 * th[1])
+    D = e**2 + 1e-12 * a2
+
+    # (i) + (iii): rows of K from the oracle, 512 at a time (cross-covariance carries no jitter / noise)
+    rows_checked = np.sort(np.random.default_rng(5).choice(n, 64, replace=False))
+    Krows = np.empty((64, n))
+    Ka = np.empty(n)
+    for lo in range(0, n, 512):
+        hi = min(lo + 512, n)
+        blk = orc.kernel_cross(kid, x[lo:hi], x, th[1:])
+        blk[np.arange(hi - lo), np.arange(lo, hi)] += D[lo:hi]
+        Ka[lo:hi] = (blk * alpha[None, :]).sum(axis=1)
+        sel = (rows_checked >= lo) & (rows_checked < hi)
+        Krows[sel] = blk[rows_checked[sel] - lo]
+    check(Ka, r, 1e-10, "K alpha = y - mu")
+
+    L = gp.L
+    logdet = float(np.log(np.diagonal(L)).sum())
+    lml = gp.marginal_likelihood(th)
+    assert abs(lml - (-0.5 * float((r * alpha).sum()) - logdet)) <= 1e-10 * abs(lml)
+    LLt = np.einsum("rk,nk->rn", L[rows_checked], L)  # rows of L L^T (L is lower triangular)
+    check(LLt, Krows, 1e-10, "L L^T = K")
+    del L, LLt
+
+    idx = np.random.default_rng(6).choice(n, 256, replace=False)
+    mu, sig = gp(x[idx])
+    check(mu, y[idx] - D[idx] * alpha[idx], 1e-10, "mean at training inputs")
+    _, loo_sig = gp.loo_predictions()  # sigma_loo^2 = 1 / (K^-1)_ii   (regression.py:466)
+    ik = 1.0 / loo_sig[idx] ** 2
+    var_expected = D[idx] - D[idx] ** 2 * ik
+    # var* is a difference of O(a^2) numbers: 1e-10 relative to a^2, the scale the kernels work at
+    assert np.abs(sig**2 - var_expected).max() <= 1e-10 * a2
