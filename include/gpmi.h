@@ -170,6 +170,31 @@ int gpmi_loo_terms(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_th
                    double extra_diag, const double* mu_host, double* alpha_host,
                    double* ikdiag_host, int* info);
 
+/* ---- Gaussian-process linear inversion (inference/gp/inversion.py) --------------------
+ * The model parameters (n of them, at the positions given to gpmi_set_data as x; y / noise of that call are
+ * unused) have the GP prior N(mu, K(theta)); the data y (m values, independent errors y_err) are
+ * A mu_true + noise with the m x n model matrix A (row-major).  All entry points work on
+ * J = A K A^T + diag(y_err^2) = L L^T (inversion.py:189, 198) with the same kernels as the regression path. */
+int gpmi_linv_set(gpmi_ctx* ctx, const double* A_host, int64_t m, const double* y_host,
+                  const double* y_err_host);
+/* Replaces GpLinearInverter.marginal_likelihood (inversion.py:177-191): -1/2 |L^-1 (y - A mu)|^2 - sum ln L_ii */
+int gpmi_linv_lml(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_theta, double extra_diag,
+                  const double* mu_host, double* lml, int* info);
+/* Replaces GpLinearInverter.marginal_likelihood_gradient (inversion.py:193-217).  grad_theta: the n_theta
+ * covariance-parameter gradients 1/2 sum (alpha alpha^T - J^-1) o (A dK_j A^T), evaluated as
+ * 1/2 sum (w w^T - A^T J^-1 A) o dK_j with w = A^T alpha; trace_q = sum_a (w_a^2 - (A^T J^-1 A)_aa) for an
+ * additive WhiteNoise term; at_alpha (n values) = w, from which the host forms the mean-parameter gradients
+ * sum_i alpha_i (A dmu_j)_i = w . dmu_j. */
+int gpmi_linv_lml_grad(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_theta, double extra_diag,
+                       const double* mu_host, double* lml, double* grad_theta, double* trace_q,
+                       double* at_alpha_host, int* info);
+/* Replaces GpLinearInverter.calculate_posterior / calculate_posterior_mean (inversion.py:138-175):
+ * mean = mu + K A^T J^-1 (y - A mu), cov = K - K A^T J^-1 A K (the Woodbury form of the reference's
+ * solve(I + K A^T Sigma^-1 A, K)); cov_host may be NULL. */
+int gpmi_linv_posterior(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_theta,
+                        double extra_diag, const double* mu_host, double* mean_host, double* cov_host,
+                        int* info);
+
 /* ---- multi-GPU result gather (RCCL over xGMI) ----------------------------------------
  * Replaces the result return of multiprocessing.Pool.map (regression.py:600-601) and the
  * (theta, log-prob) messages of the tempering processes (mcmc/parallel.py:195-201).  One process per

@@ -55,6 +55,29 @@ struct Lane {
   int* h_info = nullptr;    // pinned host mirror of info
 };
 
+// device state of the linear-inversion entry points (gpmi_linv_*): m data values, model matrix A (m x n)
+struct LinvState {
+  int64_t m = 0, mp = 0, ldm = 0;
+  double* A = nullptr;     // mp x ld   model matrix, zero padded
+  double* At = nullptr;    // np x ldm  its transpose
+  double* y = nullptr;     // mp
+  double* sig2 = nullptr;  // mp        y_err^2, 1 in the padding (keeps the padded J positive definite)
+  double* zero = nullptr;  // np        zeros (the prior covariance carries no data noise)
+  double* K = nullptr;     // np x ld   prior covariance (later A^T J^-1 A, K - X X^T)
+  double* T = nullptr;     // mp x ld   A K (later J^-1 A)
+  double* J = nullptr;     // mp x ldm  A K A^T + Sigma, then its factor L
+  double* J2 = nullptr;    // mp x ldm  L^-T, then J^-1          (gradient only)
+  double* Q = nullptr;     // np x ldm  K A^T                    (posterior only)
+  double* X = nullptr;     // np x ldm  K A^T L^-T               (posterior only)
+  double* invD = nullptr;  // 128-wide inverse diagonal blocks of L
+  double* inv2 = nullptr;  // 512-wide
+  double* inv2_t = nullptr;
+  double* panel = nullptr; // mp x 544 (in-place many-right-hand-side solve)
+  double* vec = nullptr;   // 8 x max(mp, np) work vectors
+  double* gws = nullptr;
+  int64_t gws_doubles = 0;
+};
+
 struct gpmi_ctx {
   int device = 0;
   int ncu = 256;      // compute units of the device
@@ -93,6 +116,7 @@ struct gpmi_ctx {
   KParams* bParams = nullptr;
   double* h_bRed = nullptr;
   int* h_bInfo = nullptr;
+  LinvState linv;
   // RCCL result gather (comm.hip)
   void* comm = nullptr;
   int comm_rank = 0, comm_world = 1;

@@ -211,3 +211,42 @@ class GpEngine:
 
     def close(self):
         self.h.close()
+
+
+class LinvEngine:
+    """Device side of `GpLinearInverter` (gpmi_linv_*): parameter positions, model matrix and data are
+    uploaded once; every call evaluates one hyper-parameter vector."""
+
+    def __init__(self, positions, model_matrix, y, y_err, device=None):
+        self.h = _lib.Handle(device)
+        self.x = as_f64(positions)
+        self.n, self.d = self.x.shape
+        self.A = as_f64(model_matrix)
+        self.m = self.A.shape[0]
+        zeros = np.zeros(self.n)
+        self.h.call("gpmi_set_data", dptr(self.x), dptr(zeros), None, None, self.n, self.d)
+        self.h.call("gpmi_linv_set", dptr(self.A), self.m, dptr(as_f64(y)), dptr(as_f64(y_err)))
+
+    def lml(self, kernel, theta_cov, extra_diag, mu):
+        theta, mu = as_f64(theta_cov), as_f64(mu)
+        out, info = C.c_double(0.0), C.c_int(0)
+        self.h.call("gpmi_linv_lml", kernel, dptr(theta), theta.size, float(extra_diag), dptr(mu),
+                    C.byref(out), C.byref(info))
+        return out.value, info.value
+
+    def lml_grad(self, kernel, theta_cov, extra_diag, mu):
+        theta, mu = as_f64(theta_cov), as_f64(mu)
+        lml, trq, info = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
+        grad, w = np.empty(theta.size), np.empty(self.n)
+        self.h.call("gpmi_linv_lml_grad", kernel, dptr(theta), theta.size, float(extra_diag), dptr(mu),
+                    C.byref(lml), dptr(grad), C.byref(trq), dptr(w), C.byref(info))
+        return lml.value, grad, trq.value, w, info.value
+
+    def posterior(self, kernel, theta_cov, extra_diag, mu, with_cov=True):
+        theta, mu = as_f64(theta_cov), as_f64(mu)
+        info = C.c_int(0)
+        mean = np.empty(self.n)
+        cov = np.empty((self.n, self.n)) if with_cov else None
+        self.h.call("gpmi_linv_posterior", kernel, dptr(theta), theta.size, float(extra_diag), dptr(mu),
+                    dptr(mean), dptr(cov), C.byref(info))
+        return mean, cov, info.value

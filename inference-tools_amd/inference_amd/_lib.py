@@ -57,6 +57,10 @@ SIGNATURES = {
     "gpmi_loo_diag": (C.c_int, [_vp, _dp]),
     "gpmi_loo_terms": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _ip]),
     "gpmi_loo_grad": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_linv_set": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
+    "gpmi_linv_lml": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _ip]),
+    "gpmi_linv_lml_grad": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_linv_posterior": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _ip]),
     "gpmi_comm_unique_id": (C.c_int, [C.c_char_p]),
     "gpmi_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p]),
     "gpmi_comm_allgather": (C.c_int, [_vp, _dp, _dp, _i64]),

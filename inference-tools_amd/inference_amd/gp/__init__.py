@@ -5,6 +5,7 @@ from inference_amd.gp.mean import ConstantMean, LinearMean, QuadraticMean
 from inference_amd.gp.acquisition import ExpectedImprovement, MaxVariance, UpperConfidenceBound
 from inference_amd.gp.regression import GpRegressor
 from inference_amd.gp.optimisation import GpOptimiser
+from inference_amd.gp.inversion import GpLinearInverter
 
 __all__ = sorted(
     name for name, obj in list(globals().items()) if isinstance(obj, type) and not name.startswith("_")

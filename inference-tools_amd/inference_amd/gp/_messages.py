@@ -8,6 +8,12 @@ def framed(owner: str, kind: str, *lines: str) -> str:
     return f"\n\n[ {owner} {kind} ]{body}\n"
 
 
+def framed_plain(owner: str, *lines: str) -> str:
+    """The un-indented frame of inversion.py's messages."""
+    body = "".join(f"\n>> {line}" for line in lines)
+    return f"\n\n[ {owner} error ]{body}\n"
+
+
 def y_not_1d(shape):
     return framed("GpRegressor", "error", f"'y' argument must be a 1D array, but instead has shape {shape}")
 

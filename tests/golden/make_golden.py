@@ -18,6 +18,7 @@ Cases
   cfg4       BASELINE config 4: SE, N=4096, d=4, 1000 EI candidates
   cfg2       BASELINE config 2: SE, N=8192, d=8 (needs ~16 GB RSS, several minutes)
   fail       a theta for which numpy.linalg.cholesky raises (pins the -1e50 path)
+  linv       GpLinearInverter: 1-D deconvolution (32 x 64) and 2-D tomography (300 x 400), SE / RQ / SE+WhiteNoise
 """
 import os
 import sys
@@ -307,7 +308,38 @@ def case_pt():
     return out
 
 
+def case_linv():
+    """GpLinearInverter (inversion.py): LML, LML gradient, posterior mean / covariance."""
+    from inference.gp import GpLinearInverter
+
+    out = {}
+    for prob in ("deconv", "tomo"):
+        pos, A, y, y_err = wl.linv_problem(prob)
+        for tag, kid, wn in (("se", wl.SE, False), ("rq", wl.RQ, False), ("sewn", wl.SE, True)):
+            cov = kernel_cls(kid)()
+            if wn:
+                cov = cov + WhiteNoise()
+            gli = GpLinearInverter(y=y, y_err=y_err, model_matrix=A, parameter_spatial_positions=pos,
+                                   prior_covariance_function=cov)
+            out[f"{prob}_{tag}_labels"] = np.array(gli.hyperpar_labels)
+            for i, th in enumerate(wl.linv_thetas(prob, kid, wn)):
+                key = f"{prob}_{tag}_{i}"
+                out[key + "_theta"] = th
+                out[key + "_lml"] = np.array(gli.marginal_likelihood(th))
+                l2, g = gli.marginal_likelihood_gradient(th)
+                out[key + "_lml2"] = np.array(l2)
+                out[key + "_grad"] = g
+                pm, pc = gli.calculate_posterior(th)
+                out[key + "_pmean"] = pm
+                out[key + "_pmean_only"] = gli.calculate_posterior_mean(th)
+                out[key + "_pcov"] = pc if prob == "deconv" else pc[IDX_TOMO][:, IDX_TOMO]
+    return out
+
+
+IDX_TOMO = np.arange(0, 400, 7)  # 58 rows / columns of the 400 x 400 posterior covariance
+
 CASES = {
+    "linv": case_linv,
     "pt": case_pt,
     "t32": case_t32,
     "cfg1": case_cfg1,

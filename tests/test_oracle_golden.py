@@ -153,3 +153,31 @@ def test_cholesky_failure_sentinel(golden):
     gp = orc.OracleGp(g["x"], g["y"], y_cov=g["y_cov"], kernel=orc.SE)
     assert gp.marginal_likelihood(g["theta_bad"]) == -1e50 == float(g["lml_bad"])
     close(gp.marginal_likelihood(g["theta_ok"]), g["lml_ok"])
+
+
+# ---------------------------------------------------------------------------------------
+# GpLinearInverter (inversion.py): the oracle restatement against the reference's outputs
+# ---------------------------------------------------------------------------------------
+LINV_CASES = [(prob, tag, kid, wn) for prob in ("deconv", "tomo")
+              for tag, kid, wn in (("se", orc.SE, False), ("rq", orc.RQ, False), ("sewn", orc.SE, True))]
+
+
+@pytest.mark.parametrize("prob,tag,kid,wn", LINV_CASES)
+def test_linear_inverter_oracle_matches_reference(golden, prob, tag, kid, wn):
+    from oracle.linv_oracle import OracleLinearInverter
+
+    g = golden("linv")
+    pos, A, y, y_err = wl.linv_problem(prob)
+    inv = OracleLinearInverter(y, y_err, A, pos, kid, white_noise=wn)
+    idx = np.arange(0, 400, 7)
+    for i, th in enumerate(wl.linv_thetas(prob, kid, wn)):
+        key = f"{prob}_{tag}_{i}"
+        assert np.array_equal(th, g[key + "_theta"])
+        close(inv.marginal_likelihood(th), g[key + "_lml"], rtol=1e-11)
+        lml, grad = inv.marginal_likelihood_gradient(th)
+        close(lml, g[key + "_lml2"], rtol=1e-11)
+        close(grad, g[key + "_grad"], rtol=1e-9)
+        pm, pc = inv.calculate_posterior(th)
+        close(pm, g[key + "_pmean"], rtol=1e-9)
+        close(inv.calculate_posterior_mean(th), g[key + "_pmean_only"], rtol=1e-9)
+        close(pc if prob == "deconv" else pc[idx][:, idx], g[key + "_pcov"], rtol=1e-9)

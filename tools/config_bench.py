@@ -56,3 +56,33 @@ if "cfg5" in which:
         dt, _ = t(lambda: gp.marginal_likelihood_batch(thetas), reps=2)
         print(f"cfg5 SE N=2048 d=4: 512 LML evaluations on {S:2d} streams: {dt*1e3:.1f} ms = {512/dt:.0f} evals/s "
               f"({512*2048**3/3/dt/1e12:.2f} TFLOP/s)")
+if "linv" in which:
+    # GpLinearInverter: m data values, n model parameters on a 2-D grid (synthetic smooth chords)
+    from inference_amd.gp import GpLinearInverter
+    m, g = 4096, 90
+    n = g * g
+    ax = (np.arange(g) + 0.5) / g
+    X, Y = np.meshgrid(ax, ax, indexing="ij")
+    pos = np.stack([X.ravel(), Y.ravel()], axis=1)
+    rng = np.random.default_rng(7)
+    ang, off = rng.uniform(0, np.pi, m), rng.uniform(-0.35, 0.35, m)
+    dist = (pos[None, :, 0] - 0.5) * np.cos(ang)[:, None] + (pos[None, :, 1] - 0.5) * np.sin(ang)[:, None] - off[:, None]
+    A = np.exp(-0.5 * (dist / 0.02) ** 2); A /= A.sum(axis=1, keepdims=True)
+    truth = np.exp(-((pos[:, 0] - 0.4) ** 2 + (pos[:, 1] - 0.55) ** 2) / 0.03)
+    y_err = np.full(m, 0.01); y = A @ truth + rng.normal(size=m) * y_err
+    gli = GpLinearInverter(y=y, y_err=y_err, model_matrix=A, parameter_spatial_positions=pos)
+    th = np.array([0.1, 0.0, np.log(0.2), np.log(0.2)])
+    dt_l, _ = t(lambda: gli.marginal_likelihood(th))
+    dt_g, _ = t(lambda: gli.marginal_likelihood_gradient(th), reps=2)
+    dt_m, _ = t(lambda: gli.calculate_posterior_mean(th), reps=2)
+    dt_p, _ = t(lambda: gli.calculate_posterior(th), reps=2)
+    fl = 2.0 * m * n * n + 2.0 * m * m * n / 2 + m**3 / 3
+    print(f"linv SE m={m} n={n} d=2: LML {dt_l*1e3:.1f} ms ({fl/dt_l/1e12:.1f} TFLOP/s) | LML+grad {dt_g*1e3:.1f} ms | "
+          f"posterior mean {dt_m*1e3:.1f} ms | mean+covariance ({n}x{n} download) {dt_p*1e3:.1f} ms")
+    if "--cpu" in sys.argv:
+        import time as _t
+        from oracle.linv_oracle import OracleLinearInverter
+        sub = slice(0, 1024); nsub = 45 * 45
+        o = OracleLinearInverter(y[sub], y_err[sub], A[sub, :nsub], pos[:nsub], wl.SE)
+        t0 = _t.perf_counter(); o.marginal_likelihood(th); d1 = _t.perf_counter() - t0
+        print(f"     CPU oracle at m=1024 n={nsub}: LML {d1*1e3:.0f} ms")

@@ -68,3 +68,66 @@ def theta_grid_cfg3(y, d: int):
         for ll in np.linspace(np.log(0.2), np.log(2.0), 8):
             out.append([y.mean(), la, 0.0] + [ll] * d)
     return np.array(out)
+
+
+# ---------------------------------------------------------------------------------------------
+# linear-inversion problems (GpLinearInverter): model matrix, data, parameter positions
+# ---------------------------------------------------------------------------------------------
+def linv_problem(name):
+    """`deconv`: 1-D deconvolution in the spirit of the reference's own test (32 data values, 64 model
+    parameters on [-1, 1], Gaussian blur; tests/gp/test_GpLinearInverter.py:44-67), written out
+    independently: three peaks, pixel-integrated Gaussian response.
+    `tomo`: 2-D, 400 parameters on a 20 x 20 grid seen through 300 random smooth 'chords' (each row of A a
+    normalised Gaussian ridge across the grid) - sizes that exercise the padded tiles (300 -> 384, 400 -> 512).
+    Returns (positions (n, d), A (m, n), y (m,), y_err (m,))."""
+    from scipy.special import erf
+
+    if name == "deconv":
+        m, n = 32, 64
+        x = np.linspace(-1.0, 1.0, n)
+        t = np.linspace(-1.0, 1.0, m)
+        half = 0.5 * (x[1] - x[0])
+        width = 0.075
+        truth = 1.0 / (1 + (x / 0.1) ** 2) + 0.8 / (1 + ((x - 0.3) / 0.15) ** 2) + 0.3 / (1 + ((x + 0.45) / 0.1) ** 2)
+        cdf = lambda z: 0.5 * (1.0 + erf(z / (np.sqrt(2.0) * width)))  # noqa: E731
+        A = cdf(t[:, None] + half - x[None, :]) - cdf(t[:, None] - half - x[None, :])
+        rng = np.random.default_rng(20250614 + 101)
+        y_err = np.full(m, 0.02)
+        y = A @ truth + rng.normal(size=m) * y_err
+        return x.reshape(n, 1), A, y, y_err
+    if name == "tomo":
+        g = 20
+        m, n = 300, g * g
+        ax = (np.arange(g) + 0.5) / g
+        X, Y = np.meshgrid(ax, ax, indexing="ij")
+        pos = np.stack([X.ravel(), Y.ravel()], axis=1)
+        rng = np.random.default_rng(20250614 + 102)
+        ang = rng.uniform(0, np.pi, m)
+        off = rng.uniform(-0.35, 0.35, m)
+        # distance of every pixel centre to chord i (through the centre + offset along the normal)
+        dist = (pos[None, :, 0] - 0.5) * np.cos(ang)[:, None] + (pos[None, :, 1] - 0.5) * np.sin(ang)[:, None] - off[:, None]
+        A = np.exp(-0.5 * (dist / 0.04) ** 2)
+        A /= A.sum(axis=1, keepdims=True)
+        truth = np.exp(-((pos[:, 0] - 0.4) ** 2 + (pos[:, 1] - 0.55) ** 2) / 0.03) + 0.5 * np.exp(
+            -((pos[:, 0] - 0.7) ** 2 + (pos[:, 1] - 0.3) ** 2) / 0.01
+        )
+        y_err = np.full(m, 0.01)
+        y = A @ truth + rng.normal(size=m) * y_err
+        return pos, A, y, y_err
+    raise ValueError(name)
+
+
+def linv_thetas(name, kid, white_noise=False):
+    """Three hyper-parameter vectors [mean, ln a, (ln kappa), ln l.., (ln sigma_n)] per problem."""
+    d = 1 if name == "deconv" else 2
+    base_l = np.log(0.15 if name == "deconv" else 0.2)
+    out = []
+    for i, (mean, lna, dl) in enumerate([(0.1, 0.0, 0.0), (0.3, -0.5, 0.4), (0.0, 0.4, -0.3)]):
+        th = [mean, lna]
+        if kid == RQ:
+            th.append(0.3 - 0.2 * i)
+        th += [base_l + dl + 0.1 * k for k in range(d)]
+        if white_noise:
+            th.append(np.log(0.05) + 0.3 * i)
+        out.append(np.array(th))
+    return out
