@@ -170,6 +170,15 @@ int gpmi_loo_terms(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_th
                    double extra_diag, const double* mu_host, double* alpha_host,
                    double* ikdiag_host, int* info);
 
+/* ---- per-point noise hyper-parameters (HeteroscedasticNoise, covariance.py:608-690) ----
+ * K = K_stationary + diag(sigma_i^2) + data errors: the host adds exp(2 theta_i) to the data variances and
+ * replaces the diagonal term with this call before gpmi_fit / gpmi_lml / gpmi_lml_grad (n values; ignored
+ * when a dense y_cov was given to gpmi_set_data). */
+int gpmi_set_noise(gpmi_ctx* ctx, const double* noise_var_host);
+/* q_i = alpha_i^2 - (K^-1)_ii of the most recent gpmi_lml_grad call (n values): the gradient with respect to
+ * ln sigma_i is 1/2 Q_ii 2 sigma_i^2 = sigma_i^2 q_i (covariance.py:682-686, regression.py:561-565). */
+int gpmi_lml_grad_qdiag(gpmi_ctx* ctx, double* qdiag_host);
+
 /* ---- Gaussian-process linear inversion (inference/gp/inversion.py) --------------------
  * The model parameters (n of them, at the positions given to gpmi_set_data as x; y / noise of that call are
  * unused) have the GP prior N(mu, K(theta)); the data y (m values, independent errors y_err) are

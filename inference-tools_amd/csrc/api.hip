@@ -1178,6 +1178,44 @@ int gpmi_dev_gemm_nt(gpmi_ctx* c, double* C, int64_t ldc, const double* A, int64
 
 }  // extern "C"
 
+// ---- per-point noise hyper-parameters ----------------------------------------------------------------
+namespace {
+__global__ void qdiag_kernel(const double* __restrict__ iK, int64_t ld, const double* __restrict__ alpha,
+                             double* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = alpha[i] * alpha[i] - iK[i * ld + i];
+}
+}  // namespace
+
+extern "C" {
+
+int gpmi_set_noise(gpmi_ctx* c, const double* noise_var) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->n > 0, "gpmi_set_data has not been called");
+  ARGCHK(c, noise_var != nullptr, "noise_var is NULL");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = gpmi_sync(c)) return rc;  // nothing may still be reading the old values
+  HIPCHK(c, hipMemcpy(c->noise, noise_var, sizeof(double) * c->n, hipMemcpyHostToDevice));
+  return GPMI_OK;
+}
+
+int gpmi_lml_grad_qdiag(gpmi_ctx* c, double* qdiag) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, qdiag != nullptr, "qdiag is NULL");
+  ARGCHK(c, c->lanes.size() >= 2 && c->lanes[1].B2, "gpmi_lml_grad has not been called");
+  if (int rc = set_device(c)) return rc;
+  Lane& L = c->lanes[1];  // after gpmi_lml_grad: L.A = K^-1 (lower tiles), vec + np = alpha
+  double* out = L.vec + 2 * c->np;
+  hipLaunchKernelGGL(qdiag_kernel, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, L.stream, L.A, c->ld,
+                     L.vec + c->np, out, c->n);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(qdiag, out, sizeof(double) * c->n, hipMemcpyDeviceToHost, L.stream));
+  HIPCHK(c, hipStreamSynchronize(L.stream));
+  return GPMI_OK;
+}
+
+}  // extern "C"
+
 // ---- Gaussian-process linear inversion --------------------------------------------------------------
 namespace {
 

@@ -53,6 +53,14 @@ class GpEngine:
                     dptr(out), info.ctypes.data_as(C.POINTER(C.c_int)))
         return out, info
 
+    def set_noise(self, noise_var):
+        self.h.call("gpmi_set_noise", dptr(as_f64(noise_var)))
+
+    def lml_grad_qdiag(self):
+        q = np.empty(self.n)
+        self.h.call("gpmi_lml_grad_qdiag", dptr(q))
+        return q
+
     def set_streams(self, n):
         self.h.call("gpmi_set_streams", int(n))
 

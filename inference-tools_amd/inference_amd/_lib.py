@@ -57,6 +57,8 @@ SIGNATURES = {
     "gpmi_loo_diag": (C.c_int, [_vp, _dp]),
     "gpmi_loo_terms": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _ip]),
     "gpmi_loo_grad": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_set_noise": (C.c_int, [_vp, _dp]),
+    "gpmi_lml_grad_qdiag": (C.c_int, [_vp, _dp]),
     "gpmi_linv_set": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
     "gpmi_linv_lml": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _ip]),
     "gpmi_linv_lml_grad": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _ip]),

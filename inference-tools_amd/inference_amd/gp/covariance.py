@@ -234,6 +234,49 @@ class WhiteNoise(CovarianceFunction):
         return K, [2.0 * K]
 
 
+class HeteroscedasticNoise(CovarianceFunction):
+    r"""
+    Independent Gaussian noise with one standard deviation per data value,
+    K = delta_ij sigma_i^2, theta = [ln sigma_1 .. ln sigma_N] (reference: covariance.py:608-690).
+    Used as `SquaredExponential() + HeteroscedasticNoise()`.  On the device it is part of the diagonal term
+    of the covariance build (the host adds exp(2 theta_i) to the data variances, `gpmi_set_noise`), and its
+    N gradient components come from one vector, sigma_i^2 (alpha_i^2 - (K^-1)_ii) (`gpmi_lml_grad_qdiag`),
+    instead of the reference's N dense N x N matrices.
+    """
+
+    def __init__(self, hyperpar_bounds=None):
+        self.bounds = hyperpar_bounds
+        self.n_params = 0
+        self.hyperpar_labels = []
+
+    def pass_spatial_data(self, x: ndarray):
+        self.n_params = x.shape[0]
+        self.hyperpar_labels = [f"log_sigma_{i + 1}" for i in range(self.n_params)]
+
+    def estimate_hyperpar_bounds(self, y: ndarray):
+        s = log(np.ptp(y))
+        self.bounds = [(s - 8, s + 2)] * self.n_params
+
+    def __call__(self, u: ndarray, v: ndarray, theta):
+        # the reference sizes this block by u.size / v.size (covariance.py:671-672), which only works for
+        # one spatial dimension; row counts give the same result there and the intended one for d > 1
+        return np.zeros([np.atleast_2d(u).shape[0] if np.ndim(u) > 1 else np.size(u),
+                         np.atleast_2d(v).shape[0] if np.ndim(v) > 1 else np.size(v)])
+
+    def build_covariance(self, theta):
+        return np.diag(exp(2 * np.asarray(theta)))
+
+    def covariance_and_gradients(self, theta):
+        # host fall-back only (N dense matrices, as the reference builds them); the device path never calls it
+        var = exp(2 * np.asarray(theta))
+        grads = []
+        for i, v in enumerate(var):
+            G = np.zeros([self.n_params, self.n_params])
+            G[i, i] = 2.0 * v
+            grads.append(G)
+        return np.diag(var), grads
+
+
 def slice_builder(lengths):
     out, lo = [], 0
     for n in lengths:
@@ -281,14 +324,25 @@ class CompositeCovariance(CovarianceFunction):
 def device_plan(cov):
     """How `GpRegressor` maps a covariance object onto the device kernels:
     returns (kernel_id, stationary_component, slice_of_its_theta, white_noise_index or None)
-    or None when the object is not a supported combination."""
+    or None when the object is not a supported combination: one of the stationary kernels, optionally plus
+    one WhiteNoise and / or one HeteroscedasticNoise (see `heteroscedastic_slice`)."""
     if isinstance(cov, _StationaryDeviceKernel):
         return cov._gpmi_kernel, cov, slice(0, cov.n_params), None
     if isinstance(cov, CompositeCovariance):
         stat = [(i, c) for i, c in enumerate(cov.components) if isinstance(c, _StationaryDeviceKernel)]
         wn = [(i, c) for i, c in enumerate(cov.components) if isinstance(c, WhiteNoise)]
-        if len(stat) == 1 and len(wn) <= 1 and len(stat) + len(wn) == len(cov.components):
+        het = [c for c in cov.components if isinstance(c, HeteroscedasticNoise)]
+        if len(stat) == 1 and len(wn) <= 1 and len(het) <= 1 and len(stat) + len(wn) + len(het) == len(cov.components):
             i, c = stat[0]
             wn_index = cov.slices[wn[0][0]].start if wn else None
             return c._gpmi_kernel, c, cov.slices[i], wn_index
+    return None
+
+
+def heteroscedastic_slice(cov):
+    """Slice of the HeteroscedasticNoise parameters inside the covariance parameter vector, or None."""
+    if isinstance(cov, CompositeCovariance):
+        for comp, sl in zip(cov.components, cov.slices):
+            if isinstance(comp, HeteroscedasticNoise):
+                return sl
     return None

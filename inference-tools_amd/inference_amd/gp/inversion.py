@@ -22,7 +22,7 @@ from scipy.optimize import minimize
 
 from inference_amd._engine import LinvEngine
 from inference_amd.gp import _messages as msg
-from inference_amd.gp.covariance import CovarianceFunction, SquaredExponential, device_plan
+from inference_amd.gp.covariance import CovarianceFunction, SquaredExponential, device_plan, heteroscedastic_slice
 from inference_amd.gp.mean import ConstantMean, MeanFunction
 
 
@@ -91,7 +91,7 @@ class GpLinearInverter:
         self.hyperpar_labels = [*self.mean.hyperpar_labels, *self.cov.hyperpar_labels]
 
         plan = device_plan(self.cov)
-        if plan is None:
+        if plan is None or heteroscedastic_slice(self.cov) is not None:
             raise NotImplementedError(msg.no_device_kernel(type(self.cov)).replace("GpRegressor", "GpLinearInverter"))
         self._kernel_id, self._stat, self._stat_slice, self._wn_index = plan
         self._device = device

@@ -25,7 +25,7 @@ from scipy.optimize import differential_evolution, fmin_l_bfgs_b
 
 from inference_amd._engine import GpEngine
 from inference_amd.gp import _messages as msg
-from inference_amd.gp.covariance import CovarianceFunction, SquaredExponential, device_plan
+from inference_amd.gp.covariance import heteroscedastic_slice, CovarianceFunction, SquaredExponential, device_plan
 from inference_amd.gp.mean import ConstantMean, MeanFunction
 
 
@@ -94,6 +94,8 @@ class GpRegressor:
         if plan is None:
             raise NotImplementedError(msg.no_device_kernel(type(self.cov)))
         self._kernel_id, self._stat, self._stat_slice, self._wn_index = plan
+        self._het_slice = heteroscedastic_slice(self.cov)
+        self._fit_noise = None
         self._device = device
         self._engine = None
         self._K_cache = None
@@ -154,12 +156,20 @@ class GpRegressor:
         return state
 
     def _split_cov_theta(self, theta_cov):
-        """(stationary-kernel parameters, WhiteNoise variance) of a covariance parameter vector."""
+        """(stationary-kernel parameters, WhiteNoise variance) of a covariance parameter vector.  With a
+        HeteroscedasticNoise component the per-point variances exp(2 theta_i) are added to the data variances
+        on the device (covariance.py:674-680) before the evaluation that follows."""
         theta_cov = np.asarray(theta_cov, dtype=float)
         extra = 0.0
         if self._wn_index is not None:
             extra = float(np.exp(2 * theta_cov[self._wn_index]))  # covariance.py:168
+        if self._het_slice is not None:
+            self.engine.set_noise(self._noise_total(theta_cov))
         return np.ascontiguousarray(theta_cov[self._stat_slice]), extra
+
+    def _noise_total(self, theta_cov):
+        base = np.zeros(self.n_points) if self._noise_var is None else self._noise_var
+        return base + np.exp(2 * np.asarray(theta_cov, dtype=float)[self._het_slice])
 
     @property
     def sig(self) -> ndarray:
@@ -173,6 +183,8 @@ class GpRegressor:
     @property
     def K_xx(self) -> ndarray:
         if self._K_cache is None:
+            if self._fit_noise is not None:  # a later evaluation may have left other per-point variances behind
+                self.engine.set_noise(self._fit_noise)
             self._K_cache = self.engine.get_K()
         return self._K_cache
 
@@ -202,6 +214,7 @@ class GpRegressor:
         self.cov_hyperpars = self.hyperpars[self.cov_slice]
         self.mu = self.mean.build_mean(self.mean_hyperpars)
         theta_stat, extra = self._split_cov_theta(self.cov_hyperpars)
+        self._fit_noise = self._noise_total(self.cov_hyperpars) if self._het_slice is not None else None
         self._K_cache = None
         self._L_cache = None
         alpha, logdet, info = self.engine.fit(self._kernel_id, theta_stat, extra, self.mu)
@@ -302,6 +315,8 @@ class GpRegressor:
     def loo_likelihood_gradient(self, theta: ndarray):
         """LOO log-likelihood and its gradient, R&W eqs. 5.10-5.14 (regression.py:489-526)."""
         theta = np.asarray(theta, dtype=float)
+        if self._het_slice is not None:
+            raise NotImplementedError("loo_likelihood_gradient: HeteroscedasticNoise has no device gradient yet")
         theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
         mu, grad_mu = self.mean.mean_and_gradients(theta[self.mean_slice])
         alpha, ikdiag, pvec, g_stat, trace_q, info = self.engine.loo_grad(self._kernel_id, theta_stat, extra, mu)
@@ -334,6 +349,8 @@ class GpRegressor:
         """(extension) `marginal_likelihood` for T hyper-parameter vectors at once, spread over
         the device's worker streams — the unit the grid sweep / PT driver shards over GPUs."""
         thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
+        if self._het_slice is not None:  # per-point variances change with theta: one evaluation at a time
+            return np.array([self.marginal_likelihood(t) for t in thetas])
         split = [self._split_cov_theta(t[self.cov_slice]) for t in thetas]
         th = np.array([s[0] for s in split])
         ex = np.array([s[1] for s in split])
@@ -360,6 +377,9 @@ class GpRegressor:
         g_cov[self._stat_slice] = g_stat
         if self._wn_index is not None:
             g_cov[self._wn_index] = extra * trace_q  # 1/2 sum Q o (2 sigma^2 I), covariance.py:171-175
+        if self._het_slice is not None:
+            # dK/d ln sigma_i = 2 sigma_i^2 e_i e_i^T (covariance.py:682-686): 1/2 Q_ii 2 sigma_i^2
+            g_cov[self._het_slice] = np.exp(2 * theta[self.cov_slice][self._het_slice]) * self.engine.lml_grad_qdiag()
         grad[self.cov_slice] = g_cov
         return lml, grad
 

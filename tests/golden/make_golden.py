@@ -18,6 +18,7 @@ Cases
   cfg4       BASELINE config 4: SE, N=4096, d=4, 1000 EI candidates
   cfg2       BASELINE config 2: SE, N=8192, d=8 (needs ~16 GB RSS, several minutes)
   fail       a theta for which numpy.linalg.cholesky raises (pins the -1e50 path)
+  het        SE + HeteroscedasticNoise, N=96: LML, gradient (99 parameters), fit + predict
   linv       GpLinearInverter: 1-D deconvolution (32 x 64) and 2-D tomography (300 x 400), SE / RQ / SE+WhiteNoise
 """
 import os
@@ -48,6 +49,7 @@ from inference.gp import (  # noqa: E402
     SquaredExponential,
     RationalQuadratic,
     WhiteNoise,
+    HeteroscedasticNoise,
     ExpectedImprovement,
     UpperConfidenceBound,
     MaxVariance,
@@ -308,6 +310,35 @@ def case_pt():
     return out
 
 
+def case_het():
+    """SquaredExponential + HeteroscedasticNoise (covariance.py:608-690) on a 96-point 1-D set (the
+    reference's HeteroscedasticNoise.__call__ sizes its zero block by u.size, covariance.py:671-672, so its
+    predictions only work for d = 1): 99 hyper-parameters, LML and its gradient, fit + predict."""
+    n, d = 96, 1
+    x, y, e = wl.synthetic_dataset(77, n, d)
+    rng = np.random.default_rng(770)
+    out = {}
+    for tag, with_err in (("err", True), ("noerr", False)):
+        gp = GpRegressor(x, y, y_err=e if with_err else None, kernel=SquaredExponential() + HeteroscedasticNoise(),
+                         hyperpars=None if False else np.concatenate([wl.timing_theta(wl.SE, y, d), np.log(0.1) + 0.3 * rng.standard_normal(n)]))
+        thetas = [np.concatenate([wl.timing_theta(wl.SE, y, d) + 0.1 * k, np.log(0.1) + 0.3 * rng.standard_normal(n)])
+                  for k in range(3)]
+        out[f"{tag}_thetas"] = np.array(thetas)
+        out[f"{tag}_labels"] = np.array(gp.hyperpar_labels)
+        out[f"{tag}_bounds"] = np.array(gp.hp_bounds, dtype=float)
+        out[f"{tag}_lml"] = np.array([gp.marginal_likelihood(t) for t in thetas])
+        res = [gp.marginal_likelihood_gradient(t) for t in thetas]
+        out[f"{tag}_lml2"] = np.array([r[0] for r in res])
+        out[f"{tag}_grad"] = np.array([r[1] for r in res])
+        gp.set_hyperparameters(thetas[1])
+        pts = wl.query_points(77, 40, d)
+        mu, sig = gp(pts)
+        out[f"{tag}_alpha"] = gp.alpha
+        out[f"{tag}_K_xx"] = gp.K_xx
+        out[f"{tag}_mu"], out[f"{tag}_sig"] = mu, sig
+    return out
+
+
 def case_linv():
     """GpLinearInverter (inversion.py): LML, LML gradient, posterior mean / covariance."""
     from inference.gp import GpLinearInverter
@@ -339,6 +370,7 @@ def case_linv():
 IDX_TOMO = np.arange(0, 400, 7)  # 58 rows / columns of the 400 x 400 posterior covariance
 
 CASES = {
+    "het": case_het,
     "linv": case_linv,
     "pt": case_pt,
     "t32": case_t32,

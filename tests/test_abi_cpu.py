@@ -62,3 +62,27 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src, f"{f} references the oracle"
+
+
+def test_host_side_kernel_mirrors_against_reference_vectors(golden):
+    """The O(N) host parts of the covariance classes (labels, bounds, diagonal blocks) need no GPU:
+    HeteroscedasticNoise against the reference's outputs (tests/golden/het.npz)."""
+    import numpy as np
+
+    import workloads as wl
+    from inference_amd.gp.covariance import HeteroscedasticNoise, SquaredExponential, device_plan, heteroscedastic_slice
+
+    g = golden("het")
+    x, y, _ = wl.synthetic_dataset(77, 96, 1)
+    cov = SquaredExponential() + HeteroscedasticNoise()
+    cov.pass_spatial_data(x)
+    cov.estimate_hyperpar_bounds(y)
+    assert [f"{s}" for s in cov.hyperpar_labels] == list(g["err_labels"])[1:]
+    assert np.allclose(np.array(cov.bounds, dtype=float), g["err_bounds"][1:], rtol=1e-12)
+    assert device_plan(cov) is not None and heteroscedastic_slice(cov) == slice(2, 98)
+    th = g["err_thetas"][1][1:]
+    het = cov.components[1]
+    Kh, grads = het.covariance_and_gradients(th[heteroscedastic_slice(cov)])
+    assert np.array_equal(np.diagonal(Kh), np.exp(2 * th[2:])) and np.count_nonzero(Kh) == 96
+    assert len(grads) == 96 and grads[5][5, 5] == 2 * Kh[5, 5] and np.count_nonzero(grads[5]) == 1
+    assert het(x[:3], x, th[2:]).shape == (3, 96)

@@ -593,3 +593,29 @@ def test_linear_inverter_optimise_and_errors(gp_mod):
     with pytest.raises(NotImplementedError):
         gp_mod.GpLinearInverter(y=y, y_err=y_err, model_matrix=A, parameter_spatial_positions=pos,
                                 prior_covariance_function=gp_mod.SquaredExponential() + gp_mod.RationalQuadratic())
+
+
+# ---------------------------------------------------------------------------------------
+# HeteroscedasticNoise: per-point noise hyper-parameters
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,with_err", [("err", True), ("noerr", False)])
+def test_heteroscedastic_noise_vs_reference(golden, gp_mod, tag, with_err):
+    """SE + HeteroscedasticNoise, N = 96 (99 hyper-parameters): labels, bounds, LML, the full gradient (the 96
+    noise components from one device vector), fit (K, alpha) and predict against the reference."""
+    g = golden("het")
+    n, d = 96, 1
+    x, y, e = wl.synthetic_dataset(77, n, d)
+    th = g[f"{tag}_thetas"]
+    gp = gp_mod.GpRegressor(x, y, y_err=e if with_err else None, hyperpars=th[1],
+                            kernel=gp_mod.SquaredExponential() + gp_mod.HeteroscedasticNoise())
+    assert list(g[f"{tag}_labels"]) == gp.hyperpar_labels
+    check(np.array(gp.hp_bounds, dtype=float), g[f"{tag}_bounds"], 1e-12, "bounds")
+    check(gp.alpha, g[f"{tag}_alpha"], what="alpha")
+    check(gp.marginal_likelihood_batch(th), g[f"{tag}_lml"], what="lml")
+    res = [gp.marginal_likelihood_gradient(t) for t in th]
+    check([r[0] for r in res], g[f"{tag}_lml2"], what="lml (gradient call)")
+    check([r[1] for r in res], g[f"{tag}_grad"], 1e-9, "gradient")
+    check(gp.K_xx, g[f"{tag}_K_xx"], 1e-13, "K_xx after evaluations at other thetas")
+    mu, sig = gp(wl.query_points(77, 40, d))
+    check(mu, g[f"{tag}_mu"], what="mu")
+    check(sig, g[f"{tag}_sig"], what="sig")
