@@ -174,12 +174,17 @@ class GpEngine:
         import os
         import sys
 
+        libc = C.CDLL(None)
         sys.stdout.flush()
+        libc.fflush(None)
         saved = os.dup(1)
         try:
             os.dup2(2, 1)
             self.h.call("gpmi_comm_init", int(rank), int(world), unique_id)
         finally:
+            # the banner sits in C stdio's buffer when stdout is not a terminal: flush it while fd 1 still points
+            # at stderr, or it would come out after the caller's own output at process exit
+            libc.fflush(None)
             os.dup2(saved, 1)
             os.close(saved)
         self.comm_world = world
