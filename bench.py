@@ -39,35 +39,55 @@ import numpy as np  # noqa: E402
 PEAK_FP64_MFMA_TFLOPS = 78.6  # 256 CU x 4 SIMD x 2048 FLOP / 64 clk x 2.4 GHz (tools/mfma_probe.hip)
 
 
-def cpu_baseline(n_cpu, d, m_cpu):
-    """Oracle (port of the reference path) on the host: fit + batched predict at a bounded size."""
+def cpu_baseline(n_cpu, d, m_cpu, runs=3):
+    """Oracle (port of the reference path: same NumPy / LAPACK calls) on the host cores: fit + batched predict at a
+    bounded size, one warm-up at a quarter of the size, then the median of `runs` runs."""
     from oracle import gp_oracle as orc  # checker / baseline only
     import workloads as wl
 
-    x, y, e = wl.synthetic_dataset(2, n_cpu, d)
-    theta = wl.timing_theta(wl.SE, y, d)
-    pts = wl.query_points(2, m_cpu, d)
-    threads = os.cpu_count() or 1
+    def one(n, m):
+        x, y, e = wl.synthetic_dataset(2, n, d)
+        theta = wl.timing_theta(wl.SE, y, d)
+        pts = wl.query_points(2, m, d)
+        t0 = time.perf_counter()
+        gp = orc.OracleGp(x, y, e, kernel=orc.SE, hyperpars=theta)
+        gp(pts)
+        return time.perf_counter() - t0
+
+    threads, blas = os.cpu_count() or 1, "unknown BLAS"
     try:
         from threadpoolctl import threadpool_info
 
-        info = threadpool_info()
+        info = [i for i in threadpool_info() if i.get("user_api") == "blas"] or threadpool_info()
         if info:
             threads = max(i.get("num_threads", 1) for i in info)
+            blas = "; ".join(sorted({f"{i.get('internal_api', '?')} {i.get('version', '')}".strip() for i in info}))
     except Exception:
         pass
-    t0 = time.perf_counter()
-    gp = orc.OracleGp(x, y, e, kernel=orc.SE, hyperpars=theta)
-    gp(pts)
-    dt = time.perf_counter() - t0
+    cpu = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+    except Exception:
+        pass
+    try:
+        import scipy
+
+        versions = f"NumPy {np.__version__}, SciPy {scipy.__version__}"
+    except Exception:
+        versions = f"NumPy {np.__version__}"
+    one(max(n_cpu // 4, 256), max(m_cpu // 4, 16))
+    times = sorted(one(n_cpu, m_cpu) for _ in range(runs))
+    dt = times[len(times) // 2]
     flops = n_cpu**3 / 3.0 + m_cpu * float(n_cpu) ** 2
     return {
         "value": flops / dt / 1e9,
         "unit": "GFLOP/s",
         "cores": int(threads),
         "kind": "port",
-        "sample": f"oracle fit+predict SE N={n_cpu} d={d} M={m_cpu} (same generator and theta as the workload), 1 run, "
-        f"{dt:.1f} s wall (NumPy {np.__version__} / SciPy + BLAS threads={threads}); K-build included as in the reference",
+        "sample": f"oracle fit+predict SE N={n_cpu} d={d} M={m_cpu} (same generator and theta as the workload; row-chunked "
+        f"K-build as in the reference, numpy.linalg.cholesky, scipy.linalg.solve_triangular), warm-up + median of {runs} "
+        f"runs: {dt:.1f} s each; {cpu}, {os.cpu_count()} logical CPUs, {blas} with {threads} threads, {versions}",
     }
 
 
@@ -211,7 +231,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(6144, d, 384)  # ~10-20 s of host work
+            line["cpu_baseline"] = cpu_baseline(4096, d, 256)  # ~10-15 s of host work in all
         print(json.dumps(line), flush=True)
 
     if rdv is not None:
