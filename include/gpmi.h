@@ -179,6 +179,28 @@ int gpmi_set_noise(gpmi_ctx* ctx, const double* noise_var_host);
  * ln sigma_i is 1/2 Q_ii 2 sigma_i^2 = sigma_i^2 q_i (covariance.py:682-686, regression.py:561-565). */
 int gpmi_lml_grad_qdiag(gpmi_ctx* ctx, double* qdiag_host);
 
+/* ---- mixture covariance: ChangePoint (covariance.py:371-606) ---------------------------
+ * K = sum_m diag(g_m) K_m(theta_m) diag(g_m) + extra_diag I + data errors, with up to four stationary
+ * sub-kernels K_m and per-point weights g_m (products of the logistic windows of covariance.py:529-559,
+ * evaluated on the host in O(N)).  kernels[nk]: GPMI_KERNEL_*; thetas: the sub-kernels' parameter vectors
+ * concatenated; n_thetas[nk]; g_host: nk x n row-major. */
+int gpmi_fit_mix(gpmi_ctx* ctx, int nk, const int* kernels, const double* thetas, const int* n_thetas,
+                 const double* g_host, double extra_diag, const double* mu_host, double* alpha_host,
+                 double* logdet, int* info);
+int gpmi_lml_mix(gpmi_ctx* ctx, int nk, const int* kernels, const double* thetas, const int* n_thetas,
+                 const double* g_host, double extra_diag, const double* mu_host, double* lml, int* info);
+/* LML and the gradient pieces (covariance.py:561-594 + regression.py:544-567): grad_thetas = the sub-kernels'
+ * parameter gradients, concatenated; hrows (nk x n): h_m(i) = sum_j Q_ij K_m,ij g_m(j), Q = alpha alpha^T - K^-1,
+ * from which the host forms the window-parameter gradients sum_m sum_i (d g_m / d phi)(i) h_m(i);
+ * q_i for additive noise terms comes from gpmi_lml_grad_qdiag as usual. */
+int gpmi_lml_grad_mix(gpmi_ctx* ctx, int nk, const int* kernels, const double* thetas, const int* n_thetas,
+                      const double* g_host, double extra_diag, const double* mu_host, double* lml,
+                      double* grad_thetas, double* hrows_host, double* alpha_host, int* info);
+/* prediction with the model of gpmi_fit_mix: gq_host (nk x m) are the weights of the query points;
+ * mu* = k.alpha (the host adds the mean function), negsumsq = -|L^-1 k|^2 (the host adds K_qq[0, 0]) */
+int gpmi_predict_mix(gpmi_ctx* ctx, const double* pts_host, int64_t m, const double* gq_host,
+                     double* mu_host, double* negsumsq_host);
+
 /* ---- Gaussian-process linear inversion (inference/gp/inversion.py) --------------------
  * The model parameters (n of them, at the positions given to gpmi_set_data as x; y / noise of that call are
  * unused) have the GP prior N(mu, K(theta)); the data y (m values, independent errors y_err) are

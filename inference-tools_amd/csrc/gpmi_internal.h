@@ -117,6 +117,14 @@ struct gpmi_ctx {
   double* h_bRed = nullptr;
   int* h_bInfo = nullptr;
   LinvState linv;
+  // fitted mixture model (gpmi_fit_mix): sub-kernel parameters and the training-point weights g (nk x np)
+  int mix_nk = 0;
+  KParams mix_p[4];
+  double* mix_g = nullptr;        // nk x np (row m: g_m; padding 1 for m = 0, 0 otherwise)
+  double* mix_scratch = nullptr;  // np x ld
+  double* mix_zero = nullptr;     // np zeros
+  double* Q3 = nullptr;           // third query panel (mq_cap x ld)
+  int64_t q3_cap = 0;
   // RCCL result gather (comm.hip)
   void* comm = nullptr;
   int comm_rank = 0, comm_world = 1;
@@ -184,6 +192,16 @@ struct BatchShape {
   int64_t sInv = 0;   // between the invD arrays
   int64_t sVec = 0;   // between the work-vector sets
 };
+
+// mix.hip: pieces of the mixture covariance K = sum_m diag(g_m) K_m diag(g_m) (ChangePoint)
+constexpr int GPMI_MAX_MIX = 4;
+void launch_scale_add(hipStream_t s, double* dst, int64_t ldd, const double* src, int64_t lds,
+                      const double* gr, const double* gc, int64_t rows, int64_t cols, bool accumulate);
+void launch_add_diag_vec(hipStream_t s, double* A, int64_t ld, const double* noise, double extra, int64_t n);
+void launch_vec_mul(hipStream_t s, const double* a, const double* b, double* out, int64_t n);
+// h_i = sum_j (alpha_i alpha_j - iK_ij) Km_ij g_j  (iK, Km full n x n)
+void launch_mix_rowsum(hipStream_t s, const double* iK, const double* Km, int64_t ld, const double* alpha,
+                       const double* g, double* h, int64_t n);
 
 // gemm_f64.hip  (all dims multiples of 128, k multiple of 16)
 enum GemmTiles { TILES_RECT = 0, TILES_LOWER = 1 };

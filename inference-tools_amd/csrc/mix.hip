@@ -1,0 +1,84 @@
+// Element-wise helpers of the mixture covariance  K = sum_m diag(g_m) K_m diag(g_m)  (ChangePoint,
+// covariance.py:371-606: g_m are products of logistic windows along one axis, evaluated on the host in
+// O(N)).  Every K_m is produced by the ordinary covariance-build kernel into a scratch matrix; these kernels
+// fold it into the sum and form the extra reductions the change-point gradients need.  All HBM bound.
+#include "gpmi_internal.h"
+
+namespace {
+
+// dst = (or +=) gr_i gc_j src_ij over rows x cols (both multiples of 128), 2 doubles per thread
+__global__ void scale_add_kernel(double* __restrict__ dst, int64_t ldd, const double* __restrict__ src,
+                                 int64_t lds, const double* __restrict__ gr, const double* __restrict__ gc,
+                                 int64_t cols, int accumulate) {
+  const int64_t i = blockIdx.y;
+  const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (j >= cols) return;
+  const double r = gr[i];
+  const d2_t s = *reinterpret_cast<const d2_t*>(src + i * lds + j);
+  d2_t v = d2_t{r * gc[j] * s[0], r * gc[j + 1] * s[1]};
+  if (accumulate) {
+    const d2_t o = *reinterpret_cast<const d2_t*>(dst + i * ldd + j);
+    v = d2_t{o[0] + v[0], o[1] + v[1]};
+  }
+  *reinterpret_cast<d2_t*>(dst + i * ldd + j) = v;
+}
+
+__global__ void add_diag_vec_kernel(double* __restrict__ A, int64_t ld, const double* __restrict__ noise,
+                                    double extra, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) A[i * ld + i] += noise[i] + extra;
+}
+
+__global__ void vec_mul_kernel(const double* __restrict__ a, const double* __restrict__ b,
+                               double* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] * b[i];
+}
+
+// one wave per row:  h_i = sum_j (alpha_i alpha_j - iK_ij) Km_ij g_j   (fixed order: bit-reproducible)
+__global__ __launch_bounds__(256) void mix_rowsum_kernel(const double* __restrict__ iK,
+                                                         const double* __restrict__ Km, int64_t ld,
+                                                         const double* __restrict__ alpha,
+                                                         const double* __restrict__ g,
+                                                         double* __restrict__ h, int64_t n) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const double ai = alpha[row];
+  const double* q = iK + row * ld;
+  const double* k = Km + row * ld;
+  double s = 0.0;
+  for (int64_t j = lane * 2; j < n; j += 128) {
+    const d2_t qv = *reinterpret_cast<const d2_t*>(q + j);
+    const d2_t kv = *reinterpret_cast<const d2_t*>(k + j);
+    s = fma((ai * alpha[j] - qv[0]) * kv[0], g[j], s);
+    if (j + 1 < n) s = fma((ai * alpha[j + 1] - qv[1]) * kv[1], g[j + 1], s);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) h[row] = s;
+}
+
+}  // namespace
+
+void launch_scale_add(hipStream_t s, double* dst, int64_t ldd, const double* src, int64_t lds,
+                      const double* gr, const double* gc, int64_t rows, int64_t cols, bool accumulate) {
+  dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)rows);
+  hipLaunchKernelGGL(scale_add_kernel, grid, dim3(256), 0, s, dst, ldd, src, lds, gr, gc, cols,
+                     accumulate ? 1 : 0);
+}
+
+void launch_add_diag_vec(hipStream_t s, double* A, int64_t ld, const double* noise, double extra, int64_t n) {
+  hipLaunchKernelGGL(add_diag_vec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A, ld, noise,
+                     extra, n);
+}
+
+void launch_vec_mul(hipStream_t s, const double* a, const double* b, double* out, int64_t n) {
+  hipLaunchKernelGGL(vec_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, out, n);
+}
+
+void launch_mix_rowsum(hipStream_t s, const double* iK, const double* Km, int64_t ld, const double* alpha,
+                       const double* g, double* h, int64_t n) {
+  hipLaunchKernelGGL(mix_rowsum_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, iK, Km, ld, alpha, g, h,
+                     n);
+}

@@ -53,6 +53,52 @@ class GpEngine:
                     dptr(out), info.ctypes.data_as(C.POINTER(C.c_int)))
         return out, info
 
+    # -- mixture covariance (ChangePoint): sub-kernel ids / parameter vectors + per-point weights ------------
+    @staticmethod
+    def _mix_args(kernels, thetas, weights):
+        ks = np.ascontiguousarray(kernels, dtype=np.int32)
+        nts = np.ascontiguousarray([len(t) for t in thetas], dtype=np.int32)
+        th = as_f64(np.concatenate([np.asarray(t, dtype=float) for t in thetas]))
+        g = as_f64(weights)
+        ip = C.POINTER(C.c_int)
+        return len(ks), ks, ks.ctypes.data_as(ip), th, nts, nts.ctypes.data_as(ip), g
+
+    def fit_mix(self, kernels, thetas, weights, extra_diag, mu):
+        nk, ks, kp, th, nts, ntp, g = self._mix_args(kernels, thetas, weights)
+        mu = as_f64(mu)
+        alpha = np.empty(self.n)
+        logdet, info = C.c_double(0.0), C.c_int(0)
+        self.h.call("gpmi_fit_mix", nk, kp, dptr(th), ntp, dptr(g), float(extra_diag), dptr(mu), dptr(alpha),
+                    C.byref(logdet), C.byref(info))
+        return alpha, logdet.value, info.value
+
+    def lml_mix(self, kernels, thetas, weights, extra_diag, mu):
+        nk, ks, kp, th, nts, ntp, g = self._mix_args(kernels, thetas, weights)
+        mu = as_f64(mu)
+        out, info = C.c_double(0.0), C.c_int(0)
+        self.h.call("gpmi_lml_mix", nk, kp, dptr(th), ntp, dptr(g), float(extra_diag), dptr(mu), C.byref(out),
+                    C.byref(info))
+        return out.value, info.value
+
+    def lml_grad_mix(self, kernels, thetas, weights, extra_diag, mu):
+        nk, ks, kp, th, nts, ntp, g = self._mix_args(kernels, thetas, weights)
+        mu = as_f64(mu)
+        lml, info = C.c_double(0.0), C.c_int(0)
+        grad = np.empty(th.size)
+        hrows = np.empty((nk, self.n))
+        alpha = np.empty(self.n)
+        self.h.call("gpmi_lml_grad_mix", nk, kp, dptr(th), ntp, dptr(g), float(extra_diag), dptr(mu),
+                    C.byref(lml), dptr(grad), dptr(hrows), dptr(alpha), C.byref(info))
+        return lml.value, grad, hrows, alpha, info.value
+
+    def predict_mix(self, pts, query_weights):
+        p = as_f64(pts)
+        gq = as_f64(query_weights)
+        m = p.shape[0]
+        mu, nss = np.empty(m), np.empty(m)
+        self.h.call("gpmi_predict_mix", dptr(p), m, dptr(gq), dptr(mu), dptr(nss))
+        return mu, nss
+
     def set_noise(self, noise_var):
         self.h.call("gpmi_set_noise", dptr(as_f64(noise_var)))
 

@@ -1,6 +1,6 @@
 """Device-backed Gaussian-process classes; the public names are those of `inference.gp`
 (reference inference/gp/__init__.py)."""
-from inference_amd.gp.covariance import HeteroscedasticNoise, RationalQuadratic, SquaredExponential, WhiteNoise
+from inference_amd.gp.covariance import ChangePoint, HeteroscedasticNoise, RationalQuadratic, SquaredExponential, WhiteNoise
 from inference_amd.gp.mean import ConstantMean, LinearMean, QuadraticMean
 from inference_amd.gp.acquisition import ExpectedImprovement, MaxVariance, UpperConfidenceBound
 from inference_amd.gp.regression import GpRegressor

@@ -18,6 +18,8 @@ kept for code that calls them and evaluate on the device as well.
 """
 from abc import ABC, abstractmethod
 
+from inspect import isclass
+
 import numpy as np
 from numpy import exp, log, ndarray
 
@@ -321,21 +323,155 @@ class CompositeCovariance(CovarianceFunction):
         return K, grads
 
 
+class ChangePoint(CovarianceFunction):
+    r"""
+    Change-point covariance (reference: covariance.py:371-606): the input space is divided along one axis
+    into regions, each with its own kernel, blended by logistic windows f_i(x) = 1 / (1 + exp(-(x - c_i) / w_i)):
+
+       K(u, v) = sum_m g_m(u) g_m(v) K_m(u, v),   g_0 = 1 - f_0,  g_m = f_{m-1} (1 - f_m),  g_last = f_last
+
+    theta = [theta_K0, theta_K1, .., c_0, w_0, c_1, w_1, ..].  Because the coefficients factorise over the two
+    points, K is a sum of stationary kernels scaled by per-point weights: on the device every K_m comes from the
+    ordinary covariance-build kernel and is folded in with its weights (`gpmi_fit_mix`, `gpmi_lml_mix`,
+    `gpmi_lml_grad_mix`, `gpmi_predict_mix`); the weights cost O(N) and are formed here.
+
+    :param kernels: the kernels of the regions, instances or classes (device path: SquaredExponential /
+        RationalQuadratic, at most four).
+    :param axis: the spatial axis along which the regions follow each other.
+    :param location_bounds, width_bounds: optional (lower, upper) pairs, one per change-point.
+    """
+
+    def __init__(self, kernels, axis: int = 0, location_bounds=None, width_bounds=None):
+        self.cov = [K() if isclass(K) and issubclass(K, CovarianceFunction) else K for K in kernels]
+        for K in self.cov:
+            if not isinstance(K, CovarianceFunction):
+                raise TypeError(
+                    "\n\n[ ChangePoint error ]\n>> Each of the specified covariance kernels must be an instance of"
+                    "\n>> a class which inherits from the 'CovarianceFunction' abstract\n>> base-class.\n"
+                )
+        self.n_kernels = len(kernels)
+
+        def pairs(bounds, what):
+            if bounds is None:
+                return None
+            if len(bounds) != self.n_kernels - 1:
+                raise ValueError(
+                    f"\n\n[ ChangePoint error ]\n>> The length of '{what}' must be one less than the number of kernels\n"
+                )
+            for b in bounds:
+                assert type(b) in [list, tuple, ndarray] and len(b) == 2 and b[1] > b[0]
+            return list(bounds)
+
+        self.location_bounds = pairs(location_bounds, "location_bounds")
+        self.width_bounds = pairs(width_bounds, "width_bounds")
+        self.axis = axis
+        self.bounds = None
+
+    def pass_spatial_data(self, x: ndarray):
+        for K in self.cov:
+            K.pass_spatial_data(x)
+        counts = [K.n_params for K in self.cov] + [2] * (self.n_kernels - 1)
+        self.n_params = sum(counts)
+        slices = slice_builder(counts)
+        self.cov_slc = slices[: self.n_kernels]
+        self.cp_slc = slices[self.n_kernels:]
+        self.hyperpar_labels = [f"ChngPnt K{i}: {lab}" for i, K in enumerate(self.cov) for lab in K.hyperpar_labels]
+        for i in range(self.n_kernels - 1):
+            self.hyperpar_labels += [f"ChngPnt{i} location", f"ChngPnt{i} width"]
+        self.x_cp = x[:, self.axis]
+
+    def estimate_hyperpar_bounds(self, y: ndarray):
+        lo, hi = self.x_cp.min(), self.x_cp.max()
+        span = hi - lo
+        self.bounds = []
+        for K in self.cov:
+            K.estimate_hyperpar_bounds(y)
+            self.bounds.extend(K.bounds)
+        if self.location_bounds is None:
+            self.location_bounds = [(lo, hi)] * (self.n_kernels - 1)
+        if self.width_bounds is None:
+            self.width_bounds = [(5e-3 * span, 0.5 * span)] * (self.n_kernels - 1)
+        for loc, wid in zip(self.location_bounds, self.width_bounds):
+            self.bounds += [loc, wid]
+
+    # -- the per-point weights ---------------------------------------------------------------
+    @staticmethod
+    def logistic(x, theta):
+        z = (x - theta[0]) / theta[1]
+        return 1.0 / (1.0 + exp(-z))
+
+    @staticmethod
+    def logistic_and_gradient(x, theta):
+        z = (x - theta[0]) / theta[1]
+        f = 1.0 / (1.0 + exp(-z))
+        dfdc = -f * (1 - f) / theta[1]
+        return f, [dfdc, dfdc * z]
+
+    def weights(self, axis_values, theta):
+        """g_m at the given coordinates along the change-point axis: array (n_kernels, len(axis_values))."""
+        g = [np.ones_like(axis_values, dtype=float)]
+        for slc in self.cp_slc:
+            f = self.logistic(axis_values, theta[slc])
+            g[-1] = g[-1] * (1 - f)
+            g.append(f)
+        return np.array(g)
+
+    def device_terms(self, theta):
+        """(kernel ids, sub-kernel parameter vectors) for the gpmi_*_mix entry points."""
+        return [K._gpmi_kernel for K in self.cov], [np.asarray(theta[s], dtype=float) for s in self.cov_slc]
+
+    # -- plugin methods (host composition of the sub-kernels' device results) --------------------
+    def __call__(self, u: ndarray, v: ndarray, theta: ndarray) -> ndarray:
+        gu, gv = self.weights(u[:, self.axis], theta), self.weights(v[:, self.axis], theta)
+        return sum(K(u, v, theta[s]) * (a[:, None] * b[None, :]) for K, s, a, b in zip(self.cov, self.cov_slc, gu, gv))
+
+    def build_covariance(self, theta: ndarray) -> ndarray:
+        g = self.weights(self.x_cp, theta)
+        return sum(K.build_covariance(theta[s]) * (a[:, None] * a[None, :]) for K, s, a in zip(self.cov, self.cov_slc, g))
+
+    def covariance_and_gradients(self, theta: ndarray):
+        parts = [K.covariance_and_gradients(theta[s]) for K, s in zip(self.cov, self.cov_slc)]
+        coeffs, w_vals, w_grads = [1.0], [], []
+        for slc in self.cp_slc:
+            w, dw = self.logistic_and_gradient(self.x_cp, theta[slc])
+            coeffs[-1] = coeffs[-1] * ((1 - w)[:, None] * (1 - w)[None, :])
+            coeffs.append(w[:, None] * w[None, :])
+            w_vals.append(w)
+            w_grads.append(dw)
+        K = sum(p[0] * c for p, c in zip(parts, coeffs))
+        grads = [dK * c for p, c in zip(parts, coeffs) for dK in p[1]]
+        for i, (w, dws) in enumerate(zip(w_vals, w_grads)):
+            for dw in dws:  # covariance.py:588-593
+                A = -dw[:, None] * (1 - w)[None, :]
+                B = dw[:, None] * w[None, :]
+                grads.append(parts[i][0] * (A + A.T) + parts[i + 1][0] * (B + B.T))
+        return K, grads
+
+
+def _is_device_mixture(comp):
+    return (isinstance(comp, ChangePoint) and 2 <= comp.n_kernels <= 4
+            and all(isinstance(K, _StationaryDeviceKernel) for K in comp.cov))
+
+
 def device_plan(cov):
     """How `GpRegressor` maps a covariance object onto the device kernels:
-    returns (kernel_id, stationary_component, slice_of_its_theta, white_noise_index or None)
-    or None when the object is not a supported combination: one of the stationary kernels, optionally plus
-    one WhiteNoise and / or one HeteroscedasticNoise (see `heteroscedastic_slice`)."""
+    returns (kernel_id, main_component, slice_of_its_theta, white_noise_index or None)
+    or None when the object is not a supported combination: one stationary kernel (SquaredExponential /
+    RationalQuadratic) or one ChangePoint over such kernels (kernel_id -1), optionally plus one WhiteNoise
+    and / or one HeteroscedasticNoise (see `heteroscedastic_slice`)."""
     if isinstance(cov, _StationaryDeviceKernel):
         return cov._gpmi_kernel, cov, slice(0, cov.n_params), None
+    if _is_device_mixture(cov):
+        return -1, cov, slice(0, cov.n_params), None
     if isinstance(cov, CompositeCovariance):
-        stat = [(i, c) for i, c in enumerate(cov.components) if isinstance(c, _StationaryDeviceKernel)]
+        main = [(i, c) for i, c in enumerate(cov.components)
+                if isinstance(c, _StationaryDeviceKernel) or _is_device_mixture(c)]
         wn = [(i, c) for i, c in enumerate(cov.components) if isinstance(c, WhiteNoise)]
         het = [c for c in cov.components if isinstance(c, HeteroscedasticNoise)]
-        if len(stat) == 1 and len(wn) <= 1 and len(het) <= 1 and len(stat) + len(wn) + len(het) == len(cov.components):
-            i, c = stat[0]
+        if len(main) == 1 and len(wn) <= 1 and len(het) <= 1 and len(main) + len(wn) + len(het) == len(cov.components):
+            i, c = main[0]
             wn_index = cov.slices[wn[0][0]].start if wn else None
-            return c._gpmi_kernel, c, cov.slices[i], wn_index
+            return (c._gpmi_kernel if isinstance(c, _StationaryDeviceKernel) else -1), c, cov.slices[i], wn_index
     return None
 
 

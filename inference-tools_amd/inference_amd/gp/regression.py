@@ -94,6 +94,7 @@ class GpRegressor:
         if plan is None:
             raise NotImplementedError(msg.no_device_kernel(type(self.cov)))
         self._kernel_id, self._stat, self._stat_slice, self._wn_index = plan
+        self._mix = self._stat if self._kernel_id == -1 else None  # ChangePoint: mixture entry points
         self._het_slice = heteroscedastic_slice(self.cov)
         self._fit_noise = None
         self._device = device
@@ -171,6 +172,16 @@ class GpRegressor:
         base = np.zeros(self.n_points) if self._noise_var is None else self._noise_var
         return base + np.exp(2 * np.asarray(theta_cov, dtype=float)[self._het_slice])
 
+    def _mix_args(self, theta_cp):
+        """(kernel ids, sub-kernel parameter vectors, training-point weights) of a ChangePoint block."""
+        kernels, thetas = self._mix.device_terms(theta_cp)
+        return kernels, thetas, self._mix.weights(self._mix.x_cp, theta_cp)
+
+    def _refit_mixture_if_stale(self):
+        # the fitted mixture's weights share a device buffer with the likelihood evaluations
+        if self._mix is not None and getattr(self, "_mix_fit_stale", False):
+            self.set_hyperparameters(self.hyperpars)
+
     @property
     def sig(self) -> ndarray:
         """Dense data-error covariance as in the reference (regression.py:320-322)."""
@@ -182,6 +193,9 @@ class GpRegressor:
 
     @property
     def K_xx(self) -> ndarray:
+        if self._K_cache is None and self._mix is not None:
+            # host composition of the sub-kernels' device builds (ChangePoint.build_covariance) + sig
+            self._K_cache = self.cov.build_covariance(np.asarray(self.cov_hyperpars, dtype=float)) + self.sig
         if self._K_cache is None:
             if self._fit_noise is not None:  # a later evaluation may have left other per-point variances behind
                 self.engine.set_noise(self._fit_noise)
@@ -201,7 +215,16 @@ class GpRegressor:
         """Mean and standard deviation of the regression estimate at `points`
         (regression.py:188-216), evaluated as one batched device call."""
         p = self.process_points(points)
-        mu, var = self.engine.predict(p)
+        self._refit_mixture_if_stale()
+        if self._mix is not None:
+            theta_cp = np.asarray(self.cov_hyperpars, dtype=float)[self._stat_slice]
+            gq = self._mix.weights(p[:, self._mix.axis], theta_cp)
+            mu, neg = self.engine.predict_mix(p, gq)
+            # K_qq[0, 0] = sum_m g_m(q)^2 a_m^2: cross-covariances carry neither jitter nor noise (covariance.py:529-544)
+            amp2 = np.array([np.exp(2 * theta_cp[s][0]) for s in self._mix.cov_slc])
+            var = (gq**2 * amp2[:, None]).sum(axis=0) + neg
+        else:
+            mu, var = self.engine.predict(p)
         mean_q = array([self.mean(q, self.mean_hyperpars) for q in p[:, None, :]])
         return mu + mean_q, sqrt(abs(var))
 
@@ -217,7 +240,11 @@ class GpRegressor:
         self._fit_noise = self._noise_total(self.cov_hyperpars) if self._het_slice is not None else None
         self._K_cache = None
         self._L_cache = None
-        alpha, logdet, info = self.engine.fit(self._kernel_id, theta_stat, extra, self.mu)
+        if self._mix is not None:
+            alpha, logdet, info = self.engine.fit_mix(*self._mix_args(theta_stat), extra, self.mu)
+        else:
+            alpha, logdet, info = self.engine.fit(self._kernel_id, theta_stat, extra, self.mu)
+        self._mix_fit_stale = False
         if info != 0:
             raise LinAlgError("Matrix is not positive definite")  # numpy.linalg.cholesky, regression.py:241
         self.alpha = alpha
@@ -268,6 +295,8 @@ class GpRegressor:
         return q
 
     def _require_gradient_terms(self):
+        if self._mix is not None:
+            self._mix.gradient_terms(None, None, None)  # ChangePoint has none either (covariance.py:38-44)
         if self._kernel_id != 0:
             # RationalQuadratic has no gradient_terms (covariance.py:38-44): same error as the reference
             self._stat.gradient_terms(None, None, None)
@@ -286,8 +315,13 @@ class GpRegressor:
         dmu, dvar = self.engine.spatial_derivatives(p)
         return dmu.squeeze(), dvar.squeeze()
 
+    def _no_mixture(self, what):
+        if self._mix is not None:
+            raise NotImplementedError(f"{what} is not available on the device for ChangePoint kernels yet")
+
     def build_posterior(self, points: ndarray, mean_only=False):
         """Posterior mean vector and covariance matrix (regression.py:421-449)."""
+        self._no_mixture("build_posterior")
         v = self.process_points(points)
         mu, sigma = self.engine.posterior(v, mean_only=mean_only)
         mu = mu + array([self.mean(p, self.mean_hyperpars) for p in v])
@@ -297,11 +331,13 @@ class GpRegressor:
 
     def loo_predictions(self):
         """Leave-one-out predictions, R&W eq. 5.12 (regression.py:451-466)."""
+        self._refit_mixture_if_stale()
         var = 1.0 / self.engine.loo_diag()
         return self.y - self.alpha * var, sqrt(var)
 
     def loo_likelihood(self, theta: ndarray) -> float:
         """Leave-one-out log-likelihood, R&W eqs. 5.10-5.12 (regression.py:468-487)."""
+        self._no_mixture("loo_likelihood")
         theta = np.asarray(theta, dtype=float)
         theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
         mu = self.mean.build_mean(theta[self.mean_slice])
@@ -314,6 +350,7 @@ class GpRegressor:
 
     def loo_likelihood_gradient(self, theta: ndarray):
         """LOO log-likelihood and its gradient, R&W eqs. 5.10-5.14 (regression.py:489-526)."""
+        self._no_mixture("loo_likelihood_gradient")
         theta = np.asarray(theta, dtype=float)
         if self._het_slice is not None:
             raise NotImplementedError("loo_likelihood_gradient: HeteroscedasticNoise has no device gradient yet")
@@ -339,7 +376,11 @@ class GpRegressor:
         theta = np.asarray(theta, dtype=float)
         theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
         mu = self.mean.build_mean(theta[self.mean_slice])
-        value, info = self.engine.lml(self._kernel_id, theta_stat, extra, mu)
+        if self._mix is not None:
+            value, info = self.engine.lml_mix(*self._mix_args(theta_stat), extra, mu)
+            self._mix_fit_stale = True
+        else:
+            value, info = self.engine.lml(self._kernel_id, theta_stat, extra, mu)
         if info != 0:
             warn("Cholesky decomposition failure in marginal_likelihood")
             return -1e50
@@ -349,7 +390,7 @@ class GpRegressor:
         """(extension) `marginal_likelihood` for T hyper-parameter vectors at once, spread over
         the device's worker streams — the unit the grid sweep / PT driver shards over GPUs."""
         thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
-        if self._het_slice is not None:  # per-point variances change with theta: one evaluation at a time
+        if self._het_slice is not None or self._mix is not None:  # per-point terms change with theta: one at a time
             return np.array([self.marginal_likelihood(t) for t in thetas])
         split = [self._split_cov_theta(t[self.cov_slice]) for t in thetas]
         th = np.array([s[0] for s in split])
@@ -368,7 +409,10 @@ class GpRegressor:
         theta = np.asarray(theta, dtype=float)
         theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
         mu, grad_mu = self.mean.mean_and_gradients(theta[self.mean_slice])
-        lml, g_stat, trace_q, alpha, info = self.engine.lml_grad(self._kernel_id, theta_stat, extra, mu)
+        if self._mix is not None:
+            lml, g_stat, alpha, trace_q, info = self._mixture_gradient(theta_stat, extra, mu)
+        else:
+            lml, g_stat, trace_q, alpha, info = self.engine.lml_grad(self._kernel_id, theta_stat, extra, mu)
         if info != 0:
             raise LinAlgError("Matrix is not positive definite")  # regression.py:555 has no guard
         grad = zeros(self.n_hyperpars)
@@ -382,6 +426,25 @@ class GpRegressor:
             g_cov[self._het_slice] = np.exp(2 * theta[self.cov_slice][self._het_slice]) * self.engine.lml_grad_qdiag()
         grad[self.cov_slice] = g_cov
         return lml, grad
+
+    def _mixture_gradient(self, theta_cp, extra, mu):
+        """LML gradient with respect to a ChangePoint block (covariance.py:561-594): the sub-kernels' parameters
+        from the device contraction on the weight-scaled inverse, the window parameters from the device row
+        sums h_m(i) = sum_j Q_ij K_m,ij g_m(j) contracted here with d g_m / d phi."""
+        cp = self._mix
+        if cp.n_kernels != 2:
+            raise NotImplementedError("ChangePoint gradients on the device: two regions only (the reference's "
+                                      "expression, covariance.py:588-593, is exact for two)")
+        kernels, thetas, g = self._mix_args(theta_cp)
+        lml, g_sub, hrows, alpha, info = self.engine.lml_grad_mix(kernels, thetas, g, extra, mu)
+        self._mix_fit_stale = True
+        grad = zeros(cp.n_params)
+        grad[: g_sub.size] = g_sub
+        w, dws = cp.logistic_and_gradient(cp.x_cp, theta_cp[cp.cp_slc[0]])
+        # 1/2 sum Q o (K_0 o (A + A^T) + K_1 o (B + B^T)), A = -dw (1 - w)^T, B = dw w^T  =  sum_i dw_i (h_1 - h_0)_i
+        grad[cp.cp_slc[0]] = [float((dw * (hrows[1] - hrows[0])).sum()) for dw in dws]
+        trace_q = float(self.engine.lml_grad_qdiag().sum()) if self._wn_index is not None else 0.0
+        return lml, grad, alpha, trace_q, info
 
     # ---------------------------------------------------------------------------------
     # hyper-parameter search (regression.py:569-605): SciPy drivers on the host, every

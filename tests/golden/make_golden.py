@@ -18,6 +18,7 @@ Cases
   cfg4       BASELINE config 4: SE, N=4096, d=4, 1000 EI candidates
   cfg2       BASELINE config 2: SE, N=8192, d=8 (needs ~16 GB RSS, several minutes)
   fail       a theta for which numpy.linalg.cholesky raises (pins the -1e50 path)
+  cp         ChangePoint over [SE, SE], [SE, RQ], [SE, SE] + WhiteNoise, N=200 d=2
   het        SE + HeteroscedasticNoise, N=96: LML, gradient (99 parameters), fit + predict
   linv       GpLinearInverter: 1-D deconvolution (32 x 64) and 2-D tomography (300 x 400), SE / RQ / SE+WhiteNoise
 """
@@ -50,6 +51,7 @@ from inference.gp import (  # noqa: E402
     RationalQuadratic,
     WhiteNoise,
     HeteroscedasticNoise,
+    ChangePoint,
     ExpectedImprovement,
     UpperConfidenceBound,
     MaxVariance,
@@ -310,6 +312,46 @@ def case_pt():
     return out
 
 
+def case_cp():
+    """ChangePoint (covariance.py:371-606) over [SE, SE], [SE, RQ] and [SE, SE] + WhiteNoise on a 200-point 2-D
+    set whose smoothness changes along axis 0: labels, bounds, LML, LML gradient, fit (K_xx, alpha) + predict."""
+    n, d = 200, 2
+    rng = np.random.default_rng(4242)
+    x = rng.uniform(0, 1, (n, d))
+    y = np.where(x[:, 0] < 0.5, np.sin(3 * x[:, 0] + x[:, 1]), np.sin(25 * x[:, 0]) * np.cos(9 * x[:, 1])) + 0.05 * rng.normal(size=n)
+    e = np.full(n, 0.05)
+    pts = rng.uniform(0, 1, (50, d))
+    out = {"x": x, "y": y, "y_err": e, "pts": pts}
+    for tag, subs, wn in (("sese", (wl.SE, wl.SE), False), ("serq", (wl.SE, wl.RQ), False), ("sesewn", (wl.SE, wl.SE), True)):
+        cov = ChangePoint(kernels=[kernel_cls(k) for k in subs])
+        if wn:
+            cov = cov + WhiteNoise()
+        thetas = []
+        for k in range(3):
+            th = [0.1 * k]
+            for kid, ell in zip(subs, (0.4, 0.08)):
+                th += [-0.2 + 0.1 * k] + ([0.2] if kid == wl.RQ else []) + [np.log(ell) + 0.05 * k, np.log(ell * 2) - 0.05 * k]
+            th += [0.45 + 0.03 * k, 0.05 + 0.02 * k]
+            if wn:
+                th.append(np.log(0.03) + 0.2 * k)
+            thetas.append(np.array(th))
+        gp = GpRegressor(x, y, y_err=e, kernel=cov, hyperpars=thetas[1])
+        out[f"{tag}_thetas"] = np.array(thetas)
+        out[f"{tag}_labels"] = np.array(gp.hyperpar_labels)
+        out[f"{tag}_bounds"] = np.array(gp.hp_bounds, dtype=float)
+        out[f"{tag}_alpha"] = gp.alpha
+        out[f"{tag}_K_xx"] = gp.K_xx
+        mu, sig = gp(pts)
+        out[f"{tag}_mu"], out[f"{tag}_sig"] = mu, sig
+        out[f"{tag}_lml"] = np.array([gp.marginal_likelihood(t) for t in thetas])
+        res = [gp.marginal_likelihood_gradient(t) for t in thetas]
+        out[f"{tag}_lml2"] = np.array([r[0] for r in res])
+        out[f"{tag}_grad"] = np.array([r[1] for r in res])
+        loo_mu, loo_sig = gp.loo_predictions()
+        out[f"{tag}_loo_mu"], out[f"{tag}_loo_sig"] = loo_mu, loo_sig
+    return out
+
+
 def case_het():
     """SquaredExponential + HeteroscedasticNoise (covariance.py:608-690) on a 96-point 1-D set (the
     reference's HeteroscedasticNoise.__call__ sizes its zero block by u.size, covariance.py:671-672, so its
@@ -370,6 +412,7 @@ def case_linv():
 IDX_TOMO = np.arange(0, 400, 7)  # 58 rows / columns of the 400 x 400 posterior covariance
 
 CASES = {
+    "cp": case_cp,
     "het": case_het,
     "linv": case_linv,
     "pt": case_pt,

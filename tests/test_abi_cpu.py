@@ -86,3 +86,36 @@ def test_host_side_kernel_mirrors_against_reference_vectors(golden):
     assert np.array_equal(np.diagonal(Kh), np.exp(2 * th[2:])) and np.count_nonzero(Kh) == 96
     assert len(grads) == 96 and grads[5][5, 5] == 2 * Kh[5, 5] and np.count_nonzero(grads[5]) == 1
     assert het(x[:3], x, th[2:]).shape == (3, 96)
+
+
+def test_change_point_host_side_against_reference_vectors(golden):
+    """ChangePoint's O(N) host parts (labels, bounds, the per-point weights the device entry points take)."""
+    import numpy as np
+
+    from inference_amd.gp.covariance import ChangePoint, RationalQuadratic, SquaredExponential, WhiteNoise, device_plan
+
+    g = golden("cp")
+    x, y = g["x"], g["y"]
+    cov = ChangePoint(kernels=[SquaredExponential, RationalQuadratic]) + WhiteNoise()
+    cov.pass_spatial_data(x)
+    cov.estimate_hyperpar_bounds(y)
+    plan = device_plan(cov)
+    assert plan is not None and plan[0] == -1 and plan[2] == slice(0, 9) and plan[3] == 9
+    cp = ChangePoint(kernels=[SquaredExponential, RationalQuadratic])
+    cp.pass_spatial_data(x)
+    cp.estimate_hyperpar_bounds(y)
+    assert cp.hyperpar_labels == list(g["serq_labels"])[1:]
+    assert np.allclose(np.array(cp.bounds, dtype=float), g["serq_bounds"][1:], rtol=1e-12)
+    th = g["serq_thetas"][1][1:]
+    w = cp.weights(x[:, 0], th)
+    f = 1.0 / (1.0 + np.exp(-(x[:, 0] - th[7]) / th[8]))
+    assert w.shape == (2, 200) and np.allclose(w[0], 1 - f) and np.allclose(w[1], f)
+    kernels, thetas = cp.device_terms(th)
+    assert kernels == [0, 1] and [t.size for t in thetas] == [3, 4]
+    three = ChangePoint(kernels=[SquaredExponential] * 3)
+    three.pass_spatial_data(x)
+    w3 = three.weights(x[:, 0], np.array([0, 0, 0, 0, 0, 0, 0, 0, 0, 0.3, 0.05, 0.7, 0.05]))
+    f0 = 1.0 / (1.0 + np.exp(-(x[:, 0] - 0.3) / 0.05))
+    f1 = 1.0 / (1.0 + np.exp(-(x[:, 0] - 0.7) / 0.05))
+    # the coefficient recursion of covariance.py:529-544: [1 - f0, f0 (1 - f1), f1]
+    assert np.allclose(w3[0], 1 - f0) and np.allclose(w3[1], f0 * (1 - f1)) and np.allclose(w3[2], f1)

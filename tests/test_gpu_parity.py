@@ -619,3 +619,62 @@ def test_heteroscedastic_noise_vs_reference(golden, gp_mod, tag, with_err):
     mu, sig = gp(wl.query_points(77, 40, d))
     check(mu, g[f"{tag}_mu"], what="mu")
     check(sig, g[f"{tag}_sig"], what="sig")
+
+
+# ---------------------------------------------------------------------------------------
+# ChangePoint: mixture of stationary kernels with per-point weights
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,subs,wn", [("sese", (wl.SE, wl.SE), False), ("serq", (wl.SE, wl.RQ), False),
+                                          ("sesewn", (wl.SE, wl.SE), True)])
+def test_change_point_vs_reference(golden, gp_mod, tag, subs, wn):
+    """Labels, bounds, fit (K_xx, alpha), predict, LML and the full LML gradient (sub-kernel parameters, change-point
+    location / width, WhiteNoise) and the leave-one-out predictions against the reference."""
+    g = golden("cp")
+    x, y, e, pts = g["x"], g["y"], g["y_err"], g["pts"]
+    th = g[f"{tag}_thetas"]
+    cov = gp_mod.ChangePoint(kernels=[kernel_cls(gp_mod, k) for k in subs])
+    if wn:
+        cov = cov + gp_mod.WhiteNoise()
+    gp = gp_mod.GpRegressor(x, y, y_err=e, kernel=cov, hyperpars=th[1])
+    assert list(g[f"{tag}_labels"]) == gp.hyperpar_labels
+    check(np.array(gp.hp_bounds, dtype=float), g[f"{tag}_bounds"], 1e-12, "bounds")
+    check(gp.alpha, g[f"{tag}_alpha"], what="alpha")
+    check(gp.K_xx, g[f"{tag}_K_xx"], 1e-13, "K_xx")
+    mu, sig = gp(pts)
+    check(mu, g[f"{tag}_mu"], what="mu")
+    check(sig, g[f"{tag}_sig"], what="sig")
+    check([gp.marginal_likelihood(t) for t in th], g[f"{tag}_lml"], what="lml")
+    res = [gp.marginal_likelihood_gradient(t) for t in th]
+    check([r[0] for r in res], g[f"{tag}_lml2"], what="lml (gradient call)")
+    check([r[1] for r in res], g[f"{tag}_grad"], 1e-9, "gradient")
+    # the likelihood evaluations above used other hyper-parameters: the fitted state must be restored lazily
+    mu2, sig2 = gp(pts)
+    check(mu2, g[f"{tag}_mu"], what="mu after other evaluations")
+    loo_mu, loo_sig = gp.loo_predictions()
+    check(loo_mu, g[f"{tag}_loo_mu"], what="loo mean")
+    check(loo_sig, g[f"{tag}_loo_sig"], what="loo sigma")
+
+
+def test_change_point_search_and_limits(gp_mod):
+    """Hyper-parameter search through the mixture path (L-BFGS-B with the analytic gradient); three regions
+    work for fit / predict / LML but not for the gradient; unsupported sub-kernels are refused."""
+    rng = np.random.default_rng(11)
+    x = np.sort(rng.uniform(0, 1, 120)).reshape(-1, 1)
+    y = np.where(x[:, 0] < 0.5, np.sin(4 * x[:, 0]), np.sin(40 * x[:, 0])) + 0.05 * rng.normal(size=120)
+    e = np.full(120, 0.05)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gp = gp_mod.GpRegressor(x, y, y_err=e, kernel=gp_mod.ChangePoint(kernels=[gp_mod.SquaredExponential] * 2))
+    start = np.array([b[0] + 0.5 * (b[1] - b[0]) for b in gp.hp_bounds])
+    assert gp.marginal_likelihood(gp.hyperpars) >= gp.marginal_likelihood(start)
+    mu, sig = gp(x)
+    assert np.abs(mu - y).mean() < 0.2
+    cp3 = gp_mod.ChangePoint(kernels=[gp_mod.SquaredExponential] * 3)
+    th3 = np.array([0.0, 0.0, np.log(0.3), 0.0, np.log(0.05), 0.0, np.log(0.3), 0.35, 0.03, 0.7, 0.03])
+    gp3 = gp_mod.GpRegressor(x, y, y_err=e, kernel=cp3, hyperpars=th3)
+    assert np.isfinite(gp3.marginal_likelihood(th3)) and np.isfinite(gp3(x[:5])[0]).all()
+    with pytest.raises(NotImplementedError):
+        gp3.marginal_likelihood_gradient(th3)
+    with pytest.raises(NotImplementedError):
+        gp_mod.GpRegressor(x, y, y_err=e, hyperpars=np.zeros(4),
+                           kernel=gp_mod.ChangePoint(kernels=[gp_mod.SquaredExponential, gp_mod.WhiteNoise]))
