@@ -200,6 +200,9 @@ int gpmi_lml_grad_mix(gpmi_ctx* ctx, int nk, const int* kernels, const double* t
  * mu* = k.alpha (the host adds the mean function), negsumsq = -|L^-1 k|^2 (the host adds K_qq[0, 0]) */
 int gpmi_predict_mix(gpmi_ctx* ctx, const double* pts_host, int64_t m, const double* gq_host,
                      double* mu_host, double* negsumsq_host);
+/* build_posterior (regression.py:421-449) with the model of gpmi_fit_mix: mu = K_qx alpha, cov = K_qq - Q^T Q */
+int gpmi_posterior_mix(gpmi_ctx* ctx, const double* pts_host, int64_t m, const double* gq_host,
+                       double* mu_host, double* cov_host);
 
 /* ---- Gaussian-process linear inversion (inference/gp/inversion.py) --------------------
  * The model parameters (n of them, at the positions given to gpmi_set_data as x; y / noise of that call are

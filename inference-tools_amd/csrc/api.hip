@@ -1434,6 +1434,59 @@ int gpmi_predict_mix(gpmi_ctx* c, const double* pts, int64_t m, const double* gq
   return GPMI_OK;
 }
 
+int gpmi_posterior_mix(gpmi_ctx* c, const double* pts, int64_t m, const double* gq_host, double* mu_out,
+                       double* cov_out) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->fitted && c->mix_nk > 0, "gpmi_posterior_mix needs a successful gpmi_fit_mix");
+  ARGCHK(c, pts && gq_host && m > 0, "NULL argument or m <= 0");
+  if (int rc = set_device(c)) return rc;
+  Lane& L = c->lanes[0];
+  hipStream_t s = L.stream;
+  const int nk = c->mix_nk;
+  const int64_t mp = round_up(m, GPMI_NB);
+  if (int rc = ensure_query_ws(c, mp)) return rc;
+  if (int rc = ensure_q3(c)) return rc;
+  double* gq_dev = c->pvec + 2 * mp;
+  HIPCHK(c, hipMemsetAsync(gq_dev, 0, sizeof(double) * nk * mp, s));
+  HIPCHK(c, hipMemcpyAsync(c->pts, pts, sizeof(double) * m * c->d, hipMemcpyHostToDevice, s));
+  for (int k = 0; k < nk; ++k)
+    HIPCHK(c, hipMemcpyAsync(gq_dev + (int64_t)k * mp, gq_host + (int64_t)k * m, sizeof(double) * m,
+                             hipMemcpyHostToDevice, s));
+  build_mix_cross(c, s, gq_dev, m, mp);
+  double* mu_dev = c->pvec;
+  launch_rows_dot(s, c->Q, c->ld, mp, c->np, c->alpha, mu_dev);
+  if (mu_out) HIPCHK(c, hipMemcpyAsync(mu_out, mu_dev, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+  if (cov_out) {
+    const int64_t ldq = mp + 32;
+    double *Kqq = nullptr, *tmp = nullptr;
+    HIPCHK(c, hipMalloc(&Kqq, sizeof(double) * mp * ldq));
+    hipError_t e = hipMalloc(&tmp, sizeof(double) * mp * ldq);
+    if (e == hipSuccess) {
+      if (int rc = ensure_inv2(c, L, s)) {
+        (void)hipFree(Kqq);
+        (void)hipFree(tmp);
+        return rc;
+      }
+      trsm_rows_forward(c, s, L.A, c->np, c->ld, L.inv2, c->Q, mp, false, c->Q2, nullptr);
+      // K_qq = sum_m diag(gq_m) K_m(pts, pts) diag(gq_m): no jitter, no noise (covariance.py:529-544)
+      for (int k = 0; k < nk; ++k) {
+        launch_kbuild_cross(s, c->mix_p[k], c->pts, m, mp, c->pts, m, mp, tmp, ldq);
+        launch_scale_add(s, Kqq, ldq, tmp, ldq, gq_dev + (int64_t)k * mp, gq_dev + (int64_t)k * mp, mp, mp, k > 0);
+      }
+      launch_gemm_nt(s, TILES_RECT, OP_SUB, Kqq, ldq, c->Q2, c->ld, c->Q2, c->ld, (int)(mp / GPMI_NB),
+                     (int)(mp / GPMI_NB), (int)c->np);
+      e = hipMemcpy2DAsync(cov_out, sizeof(double) * m, Kqq, sizeof(double) * ldq, sizeof(double) * m, m,
+                           hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    (void)hipFree(Kqq);
+    if (tmp) (void)hipFree(tmp);
+    HIPCHK(c, e);
+  }
+  HIPCHK(c, hipStreamSynchronize(s));
+  return GPMI_OK;
+}
+
 }  // extern "C"
 
 // ---- per-point noise hyper-parameters ----------------------------------------------------------------

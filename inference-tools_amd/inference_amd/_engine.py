@@ -99,6 +99,15 @@ class GpEngine:
         self.h.call("gpmi_predict_mix", dptr(p), m, dptr(gq), dptr(mu), dptr(nss))
         return mu, nss
 
+    def posterior_mix(self, pts, query_weights, mean_only=False):
+        p = as_f64(pts)
+        gq = as_f64(query_weights)
+        m = p.shape[0]
+        mu = np.empty(m)
+        cov = None if mean_only else np.empty((m, m))
+        self.h.call("gpmi_posterior_mix", dptr(p), m, dptr(gq), dptr(mu), dptr(cov))
+        return mu, cov
+
     def set_noise(self, noise_var):
         self.h.call("gpmi_set_noise", dptr(as_f64(noise_var)))
 

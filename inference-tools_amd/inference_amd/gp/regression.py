@@ -321,9 +321,13 @@ class GpRegressor:
 
     def build_posterior(self, points: ndarray, mean_only=False):
         """Posterior mean vector and covariance matrix (regression.py:421-449)."""
-        self._no_mixture("build_posterior")
         v = self.process_points(points)
-        mu, sigma = self.engine.posterior(v, mean_only=mean_only)
+        self._refit_mixture_if_stale()
+        if self._mix is not None:
+            theta_cp = np.asarray(self.cov_hyperpars, dtype=float)[self._stat_slice]
+            mu, sigma = self.engine.posterior_mix(v, self._mix.weights(v[:, self._mix.axis], theta_cp), mean_only=mean_only)
+        else:
+            mu, sigma = self.engine.posterior(v, mean_only=mean_only)
         mu = mu + array([self.mean(p, self.mean_hyperpars) for p in v])
         if mean_only:
             return mu

@@ -349,6 +349,8 @@ def case_cp():
         out[f"{tag}_grad"] = np.array([r[1] for r in res])
         loo_mu, loo_sig = gp.loo_predictions()
         out[f"{tag}_loo_mu"], out[f"{tag}_loo_sig"] = loo_mu, loo_sig
+        pm, pc = gp.build_posterior(pts[:20])
+        out[f"{tag}_post_mu"], out[f"{tag}_post_cov"] = pm, pc
     return out
 
 

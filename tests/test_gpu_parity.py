@@ -653,6 +653,9 @@ def test_change_point_vs_reference(golden, gp_mod, tag, subs, wn):
     loo_mu, loo_sig = gp.loo_predictions()
     check(loo_mu, g[f"{tag}_loo_mu"], what="loo mean")
     check(loo_sig, g[f"{tag}_loo_sig"], what="loo sigma")
+    pm, pc = gp.build_posterior(pts[:20])
+    check(pm, g[f"{tag}_post_mu"], what="posterior mean")
+    check(pc, g[f"{tag}_post_cov"], 1e-9, "posterior covariance")
 
 
 def test_change_point_search_and_limits(gp_mod):
