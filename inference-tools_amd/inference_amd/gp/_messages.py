@@ -76,3 +76,28 @@ def no_device_kernel(cov_type):
 NEW_Y_ERR_REQUIRED = framed("GpOptimiser", "error", "'new_y_err' argument of the 'add_evaluation' method must be",
                             "specified if the 'y_err' argument was specified when the",
                             "instance of GpOptimiser was initialised.")
+
+
+def check_inverter_shapes(y, y_err, model_matrix, positions):
+    """Shape checks of GpLinearInverter's constructor (inversion.py:63-113): same conditions, exception type
+    and wording, in the order the reference applies them."""
+    who = "GpLinearInverter"
+    problems = (
+        (model_matrix.ndim != 2, ("'model_matrix' argument must be a 2D numpy.ndarray",)),
+        (y.ndim != y_err.ndim != 1 or y.size != y_err.size,
+         ("'y' and 'y_err' arguments must be 1D numpy.ndarray", "of equal size.")),
+        (model_matrix.ndim == 2 and model_matrix.shape[0] != y.size,
+         ("The size of the first dimension of 'model_matrix' must", "equal the size of 'y', however they have shapes",
+          f"{model_matrix.shape}, {y.shape}", "respectively.")),
+        (positions.ndim != 2,
+         ("'parameter_spatial_positions' must be a 2D numpy.ndarray, with the",
+          "size of first dimension being equal to the number of model parameters",
+          "and the size of the second dimension being equal to the number of", "spatial dimensions.")),
+        (model_matrix.ndim == 2 and positions.ndim == 2 and model_matrix.shape[1] != positions.shape[0],
+         ("The size of the second dimension of 'model_matrix' must be equal",
+          "to the size of the first dimension of 'parameter_spatial_positions',", "however they have shapes",
+          f"{model_matrix.shape}, {positions.shape}", "respectively.")),
+    )
+    for failed, lines in problems:
+        if failed:
+            raise ValueError(framed_plain(who, *lines))

@@ -50,26 +50,7 @@ class GpLinearInverter:
         prior_mean_function: MeanFunction = ConstantMean,
         device=None,
     ):
-        # shape checks of inversion.py:63-113, same exception type and wording
-        if model_matrix.ndim != 2:
-            raise ValueError(msg.framed_plain("GpLinearInverter", "'model_matrix' argument must be a 2D numpy.ndarray"))
-        if y.ndim != y_err.ndim != 1 or y.size != y_err.size:
-            raise ValueError(msg.framed_plain("GpLinearInverter", "'y' and 'y_err' arguments must be 1D numpy.ndarray",
-                                              "of equal size."))
-        if model_matrix.shape[0] != y.size:
-            raise ValueError(msg.framed_plain(
-                "GpLinearInverter", "The size of the first dimension of 'model_matrix' must",
-                "equal the size of 'y', however they have shapes", f"{model_matrix.shape}, {y.shape}", "respectively."))
-        if parameter_spatial_positions.ndim != 2:
-            raise ValueError(msg.framed_plain(
-                "GpLinearInverter", "'parameter_spatial_positions' must be a 2D numpy.ndarray, with the",
-                "size of first dimension being equal to the number of model parameters",
-                "and the size of the second dimension being equal to the number of", "spatial dimensions."))
-        if model_matrix.shape[1] != parameter_spatial_positions.shape[0]:
-            raise ValueError(msg.framed_plain(
-                "GpLinearInverter", "The size of the second dimension of 'model_matrix' must be equal",
-                "to the size of the first dimension of 'parameter_spatial_positions',", "however they have shapes",
-                f"{model_matrix.shape}, {parameter_spatial_positions.shape}", "respectively."))
+        msg.check_inverter_shapes(y, y_err, model_matrix, parameter_spatial_positions)
 
         self.A = model_matrix
         self.y = y
