@@ -192,6 +192,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 
   gload(0);
   sstore(0);
+  // every C load must have landed before the loop: otherwise the compiler, which tracks the pending loads of the
+  // last accumulator registers across the back-edge, places s_waitcnt vmcnt(0) in front of their MFMAs INSIDE
+  // the loop, and each step then also waits for the operand prefetch it has just issued
+  if (OP == OP_SUB) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt / expcnt untouched
   __syncthreads();
   const int nk = (kend - kbeg) / BK;
   for (int kt = 0; kt < nk; ++kt) {
