@@ -168,10 +168,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 
   const int fr = lane & 15, fk = lane >> 4;
   double* Cg = g.C + bz * g.sC + ((int64_t)ti * BM + wr * (BM / 2)) * g.ldc + (int64_t)tj * BN + wc * (BN / 2);
+  const int sw = (fr >= 4 && fr < 12) ? 1 : 0;
+  const int a_off = (wr * (BM / 2) + fr) * LDS_STRIDE + ((fk ^ sw) << 2);
+  const int b_off = BKN ? 4 * fk * LDS_STRIDE_KN + wc * (BN / 2) + fr
+                        : (wc * (BN / 2) + fr) * LDS_STRIDE + ((fk ^ sw) << 2);
+
   // OP_SUB: the accumulators start from the C tile and the A operand is negated on its way into LDS,
-  // so C - A B^T comes out of the MFMA chain itself and the epilogue is stores only.  The 64 loads are
-  // issued together with the first operand slab (one memory latency per tile instead of a
-  // load-wait-store epilogue: ~20 k of a workgroup's ~310 k cycles at K = 512).
+  // so C - A B^T comes out of the MFMA chain itself and the epilogue is stores only.  The first operand slab is
+  // requested BEFORE the 64 C loads and the first 16-deep step is peeled off the loop: its MFMAs wait for
+  // their own accumulator tile only (vmcnt counts in order, the slab is older, the next slab's prefetch newer),
+  // so the C tile streams in under the first step instead of in front of it.  After that step nothing is
+  // pending on an accumulator register, which keeps every vmcnt wait out of the loop proper (with a pending
+  // C load at loop entry the compiler puts s_waitcnt vmcnt(0) in front of the MFMAs of the last
+  // accumulators INSIDE the loop, i.e. a wait for the prefetch just issued, in every step).
+  gload(0);
   d4_t acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -184,21 +194,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
       }
     }
-
-  const int sw = (fr >= 4 && fr < 12) ? 1 : 0;
-  const int a_off = (wr * (BM / 2) + fr) * LDS_STRIDE + ((fk ^ sw) << 2);
-  const int b_off = BKN ? 4 * fk * LDS_STRIDE_KN + wc * (BN / 2) + fr
-                        : (wc * (BN / 2) + fr) * LDS_STRIDE + ((fk ^ sw) << 2);
-
-  gload(0);
   sstore(0);
-  // every C load must have landed before the loop: otherwise the compiler, which tracks the pending loads of the
-  // last accumulator registers across the back-edge, places s_waitcnt vmcnt(0) in front of their MFMAs INSIDE
-  // the loop, and each step then also waits for the operand prefetch it has just issued
-  if (OP == OP_SUB) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt / expcnt untouched
   __syncthreads();
   const int nk = (kend - kbeg) / BK;
-  for (int kt = 0; kt < nk; ++kt) {
+  auto kstep = [&](int kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * BK);
     const double* sa = smem + cur * BUF_DOUBLES;
@@ -228,7 +227,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     }
     if (kt + 1 < nk) sstore(cur ^ 1);
     __syncthreads();
-  }
+  };
+  kstep(0);
+  for (int kt = 1; kt < nk; ++kt) kstep(kt);
 
   // End stamp (only the workgroups that can be the launch's last: dispatch is in order and tiles are uniform,
   // so the last one to finish is among the last two rounds of 512).  s_memrealtime takes ~1.5 us to return:
