@@ -196,6 +196,10 @@ int gpmi_lml_mix(gpmi_ctx* ctx, int nk, const int* kernels, const double* thetas
 int gpmi_lml_grad_mix(gpmi_ctx* ctx, int nk, const int* kernels, const double* thetas, const int* n_thetas,
                       const double* g_host, double extra_diag, const double* mu_host, double* lml,
                       double* grad_thetas, double* hrows_host, double* alpha_host, int* info);
+/* alpha and diag(K^-1) at arbitrary hyper-parameters: the O(n^3) part of loo_likelihood (regression.py:468-487) */
+int gpmi_loo_terms_mix(gpmi_ctx* ctx, int nk, const int* kernels, const double* thetas, const int* n_thetas,
+                       const double* g_host, double extra_diag, const double* mu_host, double* alpha_host,
+                       double* ikdiag_host, int* info);
 /* prediction with the model of gpmi_fit_mix: gq_host (nk x m) are the weights of the query points;
  * mu* = k.alpha (the host adds the mean function), negsumsq = -|L^-1 k|^2 (the host adds K_qq[0, 0]) */
 int gpmi_predict_mix(gpmi_ctx* ctx, const double* pts_host, int64_t m, const double* gq_host,

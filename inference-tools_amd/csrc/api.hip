@@ -1395,6 +1395,39 @@ int gpmi_lml_grad_mix(gpmi_ctx* c, int nk, const int* kernels, const double* the
   return GPMI_OK;
 }
 
+int gpmi_loo_terms_mix(gpmi_ctx* c, int nk, const int* kernels, const double* thetas, const int* n_thetas,
+                       const double* g_host, double extra_diag, const double* mu, double* alpha_out,
+                       double* ikdiag, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  KParams ps[GPMI_MAX_MIX];
+  if (int rc = ensure_lanes(c, 2)) return rc;
+  if (int rc = mix_prepare(c, nk, kernels, thetas, n_thetas, g_host, ps)) return rc;
+  ARGCHK(c, mu && alpha_out && ikdiag, "mu / alpha / ikdiag is NULL");
+  c->fitted = false;
+  Lane& L = c->lanes[1];
+  if (int rc = ensure_second_matrix(c, L)) return rc;
+  hipStream_t s = L.stream;
+  double* mu_dev = L.vec + 3 * c->np;
+  double* alpha_dev = L.vec + c->np;
+  double* diag_dev = L.vec + 2 * c->np;
+  const MixEval mx{nk, ps, c->mix_g, extra_diag, c->mix_scratch, c->mix_zero};
+  HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
+  if (int rc = enqueue_factor_and_forward(c, L, ps[0], mu_dev, 0.0, 0, true, &mx)) return rc;
+  launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev, L.info);
+  if (int rc = enqueue_inverse_factor(c, L, L)) return rc;
+  launch_rows_sumsq(s, L.B2, c->ld, c->np, c->np, 0.0, diag_dev);  // -diag(K^-1): squared row norms of L^-T
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(alpha_out, alpha_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(ikdiag, diag_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  for (int64_t i = 0; i < c->n; ++i) ikdiag[i] = -ikdiag[i];
+  INFOCHK(c, L.h_info[0]);
+  if (info) *info = L.h_info[0];
+  return GPMI_OK;
+}
+
 int gpmi_predict_mix(gpmi_ctx* c, const double* pts, int64_t m, const double* gq_host, double* mu_out,
                      double* negsumsq_out) {
   if (!c) return GPMI_ERR_ARG;

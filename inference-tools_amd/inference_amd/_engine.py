@@ -91,6 +91,15 @@ class GpEngine:
                     C.byref(lml), dptr(grad), dptr(hrows), dptr(alpha), C.byref(info))
         return lml.value, grad, hrows, alpha, info.value
 
+    def loo_terms_mix(self, kernels, thetas, weights, extra_diag, mu):
+        nk, ks, kp, th, nts, ntp, g = self._mix_args(kernels, thetas, weights)
+        mu = as_f64(mu)
+        alpha, ikdiag = np.empty(self.n), np.empty(self.n)
+        info = C.c_int(0)
+        self.h.call("gpmi_loo_terms_mix", nk, kp, dptr(th), ntp, dptr(g), float(extra_diag), dptr(mu),
+                    dptr(alpha), dptr(ikdiag), C.byref(info))
+        return alpha, ikdiag, info.value
+
     def predict_mix(self, pts, query_weights):
         p = as_f64(pts)
         gq = as_f64(query_weights)

@@ -341,11 +341,14 @@ class GpRegressor:
 
     def loo_likelihood(self, theta: ndarray) -> float:
         """Leave-one-out log-likelihood, R&W eqs. 5.10-5.12 (regression.py:468-487)."""
-        self._no_mixture("loo_likelihood")
         theta = np.asarray(theta, dtype=float)
         theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
         mu = self.mean.build_mean(theta[self.mean_slice])
-        alpha, ikdiag, info = self.engine.loo_terms(self._kernel_id, theta_stat, extra, mu)
+        if self._mix is not None:
+            alpha, ikdiag, info = self.engine.loo_terms_mix(*self._mix_args(theta_stat), extra, mu)
+            self._mix_fit_stale = True
+        else:
+            alpha, ikdiag, info = self.engine.loo_terms(self._kernel_id, theta_stat, extra, mu)
         if info != 0:
             warn("Cholesky decomposition failure in loo_likelihood")
             return -1e50

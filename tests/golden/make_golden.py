@@ -351,6 +351,7 @@ def case_cp():
         out[f"{tag}_loo_mu"], out[f"{tag}_loo_sig"] = loo_mu, loo_sig
         pm, pc = gp.build_posterior(pts[:20])
         out[f"{tag}_post_mu"], out[f"{tag}_post_cov"] = pm, pc
+        out[f"{tag}_loo"] = np.array([gp.loo_likelihood(t) for t in thetas])
     return out
 
 
@@ -380,6 +381,7 @@ def case_het():
         out[f"{tag}_alpha"] = gp.alpha
         out[f"{tag}_K_xx"] = gp.K_xx
         out[f"{tag}_mu"], out[f"{tag}_sig"] = mu, sig
+        out[f"{tag}_loo"] = np.array([gp.loo_likelihood(t) for t in thetas])
     return out
 
 

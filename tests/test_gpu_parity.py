@@ -619,6 +619,7 @@ def test_heteroscedastic_noise_vs_reference(golden, gp_mod, tag, with_err):
     mu, sig = gp(wl.query_points(77, 40, d))
     check(mu, g[f"{tag}_mu"], what="mu")
     check(sig, g[f"{tag}_sig"], what="sig")
+    check([gp.loo_likelihood(t) for t in th], g[f"{tag}_loo"], what="loo likelihood")
 
 
 # ---------------------------------------------------------------------------------------
@@ -656,6 +657,7 @@ def test_change_point_vs_reference(golden, gp_mod, tag, subs, wn):
     pm, pc = gp.build_posterior(pts[:20])
     check(pm, g[f"{tag}_post_mu"], what="posterior mean")
     check(pc, g[f"{tag}_post_cov"], 1e-9, "posterior covariance")
+    check([gp.loo_likelihood(t) for t in th], g[f"{tag}_loo"], what="loo likelihood")
 
 
 def test_change_point_search_and_limits(gp_mod):
