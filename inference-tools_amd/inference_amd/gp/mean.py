@@ -99,6 +99,12 @@ class _FeatureMean(MeanFunction):
         dq = np.atleast_2d(q - self.x_mean)
         return (self._features(dq) @ theta).squeeze()
 
+    def at_points(self, points: ndarray, theta: ndarray) -> ndarray:
+        """Prior mean at every row of `points` (M, d) in one shot — what `__call__` gives point by point."""
+        if self.degree == 0:
+            return np.full(points.shape[0], float(theta[0]))
+        return self._features(points - self.x_mean[None, :]) @ np.asarray(theta, dtype=float)
+
     def build_mean(self, theta: ndarray):
         if self.degree == 0:
             return np.zeros(self.n_data) + theta[0]

@@ -172,6 +172,13 @@ class GpRegressor:
         base = np.zeros(self.n_points) if self._noise_var is None else self._noise_var
         return base + np.exp(2 * np.asarray(theta_cov, dtype=float)[self._het_slice])
 
+    def _mean_at(self, pts):
+        """Prior mean at the rows of `pts`: vectorised for the built-in means, point by point (as the reference
+        does, regression.py:211) for user-defined ones."""
+        if hasattr(self.mean, "at_points"):
+            return self.mean.at_points(pts, self.mean_hyperpars)
+        return array([self.mean(q, self.mean_hyperpars) for q in pts[:, None, :]])
+
     def _mix_args(self, theta_cp):
         """(kernel ids, sub-kernel parameter vectors, training-point weights) of a ChangePoint block."""
         kernels, thetas = self._mix.device_terms(theta_cp)
@@ -225,8 +232,7 @@ class GpRegressor:
             var = (gq**2 * amp2[:, None]).sum(axis=0) + neg
         else:
             mu, var = self.engine.predict(p)
-        mean_q = array([self.mean(q, self.mean_hyperpars) for q in p[:, None, :]])
-        return mu + mean_q, sqrt(abs(var))
+        return mu + self._mean_at(p), sqrt(abs(var))
 
     def set_hyperparameters(self, hyperpars: ndarray):
         """Update the hyper-parameters and re-fit (regression.py:218-244)."""
@@ -328,7 +334,7 @@ class GpRegressor:
             mu, sigma = self.engine.posterior_mix(v, self._mix.weights(v[:, self._mix.axis], theta_cp), mean_only=mean_only)
         else:
             mu, sigma = self.engine.posterior(v, mean_only=mean_only)
-        mu = mu + array([self.mean(p, self.mean_hyperpars) for p in v])
+        mu = mu + self._mean_at(v)
         if mean_only:
             return mu
         return mu, sigma
