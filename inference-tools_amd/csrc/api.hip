@@ -1,5 +1,12 @@
 // C-ABI of libgpmi (see include/gpmi.h): handle management, host<->device plumbing and the
 // orchestration of the GP hot path (covariance build -> Cholesky -> solves -> reductions).
+//
+// Layout of this file:
+//   helpers (error macros, lanes / streams, workspaces, K-build + factorise + forward solve)
+//   lifecycle, data upload, fit / LML / batched LML / LML gradient
+//   predict, posterior, spatial gradients, leave-one-out, covariance downloads
+//   instrumentation (per-class events, in-kernel stamps), device-pointer entry points (tools)
+//   mixture covariance (ChangePoint), per-point noise (HeteroscedasticNoise), linear inversion (GpLinearInverter)
 #include <chrono>
 #include <cmath>
 #include <cstdio>
