@@ -683,3 +683,26 @@ def test_change_point_search_and_limits(gp_mod):
     with pytest.raises(NotImplementedError):
         gp_mod.GpRegressor(x, y, y_err=e, hyperpars=np.zeros(4),
                            kernel=gp_mod.ChangePoint(kernels=[gp_mod.SquaredExponential, gp_mod.WhiteNoise]))
+
+
+def test_ragged_large_size_vs_oracle(gp_mod):
+    """N = 6500 (padded to 6528 = 51 tile rows): large enough for the look-ahead regime, the split trailing
+    updates and the 512-wide inverse blocks with a partial last block, not a multiple of anything."""
+    from oracle import gp_oracle as orc
+
+    n, d = 6500, 5
+    x, y, e = wl.synthetic_dataset(65, n, d)
+    th = wl.timing_theta(wl.RQ, y, d)
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=th, kernel=gp_mod.RationalQuadratic)
+    ref = orc.OracleGp(x, y, e, kernel=orc.RQ, hyperpars=th)
+    check(gp.alpha, ref.alpha, what="alpha")
+    check(gp.marginal_likelihood(th), ref.marginal_likelihood(th), what="lml")
+    pts = wl.query_points(65, 300, d)
+    mu, sig = gp(pts)
+    rmu, rsig = ref(pts)
+    check(mu, rmu, what="mu")
+    check(sig, rsig, what="sig")
+    lml, grad = gp.marginal_likelihood_gradient(th)
+    rl, rg = ref.marginal_likelihood_gradient(th)
+    check(lml, rl, what="lml (gradient call)")
+    check(grad, rg, 1e-9, "gradient")
