@@ -508,8 +508,7 @@ int gpmi_fit(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double e
   if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
   const auto h1 = std::chrono::steady_clock::now();
   // alpha = L^-T v
-  launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
-  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, c->alpha, L.info);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, c->alpha, L.info);
   HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
   if (alpha_out)
@@ -655,8 +654,7 @@ int gpmi_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
   double* gout = L.red + 16;  // n_theta + 1 values (n_theta <= GPMI_MAX_D + 2)
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
   if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
-  launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
-  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev, L.info);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, alpha_dev, L.info);
   // K^-1 = L^-T L^-1 (regression.py:556-557), lower tiles, overwriting L
   if (int rc = enqueue_inverse_factor(c, L, L)) return rc;
   launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, true, L.A, c->ld, L.B2, c->ld, L.B2, c->ld,
@@ -857,8 +855,7 @@ int gpmi_loo_terms(gpmi_ctx* c, int kernel, const double* theta, int n_theta, do
   double* diag_dev = L.vec + 2 * c->np;
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
   if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
-  launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
-  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev, L.info);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, alpha_dev, L.info);
   if (int rc = enqueue_inverse_factor(c, L, L)) return rc;
   launch_rows_sumsq(s, L.B2, c->ld, c->np, c->np, 0.0, diag_dev);
   HIPCHK(c, hipGetLastError());
@@ -903,8 +900,7 @@ int gpmi_loo_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
   double* gout = L.red + 16;
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
   if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
-  launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
-  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev, L.info);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, alpha_dev, L.info);
   // K^-1 (full, both triangles) in A
   if (int rc = enqueue_inverse_factor(c, L, L)) return rc;
   launch_rows_sumsq(s, L.B2, c->ld, c->np, c->np, 0.0, diag_dev);  // = -diag(K^-1)
@@ -1283,8 +1279,7 @@ int gpmi_fit_mix(gpmi_ctx* c, int nk, const int* kernels, const double* thetas, 
   const MixEval mx{nk, ps, c->mix_g, extra_diag, c->mix_scratch, c->mix_zero};
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
   if (int rc = enqueue_factor_and_forward(c, L, ps[0], mu_dev, 0.0, 0, true, &mx)) return rc;
-  launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
-  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, c->alpha, L.info);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, c->alpha, L.info);
   HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
   if (alpha_out)
@@ -1358,8 +1353,7 @@ int gpmi_lml_grad_mix(gpmi_ctx* c, int nk, const int* kernels, const double* the
   const MixEval mx{nk, ps, c->mix_g, extra_diag, c->mix_scratch, c->mix_zero};
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
   if (int rc = enqueue_factor_and_forward(c, L, ps[0], mu_dev, 0.0, 0, true, &mx)) return rc;
-  launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
-  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev, L.info);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, alpha_dev, L.info);
   // K^-1 = L^-T L^-1, lower tiles over L, then both triangles (it is read row-wise below)
   if (int rc = enqueue_inverse_factor(c, L, L)) return rc;
   launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, 1, L.A, c->ld, L.B2, c->ld, L.B2, c->ld,
@@ -1420,8 +1414,7 @@ int gpmi_loo_terms_mix(gpmi_ctx* c, int nk, const int* kernels, const double* th
   const MixEval mx{nk, ps, c->mix_g, extra_diag, c->mix_scratch, c->mix_zero};
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
   if (int rc = enqueue_factor_and_forward(c, L, ps[0], mu_dev, 0.0, 0, true, &mx)) return rc;
-  launch_copy(s, L.vec, L.vec + 2 * c->np, c->np);
-  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, alpha_dev, L.info);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, alpha_dev, L.info);
   if (int rc = enqueue_inverse_factor(c, L, L)) return rc;
   launch_rows_sumsq(s, L.B2, c->ld, c->np, c->np, 0.0, diag_dev);  // -diag(K^-1): squared row norms of L^-T
   HIPCHK(c, hipGetLastError());
@@ -1574,11 +1567,6 @@ __global__ void linv_add_diag_kernel(double* __restrict__ J, int64_t ld, const d
                                      int64_t mp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < mp) J[i * ld + i] += sig2[i];
-}
-
-__global__ void linv_fill_kernel(double* __restrict__ v, int64_t n, int64_t np, double inside, double pad) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < np) v[i] = (i < n) ? inside : pad;
 }
 
 void linv_free(LinvState& S) {

@@ -241,14 +241,14 @@ void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t l
                  int* info, bool allow_lookahead = true);
 
 // solve.hip
-// forward substitution  L v = r : the solution goes to `out` (no aliasing; `r` may be used as scratch).
+// forward substitution  L v = r : the solution goes to `out` (no aliasing; `r` is only read).
 // `err` (device int, may be null) receives GPMI_ERR_INTERNAL if the sweep's polling ever times out.
 void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                  const double* invD, double* r, double* out, int* err = nullptr,
+                  const double* invD, const double* r, double* out, int* err = nullptr,
                   const BatchShape& bs = BatchShape());
-// backward substitution  L^T a = v : the solution goes to `out` (no aliasing; `r` may be used as scratch)
+// backward substitution  L^T a = v : the solution goes to `out` (no aliasing; `r` is only read)
 void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                   const double* invD, double* r, double* out, int* err = nullptr);
+                   const double* invD, const double* r, double* out, int* err = nullptr);
 // inverses of the 512-wide diagonal blocks of L from the 128-wide ones: inv2 (slots of 512 x 512, ld 512),
 // tmp: slots of 256 x 256
 constexpr int GPMI_OB = 512;

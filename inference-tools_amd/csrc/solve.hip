@@ -19,104 +19,8 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
-// ---- fused single-right-hand-side sweeps -------------------------------------------------------
-// One launch per 128-block (instead of a diagonal-apply launch plus a panel launch): every
-// workgroup recomputes the 128-vector of the block itself (a 128 x 128 GEMV out of L2, ~1 us) and
-// then applies it to its own 64 rows / columns of L, so the only serialisation left is the kernel
-// boundary.  Small workgroup slices (64 KiB of L each) keep every CU under its ~10 B/clk load limit.
-
-// forward, block k:  v = invD_k r_k ;  block 0 of the grid stores v to vout ;  r[rows below] -= L[rows, k] v
-// (r_k itself is left untouched: other workgroups of the launch are still reading it)
-__global__ __launch_bounds__(256) void trsv_fwd_step_kernel(const double* __restrict__ Lp, int64_t ld,
-                                                            const double* __restrict__ invD,
-                                                            const double* __restrict__ rk,
-                                                            double* __restrict__ vout,
-                                                            double* __restrict__ rbelow, int64_t rows,
-                                                            int64_t sMat, int64_t sInv, int64_t sVec) {
-  Lp += (int64_t)blockIdx.z * sMat;
-  invD += (int64_t)blockIdx.z * sInv;
-  rk += (int64_t)blockIdx.z * sVec;
-  vout += (int64_t)blockIdx.z * sVec;
-  rbelow += (int64_t)blockIdx.z * sVec;
-  __shared__ double rin[NB];
-  __shared__ double v[NB];
-  const int tid = threadIdx.x;
-  if (tid < NB) rin[tid] = rk[tid];
-  __syncthreads();
-  {
-    // v[row] = sum_c invD[row][c] rin[c]: two threads per row, 64 columns each (invD is lower triangular)
-    const int row = tid >> 1, half = tid & 1;
-    const double* p = invD + row * NB + half * 64;
-    double s = 0.0;
-#pragma unroll 8
-    for (int c = 0; c < 64; c += 2) {
-      const d2_t a = *reinterpret_cast<const d2_t*>(p + c);
-      s = fma(a[0], rin[half * 64 + c], s);
-      s = fma(a[1], rin[half * 64 + c + 1], s);
-    }
-    s += __shfl_xor(s, 1, 64);
-    if (half == 0) v[row] = s;
-  }
-  __syncthreads();
-  if (blockIdx.x == 0 && tid < NB) vout[tid] = v[tid];
-  // rows below: 64 rows per workgroup, 4 threads per row (32 columns each)
-  const int64_t row = (int64_t)blockIdx.x * 64 + (tid >> 2);
-  const int part = tid & 3;
-  double s = 0.0;
-  if (row < rows) {
-    const double* p = Lp + row * ld + part * 32;
-#pragma unroll 8
-    for (int c = 0; c < 32; c += 2) {
-      const d2_t a = *reinterpret_cast<const d2_t*>(p + c);
-      s = fma(a[0], v[part * 32 + c], s);
-      s = fma(a[1], v[part * 32 + c + 1], s);
-    }
-  }
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  if (row < rows && part == 0) rbelow[row] -= s;
-}
-
-// backward, block k:  a = invD_k^T r_k ;  block 0 stores a to aout ;  r[j] -= sum_i L[k-block row i][j] a[i], j < cols
-__global__ __launch_bounds__(256) void trsv_bwd_step_kernel(const double* __restrict__ Lr, int64_t ld,
-                                                            const double* __restrict__ invD,
-                                                            const double* __restrict__ rk,
-                                                            double* __restrict__ aout,
-                                                            double* __restrict__ r, int64_t cols) {
-  __shared__ double rin[NB];
-  __shared__ double part[2 * NB];
-  __shared__ double a[NB];
-  __shared__ double red[4 * 64];
-  const int tid = threadIdx.x;
-  if (tid < NB) rin[tid] = rk[tid];
-  __syncthreads();
-  {
-    // a[c] = sum_i invD[i][c] rin[i]: thread (half, c) sums 64 rows; coalesced along c
-    const int c = tid & 127, half = tid >> 7;
-    double s = 0.0;
-#pragma unroll 8
-    for (int i = half * 64; i < half * 64 + 64; ++i) s = fma(invD[i * NB + c], rin[i], s);
-    part[half * NB + c] = s;
-  }
-  __syncthreads();
-  if (tid < NB) a[tid] = part[tid] + part[NB + tid];
-  __syncthreads();
-  if (blockIdx.x == 0 && tid < NB) aout[tid] = a[tid];
-  // columns left of the block: 64 columns per workgroup, 4 row groups of 32 rows
-  const int64_t j = (int64_t)blockIdx.x * 64 + (tid & 63);
-  const int rg = tid >> 6;
-  double s = 0.0;
-  if (j < cols) {
-#pragma unroll 8
-    for (int i = rg * 32; i < rg * 32 + 32; ++i) s = fma(Lr[(int64_t)i * ld + j], a[i], s);
-  }
-  red[rg * 64 + (tid & 63)] = s;
-  __syncthreads();
-  if (tid < 64 && j < cols) r[j] -= red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
-}
-
 // ---- single-launch sweeps (dataflow over the 128-blocks) ----------------------------------------
-// The per-block launches above are bound by the kernel boundary (~10 us per step, 2.6 ms for the two
+// One launch per 128-block (256 per fit) is bound by the kernel boundary (~10 us per step, 2.6 ms for the two
 // sweeps of a fit at N = 16384, although L is only 1 GB).  Here ONE launch does a whole sweep:
 // workgroup k owns block row k (forward) / block column k (backward), accumulates the contributions
 // of the blocks whose solution is already published, and publishes its own 128 values.  The output
@@ -440,53 +344,23 @@ __global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restric
 
 }  // namespace
 
-// GPMI_TRSV_STEPS=1 selects the per-block launches (A/B measurements)
-static bool trsv_use_steps() {
-  static const bool v = [] {
-    const char* e = std::getenv("GPMI_TRSV_STEPS");
-    return e && e[0] == '1';
-  }();
-  return v;
-}
-
 void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                  const double* invD, double* r, double* out, int* err, const BatchShape& bs) {
+                  const double* invD, const double* r, double* out, int* err, const BatchShape& bs) {
   const int nt = (int)(np / NB);
   ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)np * np, 4.0 * np * np);
-  if (!trsv_use_steps()) {
-    hipLaunchKernelGGL(flow_fill_kernel, dim3((unsigned)((np + 255) / 256), 1, (unsigned)bs.count), dim3(256), 0,
-                       s, out, np, bs.sVec);
-    hipLaunchKernelGGL(trsv_fwd_flow_kernel, dim3((unsigned)nt, 1, (unsigned)bs.count), dim3(FLOW_THREADS), 0,
-                       s, L, ld, invD, r, out, err, bs.sMat, bs.sInv, bs.sVec);
-    return;
-  }
-  for (int k = 0; k < nt; ++k) {
-    const int64_t rows = np - (int64_t)(k + 1) * NB;
-    const unsigned blocks = rows > 0 ? (unsigned)((rows + 63) / 64) : 1u;
-    hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(blocks, 1, (unsigned)bs.count), dim3(256), 0, s,
-                       L + (int64_t)(k + 1) * NB * ld + (int64_t)k * NB, ld, invD + (int64_t)k * NB * NB,
-                       r + (int64_t)k * NB, out + (int64_t)k * NB, r + (int64_t)(k + 1) * NB, rows,
-                       bs.sMat, bs.sInv, bs.sVec);
-  }
+  hipLaunchKernelGGL(flow_fill_kernel, dim3((unsigned)((np + 255) / 256), 1, (unsigned)bs.count), dim3(256), 0, s,
+                     out, np, bs.sVec);
+  hipLaunchKernelGGL(trsv_fwd_flow_kernel, dim3((unsigned)nt, 1, (unsigned)bs.count), dim3(FLOW_THREADS), 0, s, L,
+                     ld, invD, r, out, err, bs.sMat, bs.sInv, bs.sVec);
 }
 
 void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                   const double* invD, double* r, double* out, int* err) {
+                   const double* invD, const double* r, double* out, int* err) {
   const int nt = (int)(np / NB);
   ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)np * np, 4.0 * np * np);
-  if (!trsv_use_steps()) {
-    hipLaunchKernelGGL(flow_fill_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, out, np,
-                       (int64_t)0);
-    hipLaunchKernelGGL(trsv_bwd_flow_kernel, dim3((unsigned)nt), dim3(FLOW_THREADS), 0, s, L, ld, invD, r,
-                       out, err, nt);
-    return;
-  }
-  for (int k = nt - 1; k >= 0; --k) {
-    const int64_t cols = (int64_t)k * NB;
-    const unsigned blocks = cols > 0 ? (unsigned)((cols + 63) / 64) : 1u;
-    hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(blocks), dim3(256), 0, s, L + (int64_t)k * NB * ld, ld,
-                       invD + (int64_t)k * NB * NB, r + (int64_t)k * NB, out + (int64_t)k * NB, r, cols);
-  }
+  hipLaunchKernelGGL(flow_fill_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, out, np, (int64_t)0);
+  hipLaunchKernelGGL(trsv_bwd_flow_kernel, dim3((unsigned)nt), dim3(FLOW_THREADS), 0, s, L, ld, invD, r, out, err,
+                     nt);
 }
 
 void build_inv2(hipStream_t s, const double* L, int64_t np, int64_t ld, const double* invD, double* inv2,
