@@ -706,3 +706,26 @@ def test_ragged_large_size_vs_oracle(gp_mod):
     rl, rg = ref.marginal_likelihood_gradient(th)
     check(lml, rl, what="lml (gradient call)")
     check(grad, rg, 1e-9, "gradient")
+
+
+def test_objects_pickle_without_device_state(gp_mod):
+    """the reference pickles the GP object into worker processes (regression.py:600-601,
+    parallel.py:130-136); here the device handle is dropped on pickling and re-created lazily."""
+    import pickle
+
+    x, y, e = wl.synthetic_dataset(9, 200, 2)
+    th = wl.timing_theta(wl.SE, y, 2)
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=th)
+    pts = wl.query_points(9, 10, 2)
+    mu, sig = gp(pts)
+    clone = pickle.loads(pickle.dumps(gp))
+    assert clone._engine is None
+    clone.set_hyperparameters(th)
+    mu2, sig2 = clone(pts)
+    assert np.array_equal(mu, mu2) and np.array_equal(sig, sig2)
+    assert clone.marginal_likelihood(th) == gp.marginal_likelihood(th)
+    pos, A, yy, ee = wl.linv_problem("deconv")
+    gli = gp_mod.GpLinearInverter(y=yy, y_err=ee, model_matrix=A, parameter_spatial_positions=pos)
+    t3 = np.array([0.1, 0.0, np.log(0.15)])
+    v = gli.marginal_likelihood(t3)
+    assert pickle.loads(pickle.dumps(gli)).marginal_likelihood(t3) == v
