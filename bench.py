@@ -120,6 +120,34 @@ def pmc_traffic():
         return None
 
 
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this same script and relay rank
+    0's JSON line.  The parent never touches the GPU (nothing GPU-related is imported before this point), the
+    children are fresh interpreters (no fork of an initialised runtime, no exec from a GPU process); LOCAL_RANK
+    selects the device modulo the number of visible devices, so on a box with fewer GPUs than ranks several
+    ranks share a device (RCCL then refuses the duplicate device and the gather falls back to the rendezvous
+    files — `config.parallelism` says which path ran)."""
+    import secrets
+    import subprocess
+
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=env.get("MASTER_PORT", "29511"),
+               GPMI_RDV_KEY=f"bench_{os.getpid()}_{secrets.token_hex(6)}")
+    procs = []
+    for r in range(n_ranks):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: rank(s) failed: {bad}", file=sys.stderr)
+        sys.exit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +158,10 @@ def main():
     ap.add_argument("--m", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if "RANK" not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus)  # parent: spawns the ranks before anything touches the GPU, relays, exits
+        return
 
     import workloads as wl
     from inference_amd import _lib
@@ -142,14 +174,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     rdv = sharding.FileRendezvous(rank, world) if world > 1 else None
+    try:
+        run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, local_rank, rdv)
+    finally:
+        if rdv is not None:
+            rdv.close()
 
+
+def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, local_rank, rdv):
     N, d, M = args.n, args.d, args.m
     x, y, e = wl.synthetic_dataset(2, N, d)
     thetas = wl.theta_set(wl.SE, y, d, max(world, 1), seed=11)
     theta = thetas[rank % len(thetas)] if world > 1 else thetas[0]
     pts = wl.query_points(2, M, d)
 
-    gp = GpRegressor(x, y, y_err=e, hyperpars=theta, kernel=SquaredExponential, device=local_rank)
+    gp = GpRegressor(x, y, y_err=e, hyperpars=theta, kernel=SquaredExponential,
+                     device=local_rank % max(_lib.device_count(), 1))
     eng = gp.engine
     gather = "none"
     if world > 1:
@@ -213,7 +253,7 @@ def main():
     if rank == 0:
         ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
         line = {
-            "metric": "GpRegressor fit+predict wall-time and GFLOP/s at N=16384, d=8; % fp64 MFMA peak",
+            "metric": f"GpRegressor fit+predict wall-time and GFLOP/s at N={N}, d={d}; % fp64 MFMA peak",
             "value": value,
             "unit": "GFLOP/s",
             "n_gpus": world,
@@ -249,9 +289,6 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(4096, d, 256)  # ~10-15 s of host work in all
         print(json.dumps(line), flush=True)
-
-    if rdv is not None:
-        rdv.close()
 
 
 if __name__ == "__main__":

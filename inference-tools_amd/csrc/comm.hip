@@ -55,6 +55,11 @@ Rccl* rccl() {
 
 constexpr int NCCL_DOUBLE = 8;  // ncclFloat64 (rccl.h)
 
+int hip_fail(gpmi_ctx* c, const char* what, hipError_t e) {
+  c->err = std::string(what) + ": " + hipGetErrorString(e);
+  return GPMI_ERR_HIP;
+}
+
 int fail(gpmi_ctx* c, const char* what, int code) {
   Rccl* r = rccl();
   c->err = std::string(what) + ": " +
@@ -86,7 +91,7 @@ int gpmi_comm_init(gpmi_ctx* c, int rank, int world, const char* id_bytes) {
     c->err = "bad rank / world / id";
     return GPMI_ERR_ARG;
   }
-  if (hipSetDevice(c->device) != hipSuccess) return GPMI_ERR_HIP;
+  if (hipError_t e = hipSetDevice(c->device); e != hipSuccess) return hip_fail(c, "hipSetDevice", e);
   if (c->comm) {
     r->comm_destroy(c->comm);
     c->comm = nullptr;
@@ -97,8 +102,10 @@ int gpmi_comm_init(gpmi_ctx* c, int rank, int world, const char* id_bytes) {
   if (rc != 0) return fail(c, "ncclCommInitRank", rc);
   c->comm_rank = rank;
   c->comm_world = world;
-  if (!c->comm_stream && hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) != hipSuccess)
-    return GPMI_ERR_HIP;
+  if (!c->comm_stream) {
+    if (hipError_t e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking); e != hipSuccess)
+      return hip_fail(c, "hipStreamCreateWithFlags (gather stream)", e);
+  }
   return GPMI_OK;
 }
 
@@ -113,26 +120,29 @@ int gpmi_comm_allgather(gpmi_ctx* c, const double* send_host, double* recv_host,
     c->err = "bad buffers";
     return GPMI_ERR_ARG;
   }
-  if (hipSetDevice(c->device) != hipSuccess) return GPMI_ERR_HIP;
+  if (hipError_t e = hipSetDevice(c->device); e != hipSuccess) return hip_fail(c, "hipSetDevice", e);
   const int64_t need = count * (1 + (int64_t)c->comm_world);
   if (c->comm_buf_doubles < need) {
     if (c->comm_buf) (void)hipFree(c->comm_buf);
     c->comm_buf = nullptr;
     c->comm_buf_doubles = 0;
-    if (hipMalloc(&c->comm_buf, sizeof(double) * need) != hipSuccess) return GPMI_ERR_NOMEM;
+    if (hipMalloc(&c->comm_buf, sizeof(double) * need) != hipSuccess) {
+      c->err = "out of device memory for the gather buffer";
+      return GPMI_ERR_NOMEM;
+    }
     c->comm_buf_doubles = need;
   }
   hipStream_t s = c->comm_stream;
   double* send = c->comm_buf;
   double* recv = c->comm_buf + count;
-  if (hipMemcpyAsync(send, send_host, sizeof(double) * count, hipMemcpyHostToDevice, s) != hipSuccess)
-    return GPMI_ERR_HIP;
+  if (hipError_t e = hipMemcpyAsync(send, send_host, sizeof(double) * count, hipMemcpyHostToDevice, s); e != hipSuccess)
+    return hip_fail(c, "gather upload", e);
   int rc = r->all_gather(send, recv, (size_t)count, NCCL_DOUBLE, c->comm, s);
   if (rc != 0) return fail(c, "ncclAllGather", rc);
-  if (hipMemcpyAsync(recv_host, recv, sizeof(double) * count * c->comm_world, hipMemcpyDeviceToHost, s) !=
-      hipSuccess)
-    return GPMI_ERR_HIP;
-  if (hipStreamSynchronize(s) != hipSuccess) return GPMI_ERR_HIP;
+  if (hipError_t e = hipMemcpyAsync(recv_host, recv, sizeof(double) * count * c->comm_world, hipMemcpyDeviceToHost, s);
+      e != hipSuccess)
+    return hip_fail(c, "gather download", e);
+  if (hipError_t e = hipStreamSynchronize(s); e != hipSuccess) return hip_fail(c, "gather synchronise", e);
   return GPMI_OK;
 }
 

@@ -43,6 +43,8 @@ class GpEngine:
 
     def lml_batch(self, kernel, thetas_cov, extra_diag=None, mus=None, mu_const=None):
         thetas = as_f64(thetas_cov)
+        if thetas.size == 0:
+            return np.empty(0), np.zeros(0, dtype=np.int32)
         T, nt = thetas.shape
         ex = None if extra_diag is None else as_f64(extra_diag)
         mus = None if mus is None else as_f64(mus)

@@ -107,6 +107,13 @@ def load():
     return _lib
 
 
+def device_count() -> int:
+    """Number of HIP devices visible to this process (0 without a GPU)."""
+    cnt = C.c_int(0)
+    load().gpmi_device_count(C.byref(cnt))
+    return cnt.value
+
+
 def dptr(a):
     """double* view of a C-contiguous float64 array (None -> NULL)."""
     if a is None:

@@ -212,6 +212,7 @@ class GpRegressor:
     @property
     def L(self) -> ndarray:
         if self._L_cache is None:
+            self._refit_mixture_if_stale()  # a ChangePoint likelihood evaluation shares lane 0 with the fit
             self._L_cache = self.engine.get_L()
         return self._L_cache
 
@@ -402,7 +403,10 @@ class GpRegressor:
     def marginal_likelihood_batch(self, thetas: ndarray) -> ndarray:
         """(extension) `marginal_likelihood` for T hyper-parameter vectors at once, spread over
         the device's worker streams — the unit the grid sweep / PT driver shards over GPUs."""
-        thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
+        thetas = np.asarray(thetas, dtype=float)
+        if thetas.size == 0:
+            return np.empty(0)  # an empty shard (more ranks than evaluations)
+        thetas = np.atleast_2d(thetas)
         if self._het_slice is not None or self._mix is not None:  # per-point terms change with theta: one at a time
             return np.array([self.marginal_likelihood(t) for t in thetas])
         split = [self._split_cov_theta(t[self.cov_slice]) for t in thetas]

@@ -59,22 +59,27 @@ class Parameter:
         self.bounded = False
         self.lower = self.upper = self.width = 0.0
 
+    def _fold_into_bounds(self, value):
+        """Reflect `value` back into [lower, upper] as many times as needed (a triangle wave of period 2 width)."""
+        offset = value - self.lower
+        inside = offset % self.width
+        bounces = offset // self.width
+        return self.lower + inside if bounces % 2 == 0 else self.upper - inside
+
     def proposal(self):
-        """Normal proposal around the last sample; after `max_tries` failed tries the width is
-        quartered; bounded parameters are reflected back inside (gibbs.py:88-122)."""
+        """Draw the next 1-D proposal (behaviour of gibbs.py:88-122): a normal step from the last sample; a
+        parameter that has already failed `max_tries` times in this update has its width quartered first;
+        bounded parameters are reflected inside, non-negative ones mirrored at zero."""
         self.try_count += 1
         if self.try_count > self.max_tries:
             self.adjust_sigma(0.25)
-        prop = self.rng.normal(loc=self.samples[-1], scale=self.sigma)
+        step = self.rng.normal(loc=self.samples[-1], scale=self.sigma)
         if self.bounded:
-            d = prop - self.lower
-            n = (d // self.width) % 2
-            return self.lower + d % self.width if n == 0 else self.upper - d % self.width
-        if self.non_negative:
-            return abs(prop)
-        return prop
+            return self._fold_into_bounds(step)
+        return abs(step) if self.non_negative else step
 
     def submit_accept_prob(self, p: float):
+        """Record the acceptance probability of one proposal; every `chk_int` records the width is reviewed."""
         self.num += 1
         self.avg += p
         self.var += p * (1 - p)
@@ -82,24 +87,23 @@ class Parameter:
             self.update_epsilon()
 
     def update_epsilon(self):
-        """Width assessment (gibbs.py:132-148): normal approximation of the Poisson-binomial
-        acceptance count; adjust when the target rate is outside two standard deviations."""
-        mu = self.avg / self.num
-        std = sqrt(self.var) / self.num
-        if not (mu - 2 * std < self.target_rate < mu + 2 * std):
-            adj = (log(self.target_rate) / log(mu)) ** self.adjust_rate
-            adj = max(min(adj, 3.0), 0.1)
-            self.adjust_sigma(adj)
-        else:
+        """Width review (behaviour of gibbs.py:132-148).  The number of acceptances is approximately normal
+        (Poisson-binomial); the width changes only when the target rate lies outside two standard deviations
+        of the observed mean rate, otherwise the review interval grows."""
+        rate = self.avg / self.num
+        spread = sqrt(self.var) / self.num
+        if rate - 2 * spread < self.target_rate < rate + 2 * spread:
             self.chk_int = int((self.growth_factor * self.chk_int) * 0.1) * 10
+            return
+        factor = (log(self.target_rate) / log(rate)) ** self.adjust_rate
+        self.adjust_sigma(min(max(factor, 0.1), 3.0))
 
     def adjust_sigma(self, ratio: float):
+        """Scale the proposal width, log it and restart the acceptance statistics."""
         self.sigma *= ratio
         self.sigma_values.append(copy(self.sigma))
         self.sigma_checks.append(len(self.samples))
-        self.avg = 0
-        self.var = 0
-        self.num = 0
+        self.avg = self.var = self.num = 0
 
     def add_sample(self, s):
         self.samples.append(s)

@@ -51,6 +51,9 @@ class ParallelTempering:
 
     def __init__(self, chains, batch_posterior=None):
         self.rng = default_rng()
+        # pairing uses the stdlib generator (the module-level `random.choice`, parallel.py:172); a ladder that must
+        # not share that global stream with other ladders (sharded runs) gets its own `random.Random(seed).choice`
+        self.pair_choice = choice
         self.chains = list(chains)
         self.temperatures = [1.0 / chain.inv_temp for chain in self.chains]
         self.inv_temps = [chain.inv_temp for chain in self.chains]
@@ -82,22 +85,27 @@ class ParallelTempering:
         return list(zip(proposed[::2], proposed[1::2]))
 
     def tight_pairs(self):
-        """Random pairing with almost all pairs 1 or 2 temperature levels apart
-        (parallel.py:162-188; uses the stdlib `random.choice` and the NumPy generator)."""
-        pairs = [(i, i + j) for i in range(self.N_chains - 1) for j in [1, 2]][:-1]
-        sample = []
-        while len(pairs) > 0:
-            p = choice(pairs)
-            pairs = [k for k in pairs if not any(j in k for j in p)]
-            sample.append(p)
-        remaining = len(sample) - self.N_chains // 2
-        if remaining != 0:
-            leftovers = [i for i in range(self.N_chains) if not any(i in p for p in sample)]
-            self.rng.shuffle(leftovers)
-            sample.extend(
-                [p if p[0] < p[1] else (p[1], p[0]) for p in zip(leftovers[::2], leftovers[1::2])]
-            )
-        return sample
+        """Random disjoint pairing in which almost every pair is one or two temperature levels apart
+        (behaviour of parallel.py:162-188, random numbers consumed in the same order: one stdlib `choice` per
+        picked pair over the candidates still free, then one shuffle of the chains left unpaired)."""
+        n = self.N_chains
+        # neighbours at distance 1 and 2 in ladder order; the last candidate (n - 2, n) would leave the ladder
+        candidates = []
+        for low in range(n - 1):
+            candidates += [(low, low + 1), (low, low + 2)]
+        candidates.pop()
+        chosen, taken = [], set()
+        while candidates:
+            pick = self.pair_choice(candidates)
+            chosen.append(pick)
+            taken.update(pick)
+            candidates = [c for c in candidates if c[0] not in taken and c[1] not in taken]
+        if len(chosen) != n // 2:
+            # the greedy pass can strand chains that are not neighbours: pair them at random
+            free = [i for i in range(n) if i not in taken]
+            self.rng.shuffle(free)
+            chosen += [(min(a, b), max(a, b)) for a, b in zip(free[::2], free[1::2])]
+        return chosen
 
     def swap(self):
         """Propose a position swap between randomly paired chains (parallel.py:190-231)."""
