@@ -260,6 +260,9 @@ int gpmi_profile_enable(gpmi_ctx* ctx, int on);
 int gpmi_profile_read(gpmi_ctx* ctx, int klass, int64_t* launches, double* ms, double* flops,
                       double* bytes);
 int gpmi_profile_reset(gpmi_ctx* ctx);
+/* shader clock (GHz) held during the stamped trailing-update launches since the last reset: cycles (s_memtime)
+ * over wall time (s_memrealtime) of the first workgroups of every launch; 0 if nothing was stamped */
+int gpmi_profile_clock(gpmi_ctx* ctx, double* ghz);
 
 /* ---- device-pointer entry points (kernel tests / micro-benchmarks) -------------------
  * Matrices are row-major with leading dimension ld (multiple of 128); n multiple of 128. */

@@ -49,31 +49,44 @@ constexpr int RED_SLOTS = 8192;  // per-lane result slots for batched evaluation
 
 int lane_streams(gpmi_ctx* c, Lane& L) {
   HIPCHK(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-  // CU-masked pair for the look-ahead: mask bits are dealt round-robin over the 8 XCDs (probed with
-  // tools/cumask_probe.hip), so the first 32 bits are 4 CUs on every XCD
   hipDeviceProp_t prop;
   HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
-  const int ncu = prop.multiProcessorCount;
-  c->ncu = ncu;
-  c->ncu_upd = ncu;
-  if (ncu >= 64 && ncu % 32 == 0) {
-    std::vector<uint32_t> panel((size_t)ncu / 32, 0u), upd((size_t)ncu / 32, 0xffffffffu);
-    panel[0] = 0xffffffffu;
-    upd[0] = 0u;
-    if (hipExtStreamCreateWithCUMask(&L.stream2, (uint32_t)panel.size(), panel.data()) != hipSuccess ||
-        hipExtStreamCreateWithCUMask(&L.stream_upd, (uint32_t)upd.size(), upd.data()) != hipSuccess) {
-      if (L.stream2) (void)hipStreamDestroy(L.stream2);
-      L.stream2 = L.stream_upd = nullptr;  // no look-ahead: everything on the full-chip stream
-      (void)hipGetLastError();
-    } else {
-      c->ncu_upd = ncu - 32;
-    }
-  }
+  c->ncu = prop.multiProcessorCount;
   HIPCHK(c, hipEventCreateWithFlags(&L.ev_la, hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&L.ev_panel, hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&L.ev_main, hipEventDisableTiming));
   return GPMI_OK;
 }
+
+}  // namespace
+
+// CU-masked stream pair k of the look-ahead, created the first time a lane needs it (most lanes of a
+// many-stream sweep never factorise with look-ahead, and every stream beyond the runtime's hardware-queue
+// budget shares a queue with another one).  Mask bits are dealt round-robin over the 8 XCDs (probed with
+// tools/cumask_probe.hip), so the first 8 m bits are m CUs on every XCD.  false: no masked streams on this
+// device / runtime, everything stays on the full-chip stream.
+bool ensure_masked_pair(gpmi_ctx* c, Lane& L, int k) {
+  if (L.masked_tried[k]) return L.sp[k] != nullptr;
+  L.masked_tried[k] = true;
+  const int ncu = c->ncu;
+  if (ncu < 64 || ncu % 32 != 0) return false;
+  std::vector<uint32_t> panel((size_t)ncu / 32, 0u), upd((size_t)ncu / 32, 0xffffffffu);
+  const uint32_t bits = (c->pair_cus[k] >= 32) ? 0xffffffffu : ((1u << c->pair_cus[k]) - 1u);
+  panel[0] = bits;
+  upd[0] = ~bits;
+  if (hipExtStreamCreateWithCUMask(&L.sp[k], (uint32_t)panel.size(), panel.data()) != hipSuccess ||
+      hipExtStreamCreateWithCUMask(&L.su[k], (uint32_t)upd.size(), upd.data()) != hipSuccess) {
+    if (L.sp[k]) (void)hipStreamDestroy(L.sp[k]);
+    if (L.su[k]) (void)hipStreamDestroy(L.su[k]);
+    L.sp[k] = L.su[k] = nullptr;
+    (void)hipGetLastError();
+    return false;
+  }
+  return true;
+}
+
+namespace {
 
 int lane_alloc(gpmi_ctx* c, Lane& L) {
   if (int rc = lane_streams(c, L)) return rc;
@@ -90,13 +103,18 @@ int lane_alloc(gpmi_ctx* c, Lane& L) {
 
 void lane_free(Lane& L) {
   if (L.stream) (void)hipStreamSynchronize(L.stream);
-  if (L.stream2) (void)hipStreamSynchronize(L.stream2);
-  if (L.stream_upd) (void)hipStreamSynchronize(L.stream_upd);
+  for (int k = 0; k < GPMI_NPAIRS; ++k) {
+    if (L.sp[k]) (void)hipStreamSynchronize(L.sp[k]);
+    if (L.su[k]) (void)hipStreamSynchronize(L.su[k]);
+  }
   if (L.ev_la) (void)hipEventDestroy(L.ev_la);
   if (L.ev_panel) (void)hipEventDestroy(L.ev_panel);
   if (L.ev_join) (void)hipEventDestroy(L.ev_join);
-  if (L.stream2) (void)hipStreamDestroy(L.stream2);
-  if (L.stream_upd) (void)hipStreamDestroy(L.stream_upd);
+  if (L.ev_main) (void)hipEventDestroy(L.ev_main);
+  for (int k = 0; k < GPMI_NPAIRS; ++k) {
+    if (L.sp[k]) (void)hipStreamDestroy(L.sp[k]);
+    if (L.su[k]) (void)hipStreamDestroy(L.su[k]);
+  }
   if (L.A) (void)hipFree(L.A);
   if (L.B2) (void)hipFree(L.B2);
   if (L.inv2) (void)hipFree(L.inv2);
@@ -430,6 +448,7 @@ int gpmi_destroy(gpmi_ctx* c) {
     (void)hipEventDestroy(sl.e1);
   }
   if (c->stamp_pool) (void)hipFree(c->stamp_pool);
+  if (c->dev_masked) (void)hipStreamDestroy(c->dev_masked);
   if (c->trsm_panel) (void)hipFree(c->trsm_panel);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->t0) (void)hipEventDestroy(c->t0);
@@ -445,8 +464,10 @@ int gpmi_sync(gpmi_ctx* c) {
   if (set_device(c)) return GPMI_ERR_HIP;
   for (auto& L : c->lanes) {
     HIPCHK(c, hipStreamSynchronize(L.stream));
-    if (L.stream2) HIPCHK(c, hipStreamSynchronize(L.stream2));
-    if (L.stream_upd) HIPCHK(c, hipStreamSynchronize(L.stream_upd));
+    for (int k = 0; k < GPMI_NPAIRS; ++k) {
+      if (L.sp[k]) HIPCHK(c, hipStreamSynchronize(L.sp[k]));
+      if (L.su[k]) HIPCHK(c, hipStreamSynchronize(L.su[k]));
+    }
   }
   return GPMI_OK;
 }
@@ -1043,6 +1064,16 @@ static int dev_stream(gpmi_ctx* c, hipStream_t* s) {
     if (int rc = lane_streams(c, c->lanes[0])) return rc;
   }
   *s = c->lanes[0].stream;
+  // tools only (tools/cu_scaling.sh): GPMI_DEV_CUS=<n> runs the device-pointer entry points on n CUs (n / 8 per XCD)
+  if (const char* e = std::getenv("GPMI_DEV_CUS")) {
+    if (!c->dev_masked) {
+      const int n = std::atoi(e);
+      std::vector<uint32_t> m((size_t)c->ncu / 32, 0u);
+      for (int i = 0; i < n && i < c->ncu; ++i) m[(size_t)i / 32] |= 1u << (i % 32);
+      HIPCHK(c, hipExtStreamCreateWithCUMask(&c->dev_masked, (uint32_t)m.size(), m.data()));
+    }
+    *s = c->dev_masked;
+  }
   return GPMI_OK;
 }
 
@@ -1093,6 +1124,10 @@ static int profile_collect(gpmi_ctx* c) {
         if (w[8 + j] > t1) t1 = w[8 + j];
       }
       if (t1 <= t0) continue;  // launch never ran
+      for (int j = 0; j < 8; ++j) {
+        c->prof_clock_cycles += (double)(w[16 + j] >> 32);
+        c->prof_clock_ticks += (double)(w[16 + j] & 0xffffffffull);
+      }
       c->prof_ms[GPMI_PROF_SYRK] += (double)(t1 - t0) * 1e-5;  // 10 ns ticks -> ms
       c->prof_flops[GPMI_PROF_SYRK] += c->stamp_flops[i];
       c->prof_bytes[GPMI_PROF_SYRK] += c->stamp_bytes[i];
@@ -1119,6 +1154,13 @@ int gpmi_profile_read(gpmi_ctx* c, int klass, int64_t* launches, double* ms, dou
   return GPMI_OK;
 }
 
+int gpmi_profile_clock(gpmi_ctx* c, double* ghz) {
+  if (!c || !ghz) return GPMI_ERR_ARG;
+  if (int rc = profile_collect(c)) return rc;
+  *ghz = (c->prof_clock_ticks > 0.0) ? c->prof_clock_cycles / c->prof_clock_ticks * 0.1 : 0.0;
+  return GPMI_OK;
+}
+
 int gpmi_profile_reset(gpmi_ctx* c) {
   if (!c) return GPMI_ERR_ARG;
   if (int rc = profile_collect(c)) return rc;
@@ -1126,6 +1168,7 @@ int gpmi_profile_reset(gpmi_ctx* c) {
     c->prof_ms[k] = c->prof_flops[k] = c->prof_bytes[k] = 0.0;
     c->prof_launches[k] = 0;
   }
+  c->prof_clock_cycles = c->prof_clock_ticks = 0.0;
   return GPMI_OK;
 }
 

@@ -20,6 +20,17 @@
 // It issues every 64 cycles per SIMD: 256 CUs x 4 SIMDs x 2048 FLOP / 64 clk x 2.4 GHz = 78.6 TFLOP/s.
 #include "gpmi_internal.h"
 
+// C tiles are read once and written once per launch: those accesses are marked non-temporal so that they do not
+// displace the operand panels (re-read by every tile of a strip) from the XCD's L2 (+0.5 % on the trailing update;
+// -DGPMI_C_PLAIN builds the plain form for comparison)
+#ifndef GPMI_C_PLAIN
+#define GPMI_C_LOAD(p) __builtin_nontemporal_load(p)
+#define GPMI_C_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define GPMI_C_LOAD(p) (*(p))
+#define GPMI_C_STORE(v, p) (*(p) = (v))
+#endif
+
 namespace {
 
 constexpr int BK = 16;
@@ -120,8 +131,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   // an L2, so the word keeps the value of whoever finished last there; the host takes min / max.  (Device-scope
   // atomicMin / atomicMax on one address from ~8000 workgroups cost 1 ms per step, and an atomic issued
   // at the start sat in front of the first operand loads in the wave's in-order memory queue.)
-  if (g.stamp && tid == 0 && blockIdx.x < 8 && blockIdx.z == 0)
-    g.stamp[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+  const bool stamp_first = g.stamp && tid == 0 && blockIdx.x < 8 && blockIdx.z == 0;
+  unsigned long long c_start = 0, r_start = 0;
+  if (stamp_first) {
+    r_start = __builtin_amdgcn_s_memrealtime();
+    c_start = __builtin_amdgcn_s_memtime();
+    g.stamp[blockIdx.x] = r_start;
+  }
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int kbeg = (g.kskip == 1) ? ti * BM : 0;
@@ -189,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     for (int j = 0; j < TN; ++j) {
       if (OP == OP_SUB) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = Cg[(int64_t)(i * 16 + fk + 4 * r) * g.ldc + j * 16 + fr];
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = GPMI_C_LOAD(&Cg[(int64_t)(i * 16 + fk + 4 * r) * g.ldc + j * 16 + fr]);
       } else {
         acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
       }
@@ -245,8 +261,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Cg[(int64_t)(i * 16 + fk + 4 * r) * g.ldc + j * 16 + fr] = acc[i][j][r];
+      for (int r = 0; r < 4; ++r) GPMI_C_STORE(acc[i][j][r], &Cg[(int64_t)(i * 16 + fk + 4 * r) * g.ldc + j * 16 + fr]);
   if (stamp_end) g.stamp[8 + (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 7)] = t_end;
+  // shader clock seen by the launch's first eight workgroups over their own lifetime: cycles (s_memtime) in the
+  // high word, 10 ns ticks (s_memrealtime) in the low word -> clock = cycles / ticks x 100 MHz
+  if (stamp_first)
+    g.stamp[16 + blockIdx.x] = ((__builtin_amdgcn_s_memtime() - c_start) << 32) |
+                               ((__builtin_amdgcn_s_memrealtime() - r_start) & 0xffffffffull);
 }
 
 }  // namespace

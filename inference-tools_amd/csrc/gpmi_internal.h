@@ -10,6 +10,7 @@
 
 constexpr int GPMI_NB = 128;     // tile / inner block size: every device matrix dimension is a multiple
 constexpr int GPMI_MAX_D = 64;   // max spatial dimensions handled by the covariance kernels
+constexpr int GPMI_NPAIRS = 1;   // CU-masked stream pairs of the look-ahead (32 | 224 CUs)
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -35,10 +36,12 @@ struct ProfSlot {
 // One independent evaluation lane: a stream with its own n x n scratch matrix and vectors.
 struct Lane {
   hipStream_t stream = nullptr;    // full-chip stream: covariance build, solves, small factorisations
-  // look-ahead pair (CU-masked, disjoint): trailing updates on 224 CUs, next panel on the other 32
-  hipStream_t stream_upd = nullptr;
-  hipStream_t stream2 = nullptr;
-  hipEvent_t ev_la = nullptr, ev_panel = nullptr, ev_join = nullptr;
+  // look-ahead pairs (CU-masked, disjoint; created on first use): pair k factors the next panel on
+  // gpmi_ctx::pair_cus[k] CUs (sp) while the trailing update runs on all the others (su)
+  hipStream_t sp[GPMI_NPAIRS] = {nullptr};
+  hipStream_t su[GPMI_NPAIRS] = {nullptr};
+  bool masked_tried[GPMI_NPAIRS] = {false};
+  hipEvent_t ev_la = nullptr, ev_panel = nullptr, ev_join = nullptr, ev_main = nullptr;
   double* A = nullptr;      // np x ld scratch (K then L)
   double* invD = nullptr;   // (np/128) x 128 x 128 inverses of the diagonal blocks
   double* B2 = nullptr;     // second np x ld matrix (L^-T for the gradient / LOO paths), allocated lazily
@@ -81,7 +84,7 @@ struct LinvState {
 struct gpmi_ctx {
   int device = 0;
   int ncu = 256;      // compute units of the device
-  int ncu_upd = 224;  // ... of the CU-masked trailing-update stream (look-ahead regime)
+  int pair_cus[GPMI_NPAIRS] = {32};  // CUs of the panel stream of look-ahead pair k (the update stream has the rest)
   std::string err;
   // data
   int64_t n = 0, d = 0, np = 0, ld = 0;
@@ -131,6 +134,7 @@ struct gpmi_ctx {
   hipStream_t comm_stream = nullptr;
   double* comm_buf = nullptr;
   int64_t comm_buf_doubles = 0;
+  hipStream_t dev_masked = nullptr;  // tools: CU-masked stream of the device-pointer entry points (GPMI_DEV_CUS)
   // instrumentation
   hipEvent_t t0 = nullptr, t1 = nullptr;
   unsigned prof_mask = 0;
@@ -139,6 +143,7 @@ struct gpmi_ctx {
   std::vector<double> stamp_flops, stamp_bytes;
   std::vector<ProfSlot> prof_slots;
   size_t prof_used = 0;
+  double prof_clock_cycles = 0.0, prof_clock_ticks = 0.0;  // shader cycles / 10 ns ticks over stamped workgroups
   double prof_ms[GPMI_PROF_NCLASS] = {0, 0, 0, 0};
   double prof_flops[GPMI_PROF_NCLASS] = {0, 0, 0, 0};
   double prof_bytes[GPMI_PROF_NCLASS] = {0, 0, 0, 0};
@@ -147,7 +152,7 @@ struct gpmi_ctx {
 
 // instrumentation helpers (api.hip)
 constexpr int GPMI_STAMP_SLOTS = 16384;
-constexpr int GPMI_STAMP_WORDS = 16;  // per launch: 8 start words + 8 end words (one per XCD), see gemm_f64.hip
+constexpr int GPMI_STAMP_WORDS = 24;  // per launch: 8 start words + 8 end words (one per XCD) + 8 clock words, see gemm_f64.hip
 // next stamp slot (GPMI_STAMP_WORDS words) for a trailing-update launch, or nullptr when that class is not profiled
 unsigned long long* prof_stamp_slot(gpmi_ctx* c, double flops, double bytes);
 struct ProfScope {
@@ -237,7 +242,7 @@ void launch_kbuild_square_batched(hipStream_t s, const KParams* pdev, int batch,
 // blocked right-looking Cholesky, in place, lower; invD receives the inverses of the diagonal blocks
 // allow_lookahead = false keeps everything on the lane's full-chip stream (several lanes running
 // concurrently already fill the chip, and their masked stream pairs would only fight for HW queues)
-void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t ld, double* invD,
+void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, double* invD,
                  int* info, bool allow_lookahead = true);
 
 // solve.hip

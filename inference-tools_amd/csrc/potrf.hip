@@ -11,6 +11,7 @@
 // column + 1); the factorisation then continues with a unit pivot so that the launch sequence stays
 // asynchronous — the host inspects `info` once at the end (regression.py:540-542 behaviour).
 #include <cstdlib>
+#include <vector>
 
 #include "gpmi_internal.h"
 
@@ -404,16 +405,15 @@ void factor_panel(gpmi_ctx* c, hipStream_t sp, double* A, int64_t ld, double* in
   }
 }
 
-// trailing update of tile columns [c0, c1) (relative to the trailing matrix, rows c0 .. rem):
-// A22 -= P P^T with P = A[Je.., J..Je), K = (Je - J) * 128, lower tiles only
-void trailing_update(gpmi_ctx* c, hipStream_t s, double* A, int64_t ld, int nt, int J, int Je, int c0,
-                     int c1, int ncu) {
-  const int rem = nt - Je;
-  const int kw = (Je - J) * NB;
-  const int rows = rem - c0, cols = c1 - c0;
-  if (rows <= 0 || cols <= 0) return;
-  double* P = A + (int64_t)(Je + c0) * NB * ld + (int64_t)J * NB;
-  double* C = A + (int64_t)(Je + c0) * NB * ld + (int64_t)(Je + c0) * NB;
+// Update of the tile columns [t0, t1) (rows t0 .. nt, lower tiles) by the factored tile columns [ka, ke):
+// A[t0.., t0..t1) -= P P^T with P = A[t0.., ka..ke), K = (ke - ka) * 128.
+void update_columns(gpmi_ctx* c, hipStream_t s, double* A, int64_t ld, int nt, int t0, int t1, int ka, int ke,
+                    int ncu) {
+  const int rows = nt - t0, cols = t1 - t0;
+  const int kw = (ke - ka) * NB;
+  if (rows <= 0 || cols <= 0 || kw <= 0) return;
+  double* P = A + (int64_t)t0 * NB * ld + (int64_t)ka * NB;
+  double* C = A + (int64_t)t0 * NB * ld + (int64_t)t0 * NB;
   const int64_t tiles = (int64_t)cols * (cols + 1) / 2 + (int64_t)(rows - cols) * cols;
   // the tiles of a nearly empty last round (of `ncu` tiles) run as 64 x 64 tiles in a second launch
   const int64_t nfull = gemm_split_point(tiles, ncu, kw);
@@ -428,63 +428,66 @@ void trailing_update(gpmi_ctx* c, hipStream_t s, double* A, int64_t ld, int nt, 
 
 }  // namespace
 
-void potrf_lower(gpmi_ctx* c, const Lane& lane, double* A, int64_t np, int64_t ld, double* invD,
-                 int* info, bool allow_lookahead) {
-  // Two regimes (GPMI_LOOKAHEAD_MIN=<tile rows> moves the switch, 0 disables the look-ahead).
-  // While the trailing matrix is large, look-ahead over two CU-masked streams: the
-  // panel stream (32 CUs, 4 per XCD) factors outer panel J+1 while the update stream (the other 224
-  // CUs) still applies the trailing update of panel J to the columns right of it — disjoint CUs,
-  // because a 75 KiB potrf_diag workgroup never finds a slot on a chip saturated by GEMM
-  // workgroups.  Once the trailing update is shorter than a panel factorisation everything runs in
-  // order on the full-chip stream.
-  hipStream_t sf = lane.stream, su = lane.stream_upd, sp = lane.stream2;
+bool ensure_masked_pair(gpmi_ctx* c, Lane& L, int k);  // api.hip
+
+void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, double* invD, int* info,
+                 bool allow_lookahead) {
+  // Right-looking over outer panels of 512 columns (4 tile columns), software-pipelined: step p applies
+  // the trailing update of panel p and factors panel p + 1.  While the trailing matrix is large the two
+  // overlap on a pair of CU-masked streams (disjoint CUs: a 75 KiB potrf_diag workgroup never finds a slot
+  // on a chip saturated by GEMM workgroups): the update stream first updates the columns of panel p + 1
+  // ("la"), the panel stream then factors them on 32 CUs while the update stream applies the rest on the
+  // other 224.  Below GPMI_LOOKAHEAD_MIN trailing tile rows the update is shorter than the panel chain and
+  // everything runs in order on the full-chip stream - and so does the very first panel (nothing to overlap
+  // it with: 0.49 instead of 0.92 ms).
+  //   GPMI_LOOKAHEAD_MIN=<tile rows>  end of the look-ahead regime (0 disables it)
+  // Measured and dropped: a second pair with 16 | 240 CUs for the early panels (the
+  // update is bound by the chip's power budget: 224, 240 and 256 CUs deliver the same FLOP/s, in-kernel clock
+  // 2.05 / 1.97 GHz); trailing updates applied lazily with K = 1024 .. 2048 (in place the launches are already
+  // split at round boundaries, which leaves +1 % for the larger K, and the narrower launches cost more).
+  hipStream_t sf = lane.stream;
   const int nt = (int)(np / NB);
-  const int OBT = 4;            // outer panel = 4 inner blocks = 512 columns
-  // trailing tile rows below which the look-ahead stops paying (GPMI_LOOKAHEAD_MIN overrides; 0 disables)
+  const int OBT = 4;  // tile columns per outer panel
   static const int LOOKAHEAD_MIN = [] {
     const char* e = std::getenv("GPMI_LOOKAHEAD_MIN");
     const int v = e ? std::atoi(e) : 44;
     return v > 0 ? v : (1 << 30);
   }();
-  bool overlapped = false;
-  for (int J = 0; J < nt; J += OBT) {
-    const int Je = (J + OBT < nt) ? J + OBT : nt;
-    const int rem = nt - Je;
-    const bool want = allow_lookahead && (sp != nullptr) && (rem >= LOOKAHEAD_MIN);
-    if (want && !overlapped) {
-      // enter the look-ahead regime: both masked streams start after everything queued so far
-      (void)hipEventRecord(lane.ev_join, sf);
-      (void)hipStreamWaitEvent(sp, lane.ev_join, 0);
-      (void)hipStreamWaitEvent(su, lane.ev_join, 0);
-      overlapped = true;
-    } else if (!want && overlapped) {
-      // leave it: the full-chip stream continues after both masked streams have drained
-      (void)hipEventRecord(lane.ev_join, su);
-      (void)hipStreamWaitEvent(sf, lane.ev_join, 0);
-      (void)hipEventRecord(lane.ev_panel, sp);
-      (void)hipStreamWaitEvent(sf, lane.ev_panel, 0);
-      overlapped = false;
-    }
-    if (overlapped) {
-      factor_panel(c, sp, A, ld, invD, info, nt, J, Je);
-      (void)hipEventRecord(lane.ev_panel, sp);
-      (void)hipStreamWaitEvent(su, lane.ev_panel, 0);
-      const int la = rem < OBT ? rem : OBT;
-      trailing_update(c, su, A, ld, nt, J, Je, 0, la, c->ncu_upd);  // columns of the next panel first
+  const bool la_ok = allow_lookahead && nt - OBT >= LOOKAHEAD_MIN && ensure_masked_pair(c, lane, 0);
+  auto follow = [](hipStream_t waiter, hipStream_t producer, hipEvent_t ev) {
+    if (waiter != producer) (void)hipStreamWaitEvent(waiter, ev, 0);
+  };
+  auto tile0 = [&](int panel) { return panel * OBT < nt ? panel * OBT : nt; };  // first tile column of a panel
+  const int NP = (nt + OBT - 1) / OBT;
+  factor_panel(c, sf, A, ld, invD, info, nt, 0, tile0(1));
+  hipStream_t panel_stream = sf;  // where the latest panel was factored (ev_panel recorded behind it)
+  hipStream_t main_stream = sf;   // where the latest trailing update ran (ev_main recorded behind it)
+  (void)hipEventRecord(lane.ev_panel, sf);
+  (void)hipEventRecord(lane.ev_main, sf);
+  for (int p = 0; p + 1 < NP; ++p) {
+    const int k0 = tile0(p), k1 = tile0(p + 1);  // tile columns of the panel being applied
+    const int rem = nt - k1;                      // trailing tile rows
+    const bool overlap = la_ok && rem >= LOOKAHEAD_MIN;
+    hipStream_t su = overlap ? lane.su[0] : sf, sp = overlap ? lane.sp[0] : sf;
+    const int ncu = overlap ? c->ncu - c->pair_cus[0] : c->ncu;
+    follow(su, panel_stream, lane.ev_panel);
+    follow(su, main_stream, lane.ev_main);
+    if (overlap) {
+      update_columns(c, su, A, ld, nt, k1, tile0(p + 2), k0, k1, ncu);  // the columns of the next panel first
       (void)hipEventRecord(lane.ev_la, su);
       (void)hipStreamWaitEvent(sp, lane.ev_la, 0);
-      trailing_update(c, su, A, ld, nt, J, Je, la, rem, c->ncu_upd);
+      update_columns(c, su, A, ld, nt, tile0(p + 2), nt, k0, k1, ncu);
+      (void)hipEventRecord(lane.ev_main, su);
     } else {
-      factor_panel(c, sf, A, ld, invD, info, nt, J, Je);
-      trailing_update(c, sf, A, ld, nt, J, Je, 0, rem, c->ncu);
+      update_columns(c, su, A, ld, nt, k1, nt, k0, k1, ncu);
     }
+    main_stream = su;
+    factor_panel(c, sp, A, ld, invD, info, nt, k1, tile0(p + 2));
+    if (overlap) (void)hipEventRecord(lane.ev_panel, sp);
+    panel_stream = sp;
   }
-  if (overlapped) {
-    (void)hipEventRecord(lane.ev_join, su);
-    (void)hipStreamWaitEvent(sf, lane.ev_join, 0);
-    (void)hipEventRecord(lane.ev_panel, sp);
-    (void)hipStreamWaitEvent(sf, lane.ev_panel, 0);
-  }
+  follow(sf, panel_stream, lane.ev_panel);
+  follow(sf, main_stream, lane.ev_main);
 }
 
 void potrf_lower_batched(gpmi_ctx* c, hipStream_t s, double* A, int64_t np, int64_t ld, double* invD,

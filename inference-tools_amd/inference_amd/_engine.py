@@ -285,6 +285,12 @@ class GpEngine:
         self.h.call("gpmi_profile_read", klass, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))
         return {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
 
+    def profile_clock(self):
+        """Shader clock (GHz) over the stamped trailing-update launches since the last reset."""
+        ghz = C.c_double(0.0)
+        self.h.call("gpmi_profile_clock", C.byref(ghz))
+        return ghz.value
+
     def sync(self):
         self.h.call("gpmi_sync")
 

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgpmi.so")
+# GPMI_LIB: another build of the same library (A/B timing of kernel variants: tools/ab_lib.sh); never a fallback
+LIB_PATH = os.environ.get("GPMI_LIB") or os.path.join(_HERE, "lib", "libgpmi.so")
 
 KERNEL_SE = 0
 KERNEL_RQ = 1
@@ -78,6 +79,7 @@ SIGNATURES = {
     "gpmi_profile_enable": (C.c_int, [_vp, C.c_int]),
     "gpmi_profile_read": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), _dp, _dp, _dp]),
     "gpmi_profile_reset": (C.c_int, [_vp]),
+    "gpmi_profile_clock": (C.c_int, [_vp, _dp]),
     "gpmi_dev_alloc": (C.c_int, [_vp, _i64, C.POINTER(_vp)]),
     "gpmi_dev_free": (C.c_int, [_vp, _vp]),
     "gpmi_dev_upload": (C.c_int, [_vp, _vp, _vp, _i64]),

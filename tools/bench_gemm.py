@@ -36,5 +36,7 @@ for _ in range(reps):
 cnt = C.c_int64()
 ms, fl, by = C.c_double(), C.c_double(), C.c_double()
 h.call("gpmi_profile_read", _lib.PROF_SYRK, C.byref(cnt), C.byref(ms), C.byref(fl), C.byref(by))
-print(f"n={n} k={k} lower={lower} hot={hot}: {ms.value / cnt.value:.3f} ms/launch, {fl.value / ms.value / 1e9:.2f} TFLOP/s "
+ghz = C.c_double()
+h.call("gpmi_profile_clock", C.byref(ghz))
+print(f"clock {ghz.value:.3f} GHz | n={n} k={k} lower={lower} hot={hot}: {ms.value / cnt.value:.3f} ms/launch, {fl.value / ms.value / 1e9:.2f} TFLOP/s "
       f"({100 * fl.value / ms.value / 1e9 / 78.6:.1f}% of 78.6)")
