@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include "gpmi_internal.h"
 
@@ -61,29 +63,44 @@ int lane_streams(gpmi_ctx* c, Lane& L) {
 
 }  // namespace
 
-// CU-masked stream pair k of the look-ahead, created the first time a lane needs it (most lanes of a
-// many-stream sweep never factorise with look-ahead, and every stream beyond the runtime's hardware-queue
-// budget shares a queue with another one).  Mask bits are dealt round-robin over the 8 XCDs (probed with
-// tools/cumask_probe.hip), so the first 8 m bits are m CUs on every XCD.  false: no masked streams on this
+// CU-masked stream pair k of the look-ahead.  The pairs live in a process-wide pool, one per device, created the
+// first time any lane needs them and NEVER destroyed: hipStreamDestroy on a CU-masked stream blocks forever on
+// ROCm 7.2 unless the stream was synchronised twice before (tools/probe_exit.py), and streams beyond the runtime's
+// hardware-queue budget share queues anyway.  Contexts on one device share the pair; work of two contexts that
+// factorise at the same time is merely serialised on it.  Mask bits are dealt round-robin over the 8 XCDs (probed
+// with tools/cumask_probe.hip), so the first 8 m bits are m CUs on every XCD.  false: no masked streams on this
 // device / runtime, everything stays on the full-chip stream.
+namespace {
+struct MaskedPair {
+  hipStream_t sp = nullptr, su = nullptr;
+  bool tried = false;
+};
+std::mutex g_pool_mutex;
+std::map<std::pair<int, int>, MaskedPair> g_pool;  // (device, pair index) -> streams
+}  // namespace
+
 bool ensure_masked_pair(gpmi_ctx* c, Lane& L, int k) {
   if (L.masked_tried[k]) return L.sp[k] != nullptr;
   L.masked_tried[k] = true;
   const int ncu = c->ncu;
   if (ncu < 64 || ncu % 32 != 0) return false;
-  std::vector<uint32_t> panel((size_t)ncu / 32, 0u), upd((size_t)ncu / 32, 0xffffffffu);
-  const uint32_t bits = (c->pair_cus[k] >= 32) ? 0xffffffffu : ((1u << c->pair_cus[k]) - 1u);
-  panel[0] = bits;
-  upd[0] = ~bits;
-  if (hipExtStreamCreateWithCUMask(&L.sp[k], (uint32_t)panel.size(), panel.data()) != hipSuccess ||
-      hipExtStreamCreateWithCUMask(&L.su[k], (uint32_t)upd.size(), upd.data()) != hipSuccess) {
-    if (L.sp[k]) (void)hipStreamDestroy(L.sp[k]);
-    if (L.su[k]) (void)hipStreamDestroy(L.su[k]);
-    L.sp[k] = L.su[k] = nullptr;
-    (void)hipGetLastError();
-    return false;
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  MaskedPair& mp = g_pool[{c->device, k}];
+  if (!mp.tried) {
+    mp.tried = true;
+    std::vector<uint32_t> panel((size_t)ncu / 32, 0u), upd((size_t)ncu / 32, 0xffffffffu);
+    const uint32_t bits = (c->pair_cus[k] >= 32) ? 0xffffffffu : ((1u << c->pair_cus[k]) - 1u);
+    panel[0] = bits;
+    upd[0] = ~bits;
+    if (hipExtStreamCreateWithCUMask(&mp.sp, (uint32_t)panel.size(), panel.data()) != hipSuccess ||
+        hipExtStreamCreateWithCUMask(&mp.su, (uint32_t)upd.size(), upd.data()) != hipSuccess) {
+      mp.sp = mp.su = nullptr;  // a half-created pair is left alone (see above)
+      (void)hipGetLastError();
+    }
   }
-  return true;
+  L.sp[k] = mp.sp;
+  L.su[k] = mp.su;
+  return L.sp[k] != nullptr;
 }
 
 namespace {
@@ -101,20 +118,22 @@ int lane_alloc(gpmi_ctx* c, Lane& L) {
   return GPMI_OK;
 }
 
+#define DBG_FREE(msg) do { if (std::getenv("GPMI_DEBUG_FREE")) std::fprintf(stderr, "[free] %s\n", msg); } while (0)
 void lane_free(Lane& L) {
+  DBG_FREE("lane: sync main stream");
   if (L.stream) (void)hipStreamSynchronize(L.stream);
+  DBG_FREE("lane: sync masked streams");
   for (int k = 0; k < GPMI_NPAIRS; ++k) {
     if (L.sp[k]) (void)hipStreamSynchronize(L.sp[k]);
     if (L.su[k]) (void)hipStreamSynchronize(L.su[k]);
   }
+  DBG_FREE("lane: destroy events");
   if (L.ev_la) (void)hipEventDestroy(L.ev_la);
   if (L.ev_panel) (void)hipEventDestroy(L.ev_panel);
   if (L.ev_join) (void)hipEventDestroy(L.ev_join);
   if (L.ev_main) (void)hipEventDestroy(L.ev_main);
-  for (int k = 0; k < GPMI_NPAIRS; ++k) {
-    if (L.sp[k]) (void)hipStreamDestroy(L.sp[k]);
-    if (L.su[k]) (void)hipStreamDestroy(L.su[k]);
-  }
+  // the masked streams belong to the process-wide pool (ensure_masked_pair): not destroyed here
+  DBG_FREE("lane: free buffers");
   if (L.A) (void)hipFree(L.A);
   if (L.B2) (void)hipFree(L.B2);
   if (L.inv2) (void)hipFree(L.inv2);
@@ -126,7 +145,9 @@ void lane_free(Lane& L) {
   if (L.info) (void)hipFree(L.info);
   if (L.h_red) (void)hipHostFree(L.h_red);
   if (L.h_info) (void)hipHostFree(L.h_info);
+  DBG_FREE("lane: destroy main stream");
   if (L.stream) (void)hipStreamDestroy(L.stream);
+  DBG_FREE("lane: done");
   L = Lane();
 }
 
@@ -441,8 +462,11 @@ int gpmi_create(int device, gpmi_ctx** out) {
 int gpmi_destroy(gpmi_ctx* c) {
   if (!c) return GPMI_OK;
   (void)hipSetDevice(c->device);
+  DBG_FREE("comm destroy");
   (void)gpmi_comm_destroy(c);
+  DBG_FREE("free data");
   free_data(c);
+  DBG_FREE("rest");
   for (auto& sl : c->prof_slots) {
     (void)hipEventDestroy(sl.e0);
     (void)hipEventDestroy(sl.e1);

@@ -368,10 +368,27 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
 
 }  // namespace
 
+namespace {
+// test hook (tests/test_gpu_parity.py::test_suite_detects_a_1e11_fault): scales the factored diagonal block
+__global__ void fault_scale_kernel(double* A, int64_t ld, double f, int64_t strideA) {
+  A += (int64_t)blockIdx.z * strideA;
+  const int r = blockIdx.x, c = threadIdx.x;
+  if (c <= r) A[(int64_t)r * ld + c] *= f;
+}
+}  // namespace
+
 void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0,
                        unsigned long long* dbg, const BatchShape& bs) {
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, 1, (unsigned)bs.count), dim3(DIAG_THREADS), 0, s, Ablk, ld, invD,
                      info, col0, dbg, bs.sMat, bs.sInv);
+  // GPMI_FAULT_DIAG_EPS=<eps>: fault injection for the test suite's own sensitivity check, never set otherwise
+  static const double fault = [] {
+    const char* e = std::getenv("GPMI_FAULT_DIAG_EPS");
+    return e ? std::atof(e) : 0.0;
+  }();
+  if (fault != 0.0)
+    hipLaunchKernelGGL(fault_scale_kernel, dim3(NB, 1, (unsigned)bs.count), dim3(NB), 0, s, Ablk, ld, 1.0 + fault,
+                       bs.sMat);
 }
 
 namespace {

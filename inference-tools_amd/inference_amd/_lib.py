@@ -6,8 +6,11 @@ inference-tools_amd/csrc` into `inference_amd/lib/libgpmi.so`.  Nothing here
 falls back to a CPU implementation: a missing library or device raises
 `GpmiUnavailable`.
 """
+import atexit
 import ctypes as C
 import os
+import sys
+import weakref
 
 import numpy as np
 
@@ -106,6 +109,7 @@ def load():
             fn.restype = res
             fn.argtypes = args
         _lib = lib
+        atexit.register(_close_all_handles)
     return _lib
 
 
@@ -128,6 +132,21 @@ def as_f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+_live_handles = weakref.WeakSet()
+
+
+def _close_all_handles():
+    """Destroy every live context while the HIP runtime is still up.  Registered with atexit after the library is
+    loaded, so it runs BEFORE the runtime's own exit handlers: a context that is only collected during interpreter
+    shutdown (e.g. one kept alive by the traceback of a failed test) would otherwise synchronise streams of a
+    runtime that is already gone and hang the process."""
+    for h in list(_live_handles):
+        try:
+            h.close()
+        except Exception:
+            pass
+
+
 class Handle:
     """Owns one gpmi_ctx (one device, one set of streams / workspaces)."""
 
@@ -146,6 +165,7 @@ class Handle:
         if rc != 0:
             msg = lib.gpmi_last_error(None).decode()
             raise GpmiUnavailable(f"gpmi_create(device={device}) failed with status {rc}: {msg}")
+        _live_handles.add(self)
 
     def call(self, name, *args):
         rc = getattr(self.lib, name)(self.ctx, *args)
@@ -158,6 +178,8 @@ class Handle:
             self.ctx = _vp()
 
     def __del__(self):
+        if sys.is_finalizing():
+            return  # the atexit hook has already closed what was alive; never touch the runtime from here
         try:
             self.close()
         except Exception:

@@ -30,3 +30,22 @@ def golden():
         return cache[name]
 
     return load
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Achieved errors of the GPU parity comparisons (tests/test_gpu_parity.py logs every `check`): the worst
+    ratio error / tolerance per test and label."""
+    mod = sys.modules.get("test_gpu_parity") or sys.modules.get("tests.test_gpu_parity")
+    rows = getattr(mod, "ACHIEVED", None) if mod else None
+    if not rows:
+        return
+    worst = {}
+    for test, what, r, tol in rows:
+        key = (test, what)
+        if key not in worst or r > worst[key][0]:
+            worst[key] = (r, tol)
+    tr = terminalreporter
+    tr.section("achieved parity errors (max per test / quantity)")
+    for (test, what), (r, tol) in sorted(worst.items(), key=lambda kv: -(kv[1][0] / kv[1][1] if kv[1][1] > 0 else 0))[:60]:
+        tr.write_line(f"{r:9.2e}  (tol {tol:7.1e})  {test} :: {what}")
+    tr.write_line(f"... {len(worst)} quantities, {len(rows)} comparisons in all")

@@ -21,6 +21,10 @@ Cases
   cp         ChangePoint over [SE, SE], [SE, RQ], [SE, SE] + WhiteNoise, N=200 d=2
   het        SE + HeteroscedasticNoise, N=96: LML, gradient (99 parameters), fit + predict
   linv       GpLinearInverter: 1-D deconvolution (32 x 64) and 2-D tomography (300 x 400), SE / RQ / SE+WhiteNoise
+  search     the stochastic callers under numpy.random.seed: multistart_bfgs (start positions, theta*, LML(theta*); LML and
+             LOO objectives), differential_evo, AcquisitionFunction.starting_positions, GpOptimiser.propose_evaluation
+  means      LinearMean / QuadraticMean: labels, bounds, fit, predict, LML, LML gradient (mean-parameter components
+             included), LOO gradient, posterior
 """
 import os
 import sys
@@ -413,9 +417,135 @@ def case_linv():
     return out
 
 
+def t32_data():
+    rng = np.random.default_rng(1)
+    points = rng.uniform(low=0.0, high=2.0, size=(32, 2))
+    values = np.sin(points[:, 0]) * np.cos(points[:, 1]) + rng.normal(scale=0.1, size=32)
+    return points, values, np.full(32, 0.1)
+
+
+def bo_problem():
+    """The 2-D objective of the optimiser tests (shared with tests/test_gpu_parity.py)."""
+    def objective(x):
+        return np.sin(0.5 * x[0]) * 3 / (2 + 0.5 * (x[1] - 1.0) ** 2) + 0.1 * x[0]
+
+    rng = np.random.default_rng(4)
+    bounds = [(-4.0, 6.0), (-3.0, 5.0)]
+    x = rng.uniform([b[0] for b in bounds], [b[1] for b in bounds], size=(8, 2))
+    x[5] = [7.0, 1.0]  # one evaluation outside the search bounds: starting_positions draws a uniform start for it
+    y = np.array([objective(k) for k in x])
+    return x, y, bounds
+
+
+def case_search():
+    """The callers that draw random numbers, run under numpy.random.seed (the legacy global generator is what
+    regression.py:589-594, acquisition.py:21-35 and SciPy's differential_evolution use)."""
+    from inference.gp import GpOptimiser
+
+    out = {}
+    x, y, e = t32_data()
+    for tag, kw in (("lml", {}), ("loo", {"cross_val": True}), ("rq", {"kernel": RationalQuadratic})):
+        log = []
+        orig = GpRegressor.launch_bfgs
+
+        def spy(self, x0, _orig=orig, _log=log):
+            res = _orig(self, x0)
+            _log.append((np.array(x0), np.array(res[0]), float(res[1])))
+            return res
+
+        GpRegressor.launch_bfgs = spy
+        try:
+            np.random.seed(3)
+            gp = GpRegressor(x, y, y_err=e, optimizer="bfgs", n_starts=4, **kw)
+        finally:
+            GpRegressor.launch_bfgs = orig
+        out[f"ms_{tag}_starts"] = np.array([l[0] for l in log])
+        out[f"ms_{tag}_ends"] = np.array([l[1] for l in log])
+        out[f"ms_{tag}_fvals"] = np.array([l[2] for l in log])
+        out[f"ms_{tag}_theta"] = np.array(gp.hyperpars)
+        out[f"ms_{tag}_best"] = np.array(gp.model_selector(gp.hyperpars))
+        out[f"ms_{tag}_bounds"] = np.array(gp.hp_bounds, dtype=float)
+    # default number of starts: int(2 sqrt(P)) + 1 = 5 for P = 4
+    np.random.seed(8)
+    gp = GpRegressor(x, y, y_err=e)
+    out["ms_default_theta"] = np.array(gp.hyperpars)
+    out["ms_default_best"] = np.array(gp.marginal_likelihood(gp.hyperpars))
+    np.random.seed(5)
+    gpd = GpRegressor(x, y, y_err=e, optimizer="diffev")
+    out["de_theta"] = np.array(gpd.hyperpars)
+    out["de_best"] = np.array(gpd.marginal_likelihood(gpd.hyperpars))
+
+    # acquisition starting positions and the optimiser's proposal
+    bx, by, bounds = bo_problem()
+    th = np.array([by.mean(), np.log(by.std()), np.log(2.0), np.log(2.0)])
+    for nm, acq in (("ei", ExpectedImprovement), ("ucb", UpperConfidenceBound), ("mv", MaxVariance)):
+        opt = GpOptimiser(bx, by, bounds=bounds, hyperpars=th, acquisition=acq)
+        np.random.seed(21)
+        out[f"bo_{nm}_starts"] = np.array(opt.acquisition.starting_positions(bounds))
+        np.random.seed(22)
+        prop = opt.propose_evaluation()
+        out[f"bo_{nm}_proposal"] = np.array(prop)
+        out[f"bo_{nm}_value"] = np.array(float(np.squeeze(opt.acquisition.opt_func(np.array(prop)))))
+        np.random.seed(23)
+        prop_de = opt.propose_evaluation(optimizer="diffev")
+        out[f"bo_{nm}_de_value"] = np.array(float(np.squeeze(opt.acquisition.opt_func(np.array(prop_de)))))
+    out["bo_theta"] = th
+    # one full iteration with the hyper-parameter search inside add_evaluation
+    np.random.seed(31)
+    opt = GpOptimiser(bx, by, bounds=bounds)
+    out["bo_fit_theta"] = np.array(opt.gp.hyperpars)
+    out["bo_fit_lml"] = np.array(opt.gp.marginal_likelihood(opt.gp.hyperpars))
+    return out
+
+
+def case_means():
+    """LinearMean / QuadraticMean (mean.py:54-126) with SE and RQ kernels on a 60-point 2-D set with a trend."""
+    from inference.gp import LinearMean, QuadraticMean
+
+    out = {}
+    n, d = 60, 2
+    rng = np.random.default_rng(606)
+    x = rng.uniform(-1, 2, (n, d))
+    y = 1.5 + 0.8 * x[:, 0] - 0.5 * x[:, 1] + 0.3 * x[:, 0] ** 2 + np.sin(3 * x[:, 0]) * np.cos(2 * x[:, 1]) + 0.05 * rng.normal(size=n)
+    e = np.full(n, 0.05)
+    pts = rng.uniform(-1, 2, (25, d))
+    out.update(x=x, y=y, y_err=e, pts=pts)
+    for mtag, mean, nm in (("lin", LinearMean, 1 + d), ("quad", QuadraticMean, 1 + 2 * d)):
+        for ktag, kid in (("se", wl.SE), ("rq", wl.RQ)):
+            key = f"{mtag}_{ktag}"
+            trng = np.random.default_rng(77 + nm + kid)
+            mean_part = np.concatenate([[y.mean()], 0.3 * trng.standard_normal(nm - 1)])
+            cov_part = [np.log(y.std())] + ([0.5] if kid == wl.RQ else []) + [np.log(0.6)] * d
+            base = np.concatenate([mean_part, cov_part])
+            thetas = np.array([base + 0.1 * trng.standard_normal(base.size) for _ in range(3)])
+            gp = GpRegressor(x, y, y_err=e, hyperpars=thetas[0], kernel=kernel_cls(kid), mean=mean)
+            out[key + "_thetas"] = thetas
+            out[key + "_labels"] = np.array(gp.hyperpar_labels)
+            out[key + "_bounds"] = np.array(gp.hp_bounds, dtype=float)
+            out[key + "_alpha"] = gp.alpha
+            out[key + "_mu_train"] = gp.mu
+            mu, sig = gp(pts)
+            out[key + "_mu"], out[key + "_sig"] = mu, sig
+            pm, pc = gp.build_posterior(pts[:10])
+            out[key + "_post_mu"], out[key + "_post_cov"] = pm, pc
+            out[key + "_lml"] = np.array([gp.marginal_likelihood(t) for t in thetas])
+            res = [gp.marginal_likelihood_gradient(t) for t in thetas]
+            out[key + "_lml2"] = np.array([r[0] for r in res])
+            out[key + "_grad"] = np.array([r[1] for r in res])
+            out[key + "_loo"] = np.array([gp.loo_likelihood(t) for t in thetas])
+            res = [gp.loo_likelihood_gradient(t) for t in thetas]
+            out[key + "_loo_grad"] = np.array([r[1] for r in res])
+            if kid == wl.SE:
+                sm, sv = gp.spatial_derivatives(pts[:10])
+                out[key + "_sd_mu"], out[key + "_sd_var"] = sm, sv
+    return out
+
+
 IDX_TOMO = np.arange(0, 400, 7)  # 58 rows / columns of the 400 x 400 posterior covariance
 
 CASES = {
+    "search": case_search,
+    "means": case_means,
     "cp": case_cp,
     "het": case_het,
     "linv": case_linv,

@@ -28,7 +28,36 @@ def rel(a, b):
 
 def check(a, b, tol=RTOL, what=""):
     r = rel(a, b)
+    _record(what, r, tol)
     assert r <= tol, f"{what}: relative error {r:.3e} > {tol:.1e}"
+    return r
+
+
+def _record(what, r, tol):
+    """Every comparison is logged; conftest.py prints the achieved errors at the end of the run, so that a
+    regression of a couple of digits is visible long before it reaches a tolerance."""
+    import inspect
+
+    test = next((f.function for f in inspect.stack() if f.function.startswith("test_")), "?")
+    ACHIEVED.append((test, what, r, tol))
+
+
+ACHIEVED = []
+
+
+def check_each(a, b, tol=RTOL, what="", floor=1e-6, etol=1e-7):
+    """Normwise `check` plus an element-wise one for vectors whose small entries matter (alpha, gradient
+    components): the normwise measure leaves entries far below the maximum unconstrained, so every element larger
+    than `floor` x the largest is also held to `etol` relative to ITSELF.  An entry at 1e-6 of the maximum
+    inherits a relative error of normwise-error / 1e-6 from the cancellation that made it small (measured: 2.4e-8
+    at N = 6500, 1e-11 .. 1e-12 on the small cases), hence etol = 1e-7 and not 1e-10."""
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    check(a, b, tol, what)
+    big = np.abs(b) > floor * np.abs(b).max()
+    r = float((np.abs(a - b)[big] / np.abs(b)[big]).max()) if big.any() else 0.0
+    _record(what + " (element-wise)", r, etol)
+    assert r <= etol, f"{what}: element-wise relative error {r:.3e} > {etol:.1e}"
+    return r
 
 
 @pytest.fixture(scope="module")
@@ -54,12 +83,14 @@ def test_t32_fit_and_predict_vs_reference(golden, gp_mod, name, kid):
     assert str(g[name + "str"]) == str(gp)
     check(np.array(gp.hp_bounds), g[name + "hp_bounds"], 1e-12, "hp_bounds")
     check(gp.K_xx, g[name + "K_xx"], 1e-13, "K_xx")
-    check(gp.L, g[name + "L"], what="L")
+    # the reference's own 32-point test set: measured 1e-14 (L) .. 1e-13 (alpha, mu, sigma); held to 2e-12 so that
+    # a 1e-11 error in the factor is caught here (test_suite_detects_a_1e11_fault)
+    check(gp.L, g[name + "L"], 2e-12, what="L")
     assert np.all(np.triu(gp.L, 1) == 0.0)
-    check(gp.alpha, g[name + "alpha"], what="alpha")
+    check_each(gp.alpha, g[name + "alpha"], 2e-12, what="alpha")
     mu, sig = gp(g[name + "pts"])
-    check(mu, g[name + "mu"], what="mu")
-    check(sig, g[name + "sig"], what="sig")
+    check(mu, g[name + "mu"], 2e-12, what="mu")
+    check(sig, g[name + "sig"], 2e-12, what="sig")
     pm, pc = gp.build_posterior(g[name + "pts"][:16])
     check(pm, g[name + "post_mu"], what="posterior mean")
     check(pc, g[name + "post_cov"], what="posterior covariance")
@@ -81,7 +112,7 @@ def test_t32_white_noise_composite(golden, gp_mod):
     assert [str(s) for s in g["sewn_labels"]] == gp.hyperpar_labels
     check(np.array(gp.hp_bounds), g["sewn_hp_bounds"], 1e-12)
     check(gp.marginal_likelihood(th), g["sewn_lml"])
-    check(gp.alpha, g["sewn_alpha"])
+    check_each(gp.alpha, g["sewn_alpha"], what="alpha")
     mu, sig = gp(g["se_pts"])
     check(mu, g["sewn_mu"])
     check(sig, g["sewn_sig"])
@@ -109,7 +140,7 @@ def test_config_golden(golden, gp_mod, case):
     check(np.array(gp.hp_bounds), g["hp_bounds"], 1e-12, "hp_bounds")
     check(gp.marginal_likelihood_batch(th), g["lml"], what="lml")
     check(np.linalg.norm(gp.alpha), g["alpha_norm"], what="|alpha|")
-    check(gp.alpha[g["alpha_idx"]], g["alpha_sub"], what="alpha")
+    check_each(gp.alpha[g["alpha_idx"]], g["alpha_sub"], what="alpha")
     check(gp._logdet, g["logdet"], what="logdet")
     mu, sig = gp(g["pts"])
     check(mu, g["mu"], what="mu")
@@ -132,7 +163,7 @@ def test_ragged_sizes_vs_oracle(gp_mod, n, d, kid):
     ref = orc.OracleGp(x, y, e, kernel=kid, hyperpars=th)
     check(gp.K_xx, ref.K_xx, 1e-13, "K")
     check(gp.L, ref.L, what="L")
-    check(gp.alpha, ref.alpha, what="alpha")
+    check_each(gp.alpha, ref.alpha, what="alpha")
     check(gp.marginal_likelihood(th), ref.marginal_likelihood(th), what="lml")
     pts = wl.query_points(n, 37, d)
     mu, sig = gp(pts)
@@ -184,7 +215,8 @@ def test_t32_lml_gradient_and_loo_vs_reference(golden, gp_mod, name, kid):
     gp = gp_mod.GpRegressor(g["x"], g["y"], y_err=g["y_err"], hyperpars=th[0], kernel=kernel_cls(gp_mod, kid))
     res = [gp.marginal_likelihood_gradient(t) for t in th]
     check([r[0] for r in res], g[name + "lml_g_val"], what="lml (grad path)")
-    check([r[1] for r in res], g[name + "lml_g_grad"], what="lml gradient")
+    for r, ref in zip(res, g[name + "lml_g_grad"]):
+        check_each(r[1], ref, what="lml gradient")
     lm, ls = gp.loo_predictions()
     check(lm, g[name + "loo_mu"], what="loo mu")
     check(ls, g[name + "loo_sig"], what="loo sigma")
@@ -203,7 +235,7 @@ def test_t32_white_noise_gradient(golden, gp_mod):
     )
     v, grad = gp.marginal_likelihood_gradient(th)
     check(v, g["sewn_lml_g_val"])
-    check(grad, g["sewn_lml_g_grad"], what="gradient incl. WhiteNoise parameter")
+    check_each(grad, g["sewn_lml_g_grad"], what="gradient incl. WhiteNoise parameter")
 
 
 @pytest.mark.parametrize("case", ["cfg1", "rq256", "cfg4"])
@@ -218,7 +250,7 @@ def test_config_lml_gradient_golden(golden, gp_mod, case):
     check([r[0] for r in res], g["lml_g_val"][:k], what="lml")
     # gradient components: relative to the largest component of each gradient vector
     for r, ref in zip(res, g["lml_g_grad"][:k]):
-        check(r[1], ref, 1e-9, what="lml gradient")
+        check_each(r[1], ref, what="lml gradient")
 
 
 def test_lml_gradient_matches_finite_differences(gp_mod):
@@ -300,10 +332,10 @@ def test_t32_acquisition_vs_reference(golden, gp_mod, nm):
     check(acq.opt_func_batch(pts), g[f"se_{nm}_opt"], what="opt_func_batch")
     val, grad = acq.opt_func_gradient_batch(pts)
     check(val, g[f"se_{nm}_optg_val"], what="opt_func_gradient value")
-    check(grad, g[f"se_{nm}_optg_grad"], 1e-9, what="opt_func_gradient gradient")
+    check(grad, g[f"se_{nm}_optg_grad"], what="opt_func_gradient gradient")
     v1, g1 = acq.opt_func_gradient(pts[3])
     check(float(v1), g[f"se_{nm}_optg_val"][3])
-    check(g1, g[f"se_{nm}_optg_grad"][3], 1e-9)
+    check(g1, g[f"se_{nm}_optg_grad"][3], what="opt_func_gradient gradient (scalar API)")
     check([acq.convergence_metric(p) for p in pts[:4]], g[f"se_{nm}_conv"], what="convergence metric")
 
 
@@ -316,17 +348,18 @@ def test_cfg4_expected_improvement_1000_candidates(golden, gp_mod):
     ei = gp_mod.ExpectedImprovement()
     ei.update_gp(gp)
     check(ei.mu_max, g["mu_max"], 0.0)
-    check(ei.call_batch(g["cand"]), g["ei_call"], 1e-9, "EI")
-    check(ei.opt_func_batch(g["cand"]), g["ei_opt"], 1e-9, "-ln EI")
+    check(ei.call_batch(g["cand"]), g["ei_call"], what="EI")
+    check(ei.opt_func_batch(g["cand"]), g["ei_opt"], what="-ln EI")
     val, grad = ei.opt_func_gradient_batch(g["cand"][:200])
-    check(val, g["ei_optg_val"], 1e-9)
-    check(grad, g["ei_optg_grad"], 1e-8, "grad -ln EI")
+    check(val, g["ei_optg_val"], what="-ln EI (gradient call)")
+    check(grad, g["ei_optg_grad"], 2e-10, "grad -ln EI")
     ei.mu_max = float(g["ei_far_mu_max"])  # forces Z < -3
+    # EI itself is exp(ln EI) with ln EI ~ -100 here: its relative error is |ln EI| times that of ln EI (measured 1.2e-10)
     check(ei.call_batch(g["cand"][:200]), g["ei_far_call"], 1e-9, "EI (Z < -3)")
-    check(ei.opt_func_batch(g["cand"][:200]), g["ei_far_opt"], 1e-9)
+    check(ei.opt_func_batch(g["cand"][:200]), g["ei_far_opt"], what="-ln EI (Z < -3)")
     val, grad = ei.opt_func_gradient_batch(g["cand"][:200])
-    check(val, g["ei_far_optg_val"], 1e-9)
-    check(grad, g["ei_far_optg_grad"], 1e-8)
+    check(val, g["ei_far_optg_val"], what="-ln EI (Z < -3, gradient call)")
+    check(grad, g["ei_far_optg_grad"], 2e-10, "grad -ln EI (Z < -3)")
 
 
 @pytest.mark.parametrize("acq", ["ei", "ucb", "mv"])
@@ -437,7 +470,7 @@ def test_t32_loo_gradient_vs_reference(golden, gp_mod):
         res = [gp.loo_likelihood_gradient(t) for t in th]
         check([r[0] for r in res], g[name + "loo_g_val"], what="LOO value")
         for r, ref in zip(res, g[name + "loo_g_grad"]):
-            check(r[1], ref, 1e-9, what="LOO gradient")
+            check_each(r[1], ref, what="LOO gradient")
     # finite-difference property of the reference's own test (tests/gp/test_GpRegressor.py:79-94)
     theta = g["se_thetas"][2]
     gp = gp_mod.GpRegressor(g["x"], g["y"], y_err=g["y_err"], hyperpars=theta)
@@ -550,8 +583,9 @@ def test_full_size_identities(gp_mod, cfg, n, d, kid):
 def test_linear_inverter_vs_reference(golden, gp_mod, prob, tag, kid, wn):
     """LML, its gradient, posterior mean and covariance at three hyper-parameter vectors.  The posterior is
     computed in Woodbury form (Cholesky solves) while the reference uses an LU solve of I + K A^T S^-1 A
-    (inversion.py:150-155): the two agree to the conditioning of that non-symmetric system, hence 1e-8
-    relative for the posterior (measured 1e-11 .. 1e-9) and 1e-10 for the likelihood path."""
+    (inversion.py:150-155): the two agree to the conditioning of that non-symmetric system, hence 2e-9
+    relative for the posterior mean (measured 2e-10), 2e-10 for its covariance (measured 2e-11) and 1e-10 for the
+    likelihood path (measured 1e-11 on the gradient)."""
     g = golden("linv")
     pos, A, y, y_err = wl.linv_problem(prob)
     cov = kernel_cls(gp_mod, kid)()
@@ -567,11 +601,11 @@ def test_linear_inverter_vs_reference(golden, gp_mod, prob, tag, kid, wn):
         check(gli.marginal_likelihood(th), g[key + "_lml"], what="lml")
         lml, grad = gli.marginal_likelihood_gradient(th)
         check(lml, g[key + "_lml2"], what="lml (gradient call)")
-        check(grad, g[key + "_grad"], 1e-9, "lml gradient")
+        check_each(grad, g[key + "_grad"], what="lml gradient")
         pm, pc = gli.calculate_posterior(th)
-        check(pm, g[key + "_pmean"], 1e-8, "posterior mean")
-        check(gli.calculate_posterior_mean(th), g[key + "_pmean_only"], 1e-8, "posterior mean only")
-        check(pc if prob == "deconv" else pc[idx][:, idx], g[key + "_pcov"], 1e-8, "posterior covariance")
+        check(pm, g[key + "_pmean"], 2e-9, "posterior mean")
+        check(gli.calculate_posterior_mean(th), g[key + "_pmean_only"], 2e-9, "posterior mean only")
+        check(pc if prob == "deconv" else pc[idx][:, idx], g[key + "_pcov"], 2e-10, "posterior covariance")
 
 
 def test_linear_inverter_optimise_and_errors(gp_mod):
@@ -610,11 +644,12 @@ def test_heteroscedastic_noise_vs_reference(golden, gp_mod, tag, with_err):
                             kernel=gp_mod.SquaredExponential() + gp_mod.HeteroscedasticNoise())
     assert list(g[f"{tag}_labels"]) == gp.hyperpar_labels
     check(np.array(gp.hp_bounds, dtype=float), g[f"{tag}_bounds"], 1e-12, "bounds")
-    check(gp.alpha, g[f"{tag}_alpha"], what="alpha")
+    check_each(gp.alpha, g[f"{tag}_alpha"], what="alpha")
     check(gp.marginal_likelihood_batch(th), g[f"{tag}_lml"], what="lml")
     res = [gp.marginal_likelihood_gradient(t) for t in th]
     check([r[0] for r in res], g[f"{tag}_lml2"], what="lml (gradient call)")
-    check([r[1] for r in res], g[f"{tag}_grad"], 1e-9, "gradient")
+    for r, ref in zip(res, g[f"{tag}_grad"]):
+        check_each(r[1], ref, what="gradient")
     check(gp.K_xx, g[f"{tag}_K_xx"], 1e-13, "K_xx after evaluations at other thetas")
     mu, sig = gp(wl.query_points(77, 40, d))
     check(mu, g[f"{tag}_mu"], what="mu")
@@ -639,7 +674,7 @@ def test_change_point_vs_reference(golden, gp_mod, tag, subs, wn):
     gp = gp_mod.GpRegressor(x, y, y_err=e, kernel=cov, hyperpars=th[1])
     assert list(g[f"{tag}_labels"]) == gp.hyperpar_labels
     check(np.array(gp.hp_bounds, dtype=float), g[f"{tag}_bounds"], 1e-12, "bounds")
-    check(gp.alpha, g[f"{tag}_alpha"], what="alpha")
+    check_each(gp.alpha, g[f"{tag}_alpha"], what="alpha")
     check(gp.K_xx, g[f"{tag}_K_xx"], 1e-13, "K_xx")
     mu, sig = gp(pts)
     check(mu, g[f"{tag}_mu"], what="mu")
@@ -647,7 +682,8 @@ def test_change_point_vs_reference(golden, gp_mod, tag, subs, wn):
     check([gp.marginal_likelihood(t) for t in th], g[f"{tag}_lml"], what="lml")
     res = [gp.marginal_likelihood_gradient(t) for t in th]
     check([r[0] for r in res], g[f"{tag}_lml2"], what="lml (gradient call)")
-    check([r[1] for r in res], g[f"{tag}_grad"], 1e-9, "gradient")
+    for r, ref in zip(res, g[f"{tag}_grad"]):
+        check_each(r[1], ref, what="gradient")
     # the likelihood evaluations above used other hyper-parameters: the fitted state must be restored lazily
     mu2, sig2 = gp(pts)
     check(mu2, g[f"{tag}_mu"], what="mu after other evaluations")
@@ -656,7 +692,7 @@ def test_change_point_vs_reference(golden, gp_mod, tag, subs, wn):
     check(loo_sig, g[f"{tag}_loo_sig"], what="loo sigma")
     pm, pc = gp.build_posterior(pts[:20])
     check(pm, g[f"{tag}_post_mu"], what="posterior mean")
-    check(pc, g[f"{tag}_post_cov"], 1e-9, "posterior covariance")
+    check(pc, g[f"{tag}_post_cov"], what="posterior covariance")
     check([gp.loo_likelihood(t) for t in th], g[f"{tag}_loo"], what="loo likelihood")
 
 
@@ -695,7 +731,7 @@ def test_ragged_large_size_vs_oracle(gp_mod):
     th = wl.timing_theta(wl.RQ, y, d)
     gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=th, kernel=gp_mod.RationalQuadratic)
     ref = orc.OracleGp(x, y, e, kernel=orc.RQ, hyperpars=th)
-    check(gp.alpha, ref.alpha, what="alpha")
+    check_each(gp.alpha, ref.alpha, what="alpha")
     check(gp.marginal_likelihood(th), ref.marginal_likelihood(th), what="lml")
     pts = wl.query_points(65, 300, d)
     mu, sig = gp(pts)
@@ -705,7 +741,7 @@ def test_ragged_large_size_vs_oracle(gp_mod):
     lml, grad = gp.marginal_likelihood_gradient(th)
     rl, rg = ref.marginal_likelihood_gradient(th)
     check(lml, rl, what="lml (gradient call)")
-    check(grad, rg, 1e-9, "gradient")
+    check_each(grad, rg, what="gradient")
 
 
 def test_objects_pickle_without_device_state(gp_mod):
@@ -729,3 +765,188 @@ def test_objects_pickle_without_device_state(gp_mod):
     t3 = np.array([0.1, 0.0, np.log(0.15)])
     v = gli.marginal_likelihood(t3)
     assert pickle.loads(pickle.dumps(gli)).marginal_likelihood(t3) == v
+
+
+# ---------------------------------------------------------------------------------------
+# the callers that draw random numbers, pinned against the reference under numpy.random.seed
+# (tests/golden/search.npz): multi-start L-BFGS-B, differential evolution, acquisition starts, proposals
+# ---------------------------------------------------------------------------------------
+def _t32_data():
+    rng = np.random.default_rng(1)
+    points = rng.uniform(low=0.0, high=2.0, size=(32, 2))
+    values = np.sin(points[:, 0]) * np.cos(points[:, 1]) + rng.normal(scale=0.1, size=32)
+    return points, values, np.full(32, 0.1)
+
+
+def _bo_problem():
+    def objective(x):
+        return np.sin(0.5 * x[0]) * 3 / (2 + 0.5 * (x[1] - 1.0) ** 2) + 0.1 * x[0]
+
+    rng = np.random.default_rng(4)
+    bounds = [(-4.0, 6.0), (-3.0, 5.0)]
+    x = rng.uniform([b[0] for b in bounds], [b[1] for b in bounds], size=(8, 2))
+    x[5] = [7.0, 1.0]
+    y = np.array([objective(k) for k in x])
+    return x, y, bounds
+
+
+@pytest.mark.parametrize("tag,kw", [("lml", {}), ("loo", {"cross_val": True}), ("rq", {"kernel": "rq"})])
+def test_multistart_bfgs_reproduces_reference_search(golden, gp_mod, tag, kw):
+    """regression.py:585-605 with numpy.random.seed(3): the start positions are drawn in the reference's order
+    (to the 1e-15 of the bounds), every start ends at the reference's optimum, and the selected theta* scores the same."""
+    g = golden("search")
+    x, y, e = _t32_data()
+    kw = dict(kw)
+    if kw.get("kernel") == "rq":
+        kw["kernel"] = gp_mod.RationalQuadratic
+    log = []
+    orig = gp_mod.GpRegressor.launch_bfgs
+
+    def spy(self, x0):
+        res = orig(self, x0)
+        log.append((np.array(x0), np.array(res[0]), float(res[1])))
+        return res
+
+    gp_mod.GpRegressor.launch_bfgs = spy
+    try:
+        np.random.seed(3)
+        gp = gp_mod.GpRegressor(x, y, y_err=e, optimizer="bfgs", n_starts=4, **kw)
+    finally:
+        gp_mod.GpRegressor.launch_bfgs = orig
+    check(np.array(gp.hp_bounds, dtype=float), g[f"ms_{tag}_bounds"], 1e-12, "bounds")
+    # same random numbers in the same order; the bounds they scale come from the O(N log N) identity (1e-15 apart)
+    check(np.array([l[0] for l in log]), g[f"ms_{tag}_starts"], 1e-13, "start positions")
+    # every L-BFGS-B run stops within its own convergence test (factr 1e7 -> ~2e-9 relative) of the reference's run
+    fv = np.array([l[2] for l in log])
+    err = np.abs(fv - g[f"ms_{tag}_fvals"]) / np.abs(g[f"ms_{tag}_fvals"])
+    print(f"[{tag}] per-start objective agreement {err.max():.2e}; theta* distance "
+          f"{np.abs(np.array(gp.hyperpars) - g[f'ms_{tag}_theta']).max():.2e}")
+    assert err.max() < 1e-9
+    best = float(gp.model_selector(gp.hyperpars))
+    assert abs(best - float(g[f"ms_{tag}_best"])) <= 1e-8 * abs(float(g[f"ms_{tag}_best"]))
+    assert np.abs(np.array(gp.hyperpars) - g[f"ms_{tag}_theta"]).max() < 1e-8  # the L-BFGS-B paths coincide (measured 2e-11)
+
+
+def test_default_starts_and_differential_evolution_reproduce_reference(golden, gp_mod):
+    g = golden("search")
+    x, y, e = _t32_data()
+    np.random.seed(8)
+    gp = gp_mod.GpRegressor(x, y, y_err=e)  # int(2 sqrt(P)) + 1 starts
+    v = gp.marginal_likelihood(gp.hyperpars)
+    assert abs(v - float(g["ms_default_best"])) <= 1e-8 * abs(float(g["ms_default_best"]))
+    np.random.seed(5)
+    gpd = gp_mod.GpRegressor(x, y, y_err=e, optimizer="diffev")
+    vd = gpd.marginal_likelihood(gpd.hyperpars)
+    # SciPy's differential_evolution under the same global seed: the population path is identical as long as no
+    # comparison flips on a 1e-13 difference; its polish step ends at the same optimum
+    print(f"differential evolution: LML {vd:.12g} (reference {float(g['de_best']):.12g})")
+    assert abs(vd - float(g["de_best"])) <= 1e-7 * abs(float(g["de_best"]))
+
+
+@pytest.mark.parametrize("nm", ["ei", "ucb", "mv"])
+def test_acquisition_starts_and_proposals_reproduce_reference(golden, gp_mod, nm):
+    """acquisition.py:13-37 and optimisation.py:202-249 under numpy.random.seed: the starting positions (20 probes
+    per training point, ranked by one batched device evaluation; a uniform draw for the point outside the bounds) are
+    the reference's, and the proposal reaches the reference's acquisition value."""
+    g = golden("search")
+    bx, by, bounds = _bo_problem()
+    acq = {"ei": gp_mod.ExpectedImprovement, "ucb": gp_mod.UpperConfidenceBound, "mv": gp_mod.MaxVariance}[nm]
+    opt = gp_mod.GpOptimiser(bx, by, bounds=bounds, hyperpars=g["bo_theta"], acquisition=acq)
+    np.random.seed(21)
+    starts = np.array(opt.acquisition.starting_positions(bounds))
+    check(starts, g[f"bo_{nm}_starts"], 1e-13, "starting positions")
+    np.random.seed(22)
+    prop = np.array(opt.propose_evaluation())
+    val = float(opt.acquisition.opt_func(prop))
+    ref_val = float(g[f"bo_{nm}_value"])
+    print(f"[{nm}] proposal distance {np.abs(prop - g[f'bo_{nm}_proposal']).max():.2e}, value {val:.12g} vs {ref_val:.12g}")
+    assert abs(val - ref_val) <= 1e-8 * max(abs(ref_val), 1.0)
+    assert np.abs(prop - g[f"bo_{nm}_proposal"]).max() < 1e-9  # measured <= 4e-15
+    np.random.seed(23)
+    prop_de = np.array(opt.propose_evaluation(optimizer="diffev"))
+    val_de = float(opt.acquisition.opt_func(prop_de))
+    assert abs(val_de - float(g[f"bo_{nm}_de_value"])) <= 1e-6 * max(abs(float(g[f"bo_{nm}_de_value"])), 1.0)
+
+
+def test_gp_optimiser_fit_reproduces_reference(golden, gp_mod):
+    g = golden("search")
+    bx, by, bounds = _bo_problem()
+    np.random.seed(31)
+    opt = gp_mod.GpOptimiser(bx, by, bounds=bounds)
+    v = opt.gp.marginal_likelihood(opt.gp.hyperpars)
+    assert abs(v - float(g["bo_fit_lml"])) <= 1e-8 * abs(float(g["bo_fit_lml"]))
+
+
+# ---------------------------------------------------------------------------------------
+# LinearMean / QuadraticMean (mean.py:54-126): the non-constant mean path (a mean vector per evaluation)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mtag", ["lin", "quad"])
+@pytest.mark.parametrize("ktag,kid", [("se", wl.SE), ("rq", wl.RQ)])
+def test_linear_and_quadratic_mean_vs_reference(golden, gp_mod, mtag, ktag, kid):
+    g = golden("means")
+    key = f"{mtag}_{ktag}"
+    mean = {"lin": gp_mod.LinearMean, "quad": gp_mod.QuadraticMean}[mtag]
+    th = g[key + "_thetas"]
+    gp = gp_mod.GpRegressor(g["x"], g["y"], y_err=g["y_err"], hyperpars=th[0], kernel=kernel_cls(gp_mod, kid), mean=mean)
+    assert list(g[key + "_labels"]) == gp.hyperpar_labels
+    check(np.array(gp.hp_bounds, dtype=float), g[key + "_bounds"], 1e-12, "bounds")
+    check(gp.mu, g[key + "_mu_train"], 1e-13, "prior mean at the training points")
+    check_each(gp.alpha, g[key + "_alpha"], what="alpha")
+    mu, sig = gp(g["pts"])
+    check(mu, g[key + "_mu"], what="mu")
+    check(sig, g[key + "_sig"], what="sig")
+    pm, pc = gp.build_posterior(g["pts"][:10])
+    check(pm, g[key + "_post_mu"], what="posterior mean")
+    check(pc, g[key + "_post_cov"], what="posterior covariance")
+    check([gp.marginal_likelihood(t) for t in th], g[key + "_lml"], what="lml")
+    check(gp.marginal_likelihood_batch(th), g[key + "_lml"], what="lml batch (one mean vector per evaluation)")
+    res = [gp.marginal_likelihood_gradient(t) for t in th]
+    check([r[0] for r in res], g[key + "_lml2"], what="lml (gradient call)")
+    for r, ref in zip(res, g[key + "_grad"]):
+        check_each(r[1], ref, what="lml gradient incl. the mean-parameter components")
+    check([gp.loo_likelihood(t) for t in th], g[key + "_loo"], what="loo likelihood")
+    for t, ref in zip(th, g[key + "_loo_grad"]):
+        check_each(gp.loo_likelihood_gradient(t)[1], ref, what="loo gradient")
+    if kid == wl.SE:
+        sm, sv = gp.spatial_derivatives(g["pts"][:10])
+        check(sm, g[key + "_sd_mu"], what="d mu / dx")
+        check(sv, g[key + "_sd_var"], what="d var / dx")
+
+
+# ---------------------------------------------------------------------------------------
+# dense plugin methods vs the fused device contraction
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kid", [("se_", wl.SE), ("rq_", wl.RQ)])
+def test_dense_covariance_and_gradients_vs_reference_and_device_contraction(golden, gp_mod, name, kid):
+    """`covariance_and_gradients` (covariance.py:268-276, 350-365) element by element against the reference's dense
+    matrices, and the LML gradient formed from those dense matrices on the host (regression.py:559-565) against the
+    fused on-device contraction that never stores dK."""
+    g = golden("t32")
+    th = g[name + "thetas"]
+    gp = gp_mod.GpRegressor(g["x"], g["y"], y_err=g["y_err"], hyperpars=th[0], kernel=kernel_cls(gp_mod, kid))
+    K, dK = gp.cov.covariance_and_gradients(th[1][1:])
+    check(K, g[name + "cov_K"], 1e-13, "K")
+    check(np.array(dK), g[name + "cov_dK"], 1e-13, "dK / dtheta")
+    lml, grad = gp.marginal_likelihood_gradient(th[1])
+    Kxx = K + gp.sig
+    iK = np.linalg.inv(Kxx)
+    alpha = iK @ (g["y"] - th[1][0])
+    Q = np.outer(alpha, alpha) - iK
+    host = np.array([0.5 * (Q * d.T).sum() for d in dK])
+    check_each(grad[1:], host, what="device contraction vs dense dK")
+
+
+def test_suite_detects_a_1e11_fault():
+    """The tolerances are tight enough to matter: with the factored diagonal blocks scaled by (1 + 1e-11) inside the
+    library (GPMI_FAULT_DIAG_EPS, a test hook) the golden-vector comparisons of this file must fail."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.abspath(__file__)
+    env = dict(os.environ, GPMI_FAULT_DIAG_EPS="1e-11")
+    run = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
+                          "-k", "test_t32_fit_and_predict_vs_reference or test_config_golden"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode != 0, "a 1e-11 perturbation of potrf_diag's output went unnoticed:\n" + run.stdout[-2000:]
+    assert "relative error" in run.stdout
