@@ -103,6 +103,14 @@ int gpmi_lml_batch(gpmi_ctx* ctx, int kernel, int64_t T, const double* thetas_ho
                    const double* mu_const_host, double* lml_host, int* info_host);
 /* number of concurrent worker streams (each with its own n x n scratch) used by gpmi_lml_batch */
 int gpmi_set_streams(gpmi_ctx* ctx, int n_streams);
+/* Handle options.
+ *   GPMI_OPT_LOCKSTEP_ALWAYS  1: gpmi_lml_batch / gpmi_lml take the lockstep path (all evaluations of a call in one
+ *       launch sequence, batch in blockIdx.z) for ANY number of evaluations while n <= 4096, also for T = 1.  A
+ *       value then does not depend on which other evaluations share its call - what the lockstep MCMC drivers
+ *       (GibbsChain retries make the batches ragged, reference gibbs.py:635-648) need for trajectories that are
+ *       bit-identical however the chains are grouped.  0 (default): a single evaluation uses the lane path. */
+#define GPMI_OPT_LOCKSTEP_ALWAYS 1
+int gpmi_set_option(gpmi_ctx* ctx, int option, int value);
 
 /* Replaces GpRegressor.marginal_likelihood_gradient (regression.py:544-567):
  *   grad_theta_host : n_theta values  1/2 sum (alpha alpha^T - K^-1) o dK/dtheta_j
@@ -243,6 +251,35 @@ int gpmi_comm_unique_id(char* id_out_128);
 int gpmi_comm_init(gpmi_ctx* ctx, int rank, int world, const char* id_128);
 int gpmi_comm_allgather(gpmi_ctx* ctx, const double* send_host, double* recv_host, int64_t count);
 int gpmi_comm_destroy(gpmi_ctx* ctx);
+
+/* ---- dense entry points: covariance functions that only implement the plugin ABC -------------------------
+ * Reference: CovarianceFunction (inference/gp/covariance.py:8-44) is an open plugin contract and GpRegressor
+ * (regression.py:134-155) accepts any object implementing it.  For a kernel the library has no device code for, the
+ * host evaluates the plugin's own build_covariance / __call__ and passes the dense matrices; every O(N^3) step
+ * (numpy.linalg.cholesky regression.py:241, solve_triangular :242-244 / :213 / :447, the explicit inverse :556-557)
+ * runs on the device.  gpmi_set_data must have been called (x is unused, y and n are).
+ *   K_host : n x n row-major, the complete K(theta) + Sigma (only its lower triangle is read) */
+/* fit (regression.py:218-244) on lane 0; afterwards gpmi_predict_dense / gpmi_solve_rows / gpmi_get_L /
+ * gpmi_loo_diag use this factor */
+int gpmi_fit_dense(gpmi_ctx* ctx, const double* K_host, const double* mu_host, double* alpha_host,
+                   double* logdet_host, int* info);
+/* LML (regression.py:528-542) of a dense K on a scratch lane; alpha_host (n) and iK_host (n x n, K^-1, what
+ * marginal_likelihood_gradient :555-565 and the LOO expressions :460-526 contract with the plugin's own dK) are
+ * optional (NULL) */
+int gpmi_lml_dense(gpmi_ctx* ctx, const double* K_host, const double* mu_host, double* lml_host,
+                   double* alpha_host, double* iK_host, int* info);
+/* leave-one-out pieces (regression.py:468-526) of a dense K on a scratch lane: alpha, diag(K^-1), and for the
+ * gradient the two parameter-independent pieces p = K^-1 c1 (n) and W = K^-1 diag(c2) K^-1 (n x n) with
+ * c1 = alpha var, c2 = var (1 + var alpha^2) / 2, var = 1 / diag(K^-1): d LOO / d theta_j = p . (dK_j alpha) -
+ * sum dK_j o W for the plugin's own dK_j (p_host, W_host may be NULL) */
+int gpmi_loo_dense(gpmi_ctx* ctx, const double* K_host, const double* mu_host, double* alpha_host,
+                   double* ikdiag_host, double* p_host, double* W_host, int* info);
+/* predict pieces (regression.py:208-214) for m query points given their cross-covariances Kq (m x n):
+ * kalpha_host[i] = Kq[i] . alpha, sumsq_host[i] = |L^-1 Kq[i]|^2 (either may be NULL) */
+int gpmi_predict_dense(gpmi_ctx* ctx, const double* Kq_host, int64_t m, double* kalpha_host, double* sumsq_host);
+/* X = Q L^-T for m right-hand sides given as rows (m x n), and / or their Gram matrix X X^T (m x m): the building
+ * block of build_posterior (regression.py:447-448) and of gradient / spatial_derivatives (:374-383, :410-417) */
+int gpmi_solve_rows(gpmi_ctx* ctx, const double* Q_host, int64_t m, double* X_host, double* gram_host);
 
 /* ---- instrumentation ---------------------------------------------------------------
  * HIP-event timing on the handle's own stream (torch.cuda.Event would not see it). */

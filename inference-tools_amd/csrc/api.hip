@@ -537,6 +537,13 @@ int gpmi_set_streams(gpmi_ctx* c, int n_streams) {
   return ensure_lanes(c, 1 + (size_t)n_streams);
 }
 
+int gpmi_set_option(gpmi_ctx* c, int option, int value) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, option == GPMI_OPT_LOCKSTEP_ALWAYS, "unknown option");
+  c->lockstep_always = value != 0;
+  return GPMI_OK;
+}
+
 int gpmi_fit(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,
              const double* mu, double* alpha_out, double* logdet_out, int* info) {
   if (!c) return GPMI_ERR_ARG;
@@ -600,10 +607,10 @@ int gpmi_lml_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int
     if (int rc = make_params(c, kernel, thetas + t * n_theta, n_theta, extra ? extra[t] : 0.0,
                              ps[(size_t)t]))
       return rc;
-  if (T >= 2 && c->np <= 4096 && !c->ycov) {
+  if ((T >= 2 || c->lockstep_always) && c->np <= 4096 && !c->ycov) {
     // small problems: all evaluations of a chunk advance in lockstep, one launch per step for the
     // whole chunk (blockIdx.z), instead of one latency-bound launch sequence per evaluation
-    if (int rc = ensure_batch_ws(c, (int)(T < 256 ? T : 256))) return rc;
+    if (int rc = ensure_batch_ws(c, (int)(T < 256 ? (T < 2 ? 2 : T) : 256))) return rc;
     hipStream_t s = c->lanes[1].stream;
     const BatchShape shape0{1, c->np * c->ld, (c->np / GPMI_NB) * GPMI_NB * GPMI_NB, 4 * c->np};
     for (int64_t t0 = 0; t0 < T; t0 += c->bcap) {
@@ -1845,6 +1852,254 @@ int gpmi_linv_posterior(gpmi_ctx* c, int kernel, const double* theta, int n_thet
   for (int64_t i = 0; i < c->n; ++i) mean[i] += mu[i];
   INFOCHK(c, L.h_info[0]);
   if (info) *info = L.h_info[0];
+  return GPMI_OK;
+}
+
+}  // extern "C"
+
+// ---- dense entry points: covariance functions that only implement the plugin ABC ---------------------------
+// Reference: CovarianceFunction (covariance.py:8-44) is an open plugin contract; GpRegressor accepts any object
+// that implements it.  For such kernels the host evaluates the plugin's own build_covariance / __call__ /
+// covariance_and_gradients (there is no device code for an unknown kernel) and hands the dense matrices over;
+// everything of O(N^3) - potrf, solves, K^-1, the many-right-hand-side solves of predict / posterior - runs on the
+// device exactly as for the built-in kernels.  No CPU solve anywhere.
+namespace {
+
+// zero the padding rows / columns of an np x ld matrix whose n x n block has just been uploaded, identity on the
+// padded diagonal (chol(blockdiag(K, I)) = blockdiag(L, I))
+__global__ void dense_pad_kernel(double* __restrict__ A, int64_t ld, int64_t n, int64_t np) {
+  const int64_t i = blockIdx.y;
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= np) return;
+  if (i >= n || j >= n) A[i * ld + j] = (i == j) ? 1.0 : 0.0;
+}
+
+// rows [rows_valid, rows_padded) and the columns [n, np) of every row of a query panel <- 0
+__global__ void panel_pad_kernel(double* __restrict__ Q, int64_t ld, int64_t rows_valid, int64_t n, int64_t np) {
+  const int64_t i = blockIdx.y;
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= np) return;
+  if (i >= rows_valid || j >= n) Q[i * ld + j] = 0.0;
+}
+
+int upload_dense_matrix(gpmi_ctx* c, Lane& L, const double* K_host) {
+  hipStream_t s = L.stream;
+  HIPCHK(c, hipMemcpy2DAsync(L.A, sizeof(double) * c->ld, K_host, sizeof(double) * c->n, sizeof(double) * c->n,
+                             (size_t)c->n, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(dense_pad_kernel, dim3((unsigned)((c->np + 255) / 256), (unsigned)c->np), dim3(256), 0, s, L.A,
+                     c->ld, c->n, c->np);
+  return GPMI_OK;
+}
+
+// factorise the matrix already in L.A, forward-solve the residual, reduce (the dense twin of
+// enqueue_factor_and_forward)
+int enqueue_dense_factor_and_forward(gpmi_ctx* c, Lane& L, const double* mu_dev, int slot) {
+  hipStream_t s = L.stream;
+  L.inv2_valid = false;
+  HIPCHK(c, hipMemsetAsync(L.info + slot, 0, sizeof(int), s));
+  potrf_lower(c, L, L.A, c->np, c->ld, L.invD, L.info + slot, true);
+  launch_residual(s, c->y, mu_dev, 0.0, L.vec + 2 * c->np, c->n, c->np);
+  trsv_forward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, L.vec, L.info + slot);
+  launch_lml_reduce(s, L.vec, L.A, c->ld, c->np, L.red + 2 * slot);
+  HIPCHK(c, hipGetLastError());
+  return GPMI_OK;
+}
+
+int upload_query_panel(gpmi_ctx* c, hipStream_t s, double* Q, const double* rows_host, int64_t mc, int64_t mp) {
+  HIPCHK(c, hipMemcpy2DAsync(Q, sizeof(double) * c->ld, rows_host, sizeof(double) * c->n, sizeof(double) * c->n,
+                             (size_t)mc, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(panel_pad_kernel, dim3((unsigned)((c->np + 255) / 256), (unsigned)mp), dim3(256), 0, s, Q, c->ld,
+                     mc, c->n, c->np);
+  return GPMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpmi_fit_dense(gpmi_ctx* c, const double* K_host, const double* mu, double* alpha_out, double* logdet_out,
+                   int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->n > 0, "gpmi_set_data has not been called");
+  ARGCHK(c, K_host && mu, "K / mu is NULL");
+  if (int rc = set_device(c)) return rc;
+  Lane& L = c->lanes[0];
+  hipStream_t s = L.stream;
+  double* mu_dev = L.vec + 3 * c->np;
+  HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
+  if (int rc = upload_dense_matrix(c, L, K_host)) return rc;
+  if (int rc = enqueue_dense_factor_and_forward(c, L, mu_dev, 0)) return rc;
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, c->alpha, L.info);
+  HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (alpha_out) HIPCHK(c, hipMemcpyAsync(alpha_out, c->alpha, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  if (logdet_out) *logdet_out = L.h_red[1];
+  INFOCHK(c, L.h_info[0]);
+  if (info) *info = L.h_info[0];
+  c->fit_params = KParams{};
+  c->fit_params.kernel = -1;  // dense: the kernel-specific entry points (gpmi_predict, ...) do not apply
+  c->fitted = (L.h_info[0] == 0);
+  c->mix_nk = 0;
+  return GPMI_OK;
+}
+
+int gpmi_lml_dense(gpmi_ctx* c, const double* K_host, const double* mu, double* lml, double* alpha_out,
+                   double* iK_out, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->n > 0, "gpmi_set_data has not been called");
+  ARGCHK(c, K_host && mu && lml, "K / mu / lml is NULL");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = ensure_lanes(c, 2)) return rc;
+  Lane& L = c->lanes[1];
+  hipStream_t s = L.stream;
+  double* mu_dev = L.vec + 3 * c->np;
+  double* alpha_dev = L.vec + c->np;
+  HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
+  if (int rc = upload_dense_matrix(c, L, K_host)) return rc;
+  if (int rc = enqueue_dense_factor_and_forward(c, L, mu_dev, 0)) return rc;
+  if (alpha_out || iK_out) trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, alpha_dev, L.info);
+  if (iK_out) {
+    // K^-1 = L^-T L^-1 (regression.py:556-557): L^-T by forward substitution on the identity, then the k-skipped SYRK
+    if (int rc = ensure_second_matrix(c, L)) return rc;
+    if (int rc = enqueue_inverse_factor(c, L, L)) return rc;
+    launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, true, L.A, c->ld, L.B2, c->ld, L.B2, c->ld, (int)(c->np / GPMI_NB),
+                (int)(c->np / GPMI_NB), (int)c->np);
+    launch_mirror_lower(s, L.A, c->ld, c->np);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpy2DAsync(iK_out, sizeof(double) * c->n, L.A, sizeof(double) * c->ld, sizeof(double) * c->n,
+                               (size_t)c->n, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (alpha_out) HIPCHK(c, hipMemcpyAsync(alpha_out, alpha_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  INFOCHK(c, L.h_info[0]);
+  // -1/2 v.v - sum ln L_ii (regression.py:539); the caller applies the -1e50 convention (regression.py:540-542)
+  *lml = (L.h_info[0] == 0) ? (-0.5 * L.h_red[0] - L.h_red[1]) : -1e50;
+  if (info) *info = L.h_info[0];
+  return GPMI_OK;
+}
+
+int gpmi_loo_dense(gpmi_ctx* c, const double* K_host, const double* mu, double* alpha_out, double* ikdiag,
+                   double* p_out, double* W_out, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->n > 0, "gpmi_set_data has not been called");
+  ARGCHK(c, K_host && mu && alpha_out && ikdiag, "NULL argument");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = ensure_lanes(c, 2)) return rc;
+  Lane& L = c->lanes[1];
+  if (int rc = ensure_second_matrix(c, L)) return rc;
+  const int64_t need = 4 * c->np;
+  if (L.gws_doubles < need) {
+    if (L.gws) (void)hipFree(L.gws);
+    L.gws = nullptr;
+    L.gws_doubles = 0;
+    HIPCHK(c, hipMalloc(&L.gws, sizeof(double) * need));
+    L.gws_doubles = need;
+  }
+  hipStream_t s = L.stream;
+  const int nt = (int)(c->np / GPMI_NB);
+  double* mu_dev = L.vec + 3 * c->np;
+  double* alpha_dev = L.vec + c->np;
+  double *diag_dev = L.gws, *c1_dev = L.gws + c->np, *sc2_dev = L.gws + 2 * c->np, *p_dev = L.gws + 3 * c->np;
+  HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
+  if (int rc = upload_dense_matrix(c, L, K_host)) return rc;
+  if (int rc = enqueue_dense_factor_and_forward(c, L, mu_dev, 0)) return rc;
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, alpha_dev, L.info);
+  if (int rc = enqueue_inverse_factor(c, L, L)) return rc;
+  launch_rows_sumsq(s, L.B2, c->ld, c->np, c->np, 0.0, diag_dev);  // = -diag(K^-1)   (regression.py:503)
+  hipLaunchKernelGGL(negate_kernel, dim3((unsigned)((c->np + 255) / 256)), dim3(256), 0, s, diag_dev, c->np);
+  HIPCHK(c, hipMemcpyAsync(ikdiag, diag_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  if (p_out || W_out) {
+    // the gradient's two parameter-independent pieces (regression.py:507-514 regrouped):
+    //   sum_i c1_i (K^-1 dK alpha)_i = p . (dK alpha),  p = K^-1 c1
+    //   sum_i c2_i (K^-1 dK K^-1)_ii = sum dK o W,       W = K^-1 diag(c2) K^-1 = G G^T, G = K^-1 diag(sqrt c2)
+    launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, true, L.A, c->ld, L.B2, c->ld, L.B2, c->ld, nt, nt, (int)c->np);
+    launch_mirror_lower(s, L.A, c->ld, c->np);
+    launch_loo_vectors(s, alpha_dev, diag_dev, c1_dev, sc2_dev, c->n, c->np);
+    launch_rows_dot(s, L.A, c->ld, c->np, c->np, c1_dev, p_dev);
+    if (p_out) HIPCHK(c, hipMemcpyAsync(p_out, p_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+    if (W_out) {
+      launch_scale_columns(s, L.A, sc2_dev, L.B2, c->ld, c->np);
+      launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, false, L.A, c->ld, L.B2, c->ld, L.B2, c->ld, nt, nt, (int)c->np);
+      launch_mirror_lower(s, L.A, c->ld, c->np);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipMemcpy2DAsync(W_out, sizeof(double) * c->n, L.A, sizeof(double) * c->ld, sizeof(double) * c->n,
+                                 (size_t)c->n, hipMemcpyDeviceToHost, s));
+    }
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(alpha_out, alpha_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  INFOCHK(c, L.h_info[0]);
+  if (info) *info = L.h_info[0];
+  return GPMI_OK;
+}
+
+int gpmi_predict_dense(gpmi_ctx* c, const double* Kq_host, int64_t m, double* kalpha_out, double* sumsq_out) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->fitted, "gpmi_predict_dense needs a successful fit");
+  ARGCHK(c, Kq_host && m > 0, "Kq is NULL or m <= 0");
+  if (int rc = set_device(c)) return rc;
+  Lane& L = c->lanes[0];
+  hipStream_t s = L.stream;
+  const int64_t chunk = 2048;
+  for (int64_t m0 = 0; m0 < m; m0 += chunk) {
+    const int64_t mc = (m - m0 < chunk) ? m - m0 : chunk;
+    const int64_t mp = round_up(mc, GPMI_NB);
+    if (int rc = ensure_query_ws(c, mp)) return rc;
+    if (int rc = upload_query_panel(c, s, c->Q, Kq_host + m0 * c->n, mc, mp)) return rc;
+    double* mu_dev = c->pvec;
+    double* ss_dev = c->pvec + mp;
+    if (kalpha_out) launch_rows_dot(s, c->Q, c->ld, mp, c->np, c->alpha, mu_dev);
+    if (sumsq_out) {
+      if (int rc = ensure_inv2(c, L, s)) return rc;
+      trsm_rows_forward(c, s, L.A, c->np, c->ld, L.inv2, c->Q, mp, false, c->Q2, nullptr);
+      launch_rows_sumsq(s, c->Q2, c->ld, mp, c->np, 0.0, ss_dev);  // - |L^-1 k|^2
+    }
+    HIPCHK(c, hipGetLastError());
+    if (kalpha_out) HIPCHK(c, hipMemcpyAsync(kalpha_out + m0, mu_dev, sizeof(double) * mc, hipMemcpyDeviceToHost, s));
+    if (sumsq_out) HIPCHK(c, hipMemcpyAsync(sumsq_out + m0, ss_dev, sizeof(double) * mc, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+  }
+  if (sumsq_out)
+    for (int64_t i = 0; i < m; ++i) sumsq_out[i] = -sumsq_out[i];
+  return GPMI_OK;
+}
+
+int gpmi_solve_rows(gpmi_ctx* c, const double* Q_host, int64_t m, double* X_host, double* gram_host) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->fitted, "gpmi_solve_rows needs a successful fit");
+  ARGCHK(c, Q_host && m > 0 && (X_host || gram_host), "Q is NULL, m <= 0 or nothing requested");
+  if (int rc = set_device(c)) return rc;
+  Lane& L = c->lanes[0];
+  hipStream_t s = L.stream;
+  const int64_t mp = round_up(m, GPMI_NB);
+  ARGCHK(c, mp <= 8192, "at most 8192 right-hand sides per call");
+  if (int rc = ensure_query_ws(c, mp)) return rc;
+  if (int rc = upload_query_panel(c, s, c->Q, Q_host, m, mp)) return rc;
+  if (int rc = ensure_inv2(c, L, s)) return rc;
+  trsm_rows_forward(c, s, L.A, c->np, c->ld, L.inv2, c->Q, mp, false, c->Q2, nullptr);  // X = Q L^-T
+  HIPCHK(c, hipGetLastError());
+  if (X_host)
+    HIPCHK(c, hipMemcpy2DAsync(X_host, sizeof(double) * c->n, c->Q2, sizeof(double) * c->ld, sizeof(double) * c->n,
+                               (size_t)m, hipMemcpyDeviceToHost, s));
+  if (gram_host) {
+    // G = X X^T (m x m): what posterior covariances are made of (regression.py:447-448)
+    double* G = nullptr;
+    const int64_t ldg = mp + 32;
+    HIPCHK(c, hipMalloc(&G, sizeof(double) * mp * ldg));
+    launch_gemm_nt(s, TILES_RECT, OP_ASSIGN, G, ldg, c->Q2, c->ld, c->Q2, c->ld, (int)(mp / GPMI_NB),
+                   (int)(mp / GPMI_NB), (int)c->np);
+    hipError_t e = hipMemcpy2DAsync(gram_host, sizeof(double) * m, G, sizeof(double) * ldg, sizeof(double) * m,
+                                    (size_t)m, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(G);
+    HIPCHK(c, e);
+  }
+  HIPCHK(c, hipStreamSynchronize(s));
   return GPMI_OK;
 }
 

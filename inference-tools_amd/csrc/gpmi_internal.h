@@ -95,6 +95,7 @@ struct gpmi_ctx {
   // fitted state lives in lanes[0]
   std::vector<Lane> lanes;
   bool fitted = false;
+  bool lockstep_always = false;  // GPMI_OPT_LOCKSTEP_ALWAYS
   KParams fit_params{};
   double* alpha = nullptr;  // np (device) — fitted alpha
   // prediction workspace

@@ -127,6 +127,9 @@ class GpEngine:
         self.h.call("gpmi_lml_grad_qdiag", dptr(q))
         return q
 
+    def set_option(self, option, value):
+        self.h.call("gpmi_set_option", int(option), int(value))
+
     def set_streams(self, n):
         self.h.call("gpmi_set_streams", int(n))
 
@@ -224,6 +227,47 @@ class GpEngine:
         self.h.call("gpmi_loo_grad", kernel, dptr(theta), theta.size, float(extra_diag), dptr(mu),
                     dptr(alpha), dptr(ikdiag), dptr(pvec), dptr(grad), C.byref(trq), C.byref(info))
         return alpha, ikdiag, pvec, grad, trq.value, info.value
+
+    # -- dense entry points (covariance functions that only implement the plugin ABC) ------------------
+    def fit_dense(self, K, mu):
+        K, mu = as_f64(K), as_f64(mu)
+        alpha = np.empty(self.n)
+        logdet, info = C.c_double(0.0), C.c_int(0)
+        self.h.call("gpmi_fit_dense", dptr(K), dptr(mu), dptr(alpha), C.byref(logdet), C.byref(info))
+        return alpha, logdet.value, info.value
+
+    def lml_dense(self, K, mu, want_alpha=False, want_inverse=False):
+        K, mu = as_f64(K), as_f64(mu)
+        lml, info = C.c_double(0.0), C.c_int(0)
+        alpha = np.empty(self.n) if want_alpha else None
+        iK = np.empty((self.n, self.n)) if want_inverse else None
+        self.h.call("gpmi_lml_dense", dptr(K), dptr(mu), C.byref(lml), dptr(alpha), dptr(iK), C.byref(info))
+        return lml.value, alpha, iK, info.value
+
+    def loo_dense(self, K, mu, want_gradient_pieces=False):
+        K, mu = as_f64(K), as_f64(mu)
+        alpha, ikdiag = np.empty(self.n), np.empty(self.n)
+        pvec = np.empty(self.n) if want_gradient_pieces else None
+        W = np.empty((self.n, self.n)) if want_gradient_pieces else None
+        info = C.c_int(0)
+        self.h.call("gpmi_loo_dense", dptr(K), dptr(mu), dptr(alpha), dptr(ikdiag), dptr(pvec), dptr(W), C.byref(info))
+        return alpha, ikdiag, pvec, W, info.value
+
+    def predict_dense(self, Kq, want_var=True):
+        Kq = as_f64(Kq)
+        m = Kq.shape[0]
+        ka = np.empty(m)
+        ss = np.empty(m) if want_var else None
+        self.h.call("gpmi_predict_dense", dptr(Kq), m, dptr(ka), dptr(ss))
+        return ka, ss
+
+    def solve_rows(self, Q, want_rows=True, want_gram=False):
+        Q = as_f64(Q)
+        m = Q.shape[0]
+        X = np.empty((m, self.n)) if want_rows else None
+        G = np.empty((m, m)) if want_gram else None
+        self.h.call("gpmi_solve_rows", dptr(Q), m, dptr(X), dptr(G))
+        return X, G
 
     # -- multi-GPU gather (RCCL) -----------------------------------------------------------
     @staticmethod

@@ -21,6 +21,7 @@ LIB_PATH = os.environ.get("GPMI_LIB") or os.path.join(_HERE, "lib", "libgpmi.so"
 KERNEL_SE = 0
 KERNEL_RQ = 1
 PROF_KBUILD, PROF_SYRK, PROF_PANEL, PROF_SOLVE = 0, 1, 2, 3
+OPT_LOCKSTEP_ALWAYS = 1
 
 
 class GpmiUnavailable(RuntimeError):
@@ -49,6 +50,7 @@ SIGNATURES = {
     "gpmi_lml": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _ip]),
     "gpmi_lml_batch": (C.c_int, [_vp, C.c_int, _i64, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_set_streams": (C.c_int, [_vp, C.c_int]),
+    "gpmi_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
     "gpmi_lml_grad": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_predict": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
     "gpmi_posterior": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
@@ -73,6 +75,11 @@ SIGNATURES = {
     "gpmi_linv_lml": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _ip]),
     "gpmi_linv_lml_grad": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_linv_posterior": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _ip]),
+    "gpmi_fit_dense": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_lml_dense": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_loo_dense": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_predict_dense": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
+    "gpmi_solve_rows": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
     "gpmi_comm_unique_id": (C.c_int, [C.c_char_p]),
     "gpmi_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p]),
     "gpmi_comm_allgather": (C.c_int, [_vp, _dp, _dp, _i64]),

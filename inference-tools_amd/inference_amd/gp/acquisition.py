@@ -99,7 +99,7 @@ class ExpectedImprovement(AcquisitionFunction):
         """(-ln EI, -grad ln EI) for M points: (M,), (M, d) (acquisition.py:99-125)."""
         p = self.gp.process_points(points)
         mu, sig = self.gp(p)
-        dmu, dvar = self.gp.engine.spatial_derivatives(p)
+        dmu, dvar = self.gp.spatial_derivatives_batch(p)
         ln_ei, Z, lo = self._ln_ei(mu, sig)
         grad = np.empty_like(dmu)
         if lo.any():
@@ -155,7 +155,7 @@ class UpperConfidenceBound(AcquisitionFunction):
     def opt_func_gradient_batch(self, points):
         p = self.gp.process_points(points)
         mu, sig = self.gp(p)
-        dmu, dvar = self.gp.engine.spatial_derivatives(p)
+        dmu, dvar = self.gp.spatial_derivatives_batch(p)
         return -(mu + self.kappa * sig), -(dmu + 0.5 * self.kappa * dvar / sig[:, None])
 
     def __call__(self, x) -> float:
@@ -186,7 +186,7 @@ class MaxVariance(AcquisitionFunction):
     def opt_func_gradient_batch(self, points):
         p = self.gp.process_points(points)
         _, sig = self.gp(p)
-        _, dvar = self.gp.engine.spatial_derivatives(p)
+        _, dvar = self.gp.spatial_derivatives_batch(p)
         return -(sig**2), -dvar
 
     def __call__(self, x) -> float:

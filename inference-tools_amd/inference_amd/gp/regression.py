@@ -46,8 +46,9 @@ class GpRegressor:
     :param mean: mean-function class or instance.
     :param bool cross_val: select hyper-parameters by LOO cross-validation.
     :param str optimizer: ``"bfgs"`` (multi-start L-BFGS-B) or ``"diffev"``.
-    :param int n_processes: kept for signature compatibility; the starts are
-        evaluated on the device one after another.
+    :param int n_processes: number of GPU workers for the multi-start search: inside a multi-GPU
+        job (one process per GPU, `inference_amd.sharding`) the L-BFGS-B starts are sharded over the
+        ranks; in a single process they run one after another on the device.
     :param int n_starts: number of L-BFGS-B starting positions.
     :param device: (extension) HIP device index; default ``LOCAL_RANK`` / 0.
     """
@@ -91,11 +92,14 @@ class GpRegressor:
         self.hyperpar_labels = [*self.mean.hyperpar_labels, *self.cov.hyperpar_labels]
 
         plan = device_plan(self.cov)
-        if plan is None:
-            raise NotImplementedError(msg.no_device_kernel(type(self.cov)))
+        # A covariance object that only implements the plugin ABC (covariance.py:8-44): its own host methods
+        # produce the dense matrices, the device does every O(N^3) step (gpmi_*_dense).  No CPU solve anywhere.
+        self._generic = plan is None
+        if self._generic:
+            plan = (None, None, slice(0, self.cov.n_params), None)
         self._kernel_id, self._stat, self._stat_slice, self._wn_index = plan
         self._mix = self._stat if self._kernel_id == -1 else None  # ChangePoint: mixture entry points
-        self._het_slice = heteroscedastic_slice(self.cov)
+        self._het_slice = None if self._generic else heteroscedastic_slice(self.cov)
         self._fit_noise = None
         self._device = device
         self._engine = None
@@ -200,6 +204,8 @@ class GpRegressor:
 
     @property
     def K_xx(self) -> ndarray:
+        if self._K_cache is None and self._generic:
+            self._K_cache = self._dense_K(self.cov_hyperpars)
         if self._K_cache is None and self._mix is not None:
             # host composition of the sub-kernels' device builds (ChangePoint.build_covariance) + sig
             self._K_cache = self.cov.build_covariance(np.asarray(self.cov_hyperpars, dtype=float)) + self.sig
@@ -223,6 +229,8 @@ class GpRegressor:
         """Mean and standard deviation of the regression estimate at `points`
         (regression.py:188-216), evaluated as one batched device call."""
         p = self.process_points(points)
+        if self._generic:
+            return self._generic_predict(p)
         self._refit_mixture_if_stale()
         if self._mix is not None:
             theta_cp = np.asarray(self.cov_hyperpars, dtype=float)[self._stat_slice]
@@ -243,6 +251,14 @@ class GpRegressor:
         self.mean_hyperpars = self.hyperpars[self.mean_slice]
         self.cov_hyperpars = self.hyperpars[self.cov_slice]
         self.mu = self.mean.build_mean(self.mean_hyperpars)
+        if self._generic:
+            self._K_cache = self._dense_K(self.cov_hyperpars)
+            self._L_cache = None
+            alpha, logdet, info = self.engine.fit_dense(self._K_cache, self.mu)
+            if info != 0:
+                raise LinAlgError("Matrix is not positive definite")
+            self.alpha, self._logdet = alpha, logdet
+            return
         theta_stat, extra = self._split_cov_theta(self.cov_hyperpars)
         self._fit_noise = self._noise_total(self.cov_hyperpars) if self._het_slice is not None else None
         self._K_cache = None
@@ -302,6 +318,8 @@ class GpRegressor:
         return q
 
     def _require_gradient_terms(self):
+        if self._generic:
+            return
         if self._mix is not None:
             self._mix.gradient_terms(None, None, None)  # ChangePoint has none either (covariance.py:38-44)
         if self._kernel_id != 0:
@@ -312,6 +330,8 @@ class GpRegressor:
         """Mean and covariance of the gradient of the estimate (regression.py:351-385)."""
         self._require_gradient_terms()
         p = self.process_points(points)
+        if self._generic:
+            return self._generic_gradient(p)
         gmu, gcov = self.engine.gradient(p)
         return gmu.squeeze(), gcov.squeeze()
 
@@ -319,8 +339,20 @@ class GpRegressor:
         """Gradients of the predictive mean and variance (regression.py:387-419)."""
         self._require_gradient_terms()
         p = self.process_points(points)
+        if self._generic:
+            return self._generic_spatial_derivatives(p)
         dmu, dvar = self.engine.spatial_derivatives(p)
         return dmu.squeeze(), dvar.squeeze()
+
+    def spatial_derivatives_batch(self, points: ndarray):
+        """(extension) `spatial_derivatives` for M points with un-squeezed (M, d) results: the form the batched
+        acquisition functions consume."""
+        self._require_gradient_terms()
+        p = self.process_points(points)
+        if self._generic:
+            dmu, dvar = self._generic_spatial_derivatives(p)
+            return dmu.reshape(len(p), -1), dvar.reshape(len(p), -1)
+        return self.engine.spatial_derivatives(p)
 
     def _no_mixture(self, what):
         if self._mix is not None:
@@ -329,6 +361,8 @@ class GpRegressor:
     def build_posterior(self, points: ndarray, mean_only=False):
         """Posterior mean vector and covariance matrix (regression.py:421-449)."""
         v = self.process_points(points)
+        if self._generic:
+            return self._generic_posterior(v, mean_only)
         self._refit_mixture_if_stale()
         if self._mix is not None:
             theta_cp = np.asarray(self.cov_hyperpars, dtype=float)[self._stat_slice]
@@ -342,13 +376,16 @@ class GpRegressor:
 
     def loo_predictions(self):
         """Leave-one-out predictions, R&W eq. 5.12 (regression.py:451-466)."""
-        self._refit_mixture_if_stale()
+        if not self._generic:
+            self._refit_mixture_if_stale()
         var = 1.0 / self.engine.loo_diag()
         return self.y - self.alpha * var, sqrt(var)
 
     def loo_likelihood(self, theta: ndarray) -> float:
         """Leave-one-out log-likelihood, R&W eqs. 5.10-5.12 (regression.py:468-487)."""
         theta = np.asarray(theta, dtype=float)
+        if self._generic:
+            return self._generic_loo(theta, want_gradient=False)
         theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
         mu = self.mean.build_mean(theta[self.mean_slice])
         if self._mix is not None:
@@ -364,8 +401,10 @@ class GpRegressor:
 
     def loo_likelihood_gradient(self, theta: ndarray):
         """LOO log-likelihood and its gradient, R&W eqs. 5.10-5.14 (regression.py:489-526)."""
-        self._no_mixture("loo_likelihood_gradient")
         theta = np.asarray(theta, dtype=float)
+        if self._generic:
+            return self._generic_loo(theta, want_gradient=True)
+        self._no_mixture("loo_likelihood_gradient")
         if self._het_slice is not None:
             raise NotImplementedError("loo_likelihood_gradient: HeteroscedasticNoise has no device gradient yet")
         theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
@@ -388,6 +427,13 @@ class GpRegressor:
     def marginal_likelihood(self, theta: ndarray) -> float:
         """Log-marginal likelihood, R&W eq. 5.8 without the 2 pi constant (regression.py:528-542)."""
         theta = np.asarray(theta, dtype=float)
+        if self._generic:
+            value, _, _, info = self.engine.lml_dense(self._dense_K(theta[self.cov_slice]),
+                                                      self.mean.build_mean(theta[self.mean_slice]))
+            if info != 0:
+                warn("Cholesky decomposition failure in marginal_likelihood")
+                return -1e50
+            return float(value)
         theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
         mu = self.mean.build_mean(theta[self.mean_slice])
         if self._mix is not None:
@@ -400,6 +446,15 @@ class GpRegressor:
             return -1e50
         return float(value)
 
+    def batch_independent_values(self, on: bool = True):
+        """(extension) Make `marginal_likelihood_batch` values independent of the batch they are evaluated in
+        (`GPMI_OPT_LOCKSTEP_ALWAYS`): every call, also of a single theta, takes the lockstep device path.  The
+        lockstep MCMC drivers switch this on so that a chain's trajectory does not depend on which other chains
+        happen to share its proposal rounds."""
+        from inference_amd import _lib
+
+        self.engine.set_option(_lib.OPT_LOCKSTEP_ALWAYS, 1 if on else 0)
+
     def marginal_likelihood_batch(self, thetas: ndarray) -> ndarray:
         """(extension) `marginal_likelihood` for T hyper-parameter vectors at once, spread over
         the device's worker streams — the unit the grid sweep / PT driver shards over GPUs."""
@@ -407,7 +462,7 @@ class GpRegressor:
         if thetas.size == 0:
             return np.empty(0)  # an empty shard (more ranks than evaluations)
         thetas = np.atleast_2d(thetas)
-        if self._het_slice is not None or self._mix is not None:  # per-point terms change with theta: one at a time
+        if self._generic or self._het_slice is not None or self._mix is not None:  # per-point terms change with theta: one at a time
             return np.array([self.marginal_likelihood(t) for t in thetas])
         split = [self._split_cov_theta(t[self.cov_slice]) for t in thetas]
         th = np.array([s[0] for s in split])
@@ -424,6 +479,8 @@ class GpRegressor:
     def marginal_likelihood_gradient(self, theta: ndarray):
         """LML and its gradient, R&W eqs. 5.8-5.9 (regression.py:544-567)."""
         theta = np.asarray(theta, dtype=float)
+        if self._generic:
+            return self._generic_lml_gradient(theta)
         theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
         mu, grad_mu = self.mean.mean_and_gradients(theta[self.mean_slice])
         if self._mix is not None:
@@ -464,6 +521,112 @@ class GpRegressor:
         return lml, grad, alpha, trace_q, info
 
     # ---------------------------------------------------------------------------------
+    # covariance functions that only implement the plugin ABC: the plugin's host methods make the dense
+    # matrices, the device factorises / solves (gpmi_fit_dense, gpmi_lml_dense, gpmi_predict_dense, gpmi_solve_rows)
+    # ---------------------------------------------------------------------------------
+    def _dense_K(self, theta_cov):
+        return np.ascontiguousarray(self.cov.build_covariance(np.asarray(theta_cov, dtype=float)) + self.sig)
+
+    def _generic_cross(self, p):
+        """(K_qx (M, N), diag K_qq (M,)) from the plugin's __call__ (regression.py:209-210 evaluates it point by point)."""
+        th = np.asarray(self.cov_hyperpars, dtype=float)
+        Kq = np.ascontiguousarray(self.cov(p, self.x, th))
+        kqq = array([float(self.cov(q, q, th)[0, 0]) for q in p[:, None, :]])
+        return Kq, kqq
+
+    def _generic_predict(self, p):
+        Kq, kqq = self._generic_cross(p)
+        ka, ss = self.engine.predict_dense(Kq)
+        return ka + self._mean_at(p), sqrt(abs(kqq - ss))
+
+    def _generic_posterior(self, v, mean_only):
+        th = np.asarray(self.cov_hyperpars, dtype=float)
+        Kq = np.ascontiguousarray(self.cov(v, self.x, th))
+        mu = self.engine.predict_dense(Kq, want_var=False)[0] + self._mean_at(v)
+        if mean_only:
+            return mu
+        _, gram = self.engine.solve_rows(Kq, want_rows=False, want_gram=True)
+        return mu, self.cov(v, v, th) - gram  # regression.py:447-448
+
+    def _generic_lml_gradient(self, theta):
+        """regression.py:544-567 with K^-1 from the device and dK from the plugin's covariance_and_gradients."""
+        K, grad_K = self.cov.covariance_and_gradients(theta[self.cov_slice])
+        mu, grad_mu = self.mean.mean_and_gradients(theta[self.mean_slice])
+        lml, alpha, iK, info = self.engine.lml_dense(np.ascontiguousarray(K + self.sig), mu, want_alpha=True,
+                                                     want_inverse=True)
+        if info != 0:
+            raise LinAlgError("Matrix is not positive definite")
+        Q = alpha[:, None] * alpha[None, :] - iK
+        grad = zeros(self.n_hyperpars)
+        grad[self.mean_slice] = array([(alpha * dmu).sum() for dmu in grad_mu])
+        grad[self.cov_slice] = array([0.5 * (Q * dK.T).sum() for dK in grad_K])
+        return lml, grad
+
+    def _generic_loo(self, theta, want_gradient):
+        """regression.py:468-526.  The device returns alpha, diag(K^-1) and - for the gradient - the two
+        parameter-independent pieces p = K^-1 c1 and W = K^-1 diag(c2) K^-1, so that each of the P gradient
+        components is an O(N^2) contraction with the plugin's own dK_j instead of the reference's N^3 product
+        K^-1 dK_j (:512): sum_i c1_i (K^-1 dK alpha)_i - c2_i (K^-1 dK K^-1)_ii = p . (dK alpha) - sum dK o W."""
+        if want_gradient:
+            K, grad_K = self.cov.covariance_and_gradients(theta[self.cov_slice])
+            mu, grad_mu = self.mean.mean_and_gradients(theta[self.mean_slice])
+        else:
+            K, mu = self.cov.build_covariance(theta[self.cov_slice]), self.mean.build_mean(theta[self.mean_slice])
+        alpha, ikdiag, pvec, W, info = self.engine.loo_dense(np.ascontiguousarray(K + self.sig), mu, want_gradient)
+        if info != 0:
+            if want_gradient:
+                raise LinAlgError("Matrix is not positive definite")
+            warn("Cholesky decomposition failure in loo_likelihood")
+            return -1e50
+        var = 1.0 / ikdiag
+        LOO = float(-0.5 * (var * alpha**2 + np.log(var)).sum())
+        if not want_gradient:
+            return LOO
+        grad = zeros(self.n_hyperpars)
+        grad[self.mean_slice] = array([(pvec * dmu).sum() for dmu in grad_mu])
+        grad[self.cov_slice] = array([pvec @ (dK @ alpha) - (dK * W).sum() for dK in grad_K])
+        return LOO, grad
+
+    def _gradient_pieces(self, p):
+        """Per query point: A (d, N), R, k (N,) from the plugin's gradient_terms / __call__ (regression.py:368-372)."""
+        th = np.asarray(self.cov_hyperpars, dtype=float)
+        Kq = np.ascontiguousarray(self.cov(p, self.x, th))
+        terms = [self.cov.gradient_terms(q, self.x, th) for q in p]
+        return Kq, [t[0] for t in terms], [t[1] for t in terms]
+
+    def _generic_gradient(self, p):
+        """regression.py:351-385: mean and covariance of the gradient, the triangular solves batched on the device."""
+        Kq, As, Rs = self._gradient_pieces(p)
+        d = self.n_dimensions
+        gmu = array([A @ (k * self.alpha) for A, k in zip(As, Kq)])
+        rhs = np.concatenate([A * k[None, :] for A, k in zip(As, Kq)], axis=0)  # (M d, N)
+        gcov = np.empty((len(p), d, d))
+        step = max(1, 4096 // d)
+        for lo in range(0, len(p), step):
+            hi = min(lo + step, len(p))
+            X, _ = self.engine.solve_rows(rhs[lo * d:hi * d])
+            for i in range(lo, hi):
+                Xi = X[(i - lo) * d:(i - lo + 1) * d]
+                gcov[i] = Rs[i] - Xi @ Xi.T  # regression.py:379 (a vector R broadcasts over the rows, as there)
+        return gmu.squeeze(), gcov.squeeze()
+
+    def _generic_spatial_derivatives(self, p):
+        """regression.py:387-419: grad mu = A (k o alpha), grad var = -2 (A o k) K^-1 k."""
+        Kq, As, _ = self._gradient_pieces(p)
+        d = self.n_dimensions
+        dmu = array([A @ (k * self.alpha) for A, k in zip(As, Kq)])
+        dvar = np.empty((len(p), d))
+        step = max(1, 4096 // (d + 1))
+        for lo in range(0, len(p), step):
+            hi = min(lo + step, len(p))
+            rows = np.concatenate([np.vstack([As[i] * Kq[i][None, :], Kq[i][None, :]]) for i in range(lo, hi)], axis=0)
+            X, _ = self.engine.solve_rows(rows)  # rows L^-T: (A o k) L^-T and k L^-T per point
+            for i in range(lo, hi):
+                blk = X[(i - lo) * (d + 1):(i - lo + 1) * (d + 1)]
+                dvar[i] = -2.0 * blk[:d] @ blk[d]
+        return dmu.squeeze(), dvar.squeeze()
+
+    # ---------------------------------------------------------------------------------
     # hyper-parameter search (regression.py:569-605): SciPy drivers on the host, every
     # objective evaluation on the device
     # ---------------------------------------------------------------------------------
@@ -485,6 +648,16 @@ class GpRegressor:
         # random starts from the legacy global RNG plus the bounds centre (regression.py:589-594)
         starting_positions = [lwr + (upr - lwr) * random(size=len(self.hp_bounds)) for _ in range(starts - 1)]
         starting_positions.append(0.5 * (lwr + upr))
+        if n_processes > 1:
+            # the reference farms the starts over a multiprocessing.Pool (regression.py:597-601); here
+            # `n_processes` counts GPU workers: when this process is one rank of a multi-GPU job (one process per
+            # GPU, see inference_amd.sharding) the starts are block-sharded over the ranks and ONE all-gather
+            # returns (theta*, f*) of every start - never a fork of a process that holds a device context.
+            from inference_amd import sharding
+
+            if sharding.world()[1] > 1:
+                thetas, fvals = sharding.multistart_sweep(self, array(starting_positions))
+                return thetas[int(np.argsort(fvals, kind="stable")[0])]
         results = [self.launch_bfgs(x0) for x0 in starting_positions]
         return sorted(results, key=lambda r: r[1])[0][0]
 

@@ -39,7 +39,11 @@ def _common_batch_posterior(chains):
         if not hasattr(obj, "marginal_likelihood_batch") or (owner is not None and obj is not owner):
             return None
         owner = obj
-    return owner.marginal_likelihood_batch if owner is not None else None
+    if owner is None:
+        return None
+    if hasattr(owner, "batch_independent_values"):
+        owner.batch_independent_values(True)  # ragged retry rounds: a value must not depend on its batch
+    return owner.marginal_likelihood_batch
 
 
 class ParallelTempering:

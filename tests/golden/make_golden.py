@@ -23,6 +23,8 @@ Cases
   linv       GpLinearInverter: 1-D deconvolution (32 x 64) and 2-D tomography (300 x 400), SE / RQ / SE+WhiteNoise
   search     the stochastic callers under numpy.random.seed: multistart_bfgs (start positions, theta*, LML(theta*); LML and
              LOO objectives), differential_evo, AcquisitionFunction.starting_positions, GpOptimiser.propose_evaluation
+  plugin     a user-defined covariance function written against the plugin ABC only (Matern-3/2, workloads.Matern32Math):
+             every public GpRegressor method, the seeded hyper-parameter search and an EI proposal
   means      LinearMean / QuadraticMean: labels, bounds, fit, predict, LML, LML gradient (mean-parameter components
              included), LOO gradient, posterior
 """
@@ -498,6 +500,47 @@ def case_search():
     return out
 
 
+def case_plugin():
+    """A covariance function that only implements the ABC (covariance.py:8-44) through the reference's classes."""
+    from inference.gp import GpOptimiser
+    from inference.gp.covariance import CovarianceFunction
+
+    class Matern32(wl.Matern32Math, CovarianceFunction):
+        pass
+
+    out = {}
+    x, y, e, pts, thetas = wl.plugin_problem()
+    gp = GpRegressor(x, y, y_err=e, hyperpars=thetas[0], kernel=Matern32)
+    out["thetas"] = thetas
+    out["labels"] = np.array(gp.hyperpar_labels)
+    out["bounds"] = np.array(gp.hp_bounds, dtype=float)
+    out["K_xx"], out["L"], out["alpha"] = gp.K_xx, gp.L, gp.alpha
+    out["mu"], out["sig"] = gp(pts)
+    out["post_mu"], out["post_cov"] = gp.build_posterior(pts[:12])
+    out["grad_mu"], out["grad_cov"] = gp.gradient(pts[:12])
+    out["sd_mu"], out["sd_var"] = gp.spatial_derivatives(pts[:12])
+    out["loo_mu"], out["loo_sig"] = gp.loo_predictions()
+    out["lml"] = np.array([gp.marginal_likelihood(t) for t in thetas])
+    res = [gp.marginal_likelihood_gradient(t) for t in thetas]
+    out["lml2"], out["grad"] = np.array([r[0] for r in res]), np.array([r[1] for r in res])
+    out["loo"] = np.array([gp.loo_likelihood(t) for t in thetas])
+    res = [gp.loo_likelihood_gradient(t) for t in thetas]
+    out["loo2"], out["loo_grad"] = np.array([r[0] for r in res]), np.array([r[1] for r in res])
+    np.random.seed(17)
+    gps = GpRegressor(x, y, y_err=e, kernel=Matern32, n_starts=3)
+    out["search_theta"] = np.array(gps.hyperpars)
+    out["search_lml"] = np.array(gps.marginal_likelihood(gps.hyperpars))
+    # Bayesian optimisation on the plugin kernel: EI with its analytic gradient through gradient_terms
+    bx, by, bounds = bo_problem()
+    th = np.array([by.mean(), np.log(by.std()), np.log(2.0), np.log(2.0)])
+    opt = GpOptimiser(bx, by, bounds=bounds, hyperpars=th, kernel=Matern32)
+    np.random.seed(41)
+    prop = opt.propose_evaluation()
+    out["bo_theta"], out["bo_proposal"] = th, np.array(prop)
+    out["bo_value"] = np.array(float(np.squeeze(opt.acquisition.opt_func(np.array(prop)))))
+    return out
+
+
 def case_means():
     """LinearMean / QuadraticMean (mean.py:54-126) with SE and RQ kernels on a 60-point 2-D set with a trend."""
     from inference.gp import LinearMean, QuadraticMean
@@ -545,6 +588,7 @@ IDX_TOMO = np.arange(0, 400, 7)  # 58 rows / columns of the 400 x 400 posterior 
 
 CASES = {
     "search": case_search,
+    "plugin": case_plugin,
     "means": case_means,
     "cp": case_cp,
     "het": case_het,

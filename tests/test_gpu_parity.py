@@ -698,7 +698,7 @@ def test_change_point_vs_reference(golden, gp_mod, tag, subs, wn):
 
 def test_change_point_search_and_limits(gp_mod):
     """Hyper-parameter search through the mixture path (L-BFGS-B with the analytic gradient); three regions
-    work for fit / predict / LML but not for the gradient; unsupported sub-kernels are refused."""
+    work for fit / predict / LML but not for the gradient; sub-kernels without device code take the dense path."""
     rng = np.random.default_rng(11)
     x = np.sort(rng.uniform(0, 1, 120)).reshape(-1, 1)
     y = np.where(x[:, 0] < 0.5, np.sin(4 * x[:, 0]), np.sin(40 * x[:, 0])) + 0.05 * rng.normal(size=120)
@@ -716,9 +716,11 @@ def test_change_point_search_and_limits(gp_mod):
     assert np.isfinite(gp3.marginal_likelihood(th3)) and np.isfinite(gp3(x[:5])[0]).all()
     with pytest.raises(NotImplementedError):
         gp3.marginal_likelihood_gradient(th3)
-    with pytest.raises(NotImplementedError):
-        gp_mod.GpRegressor(x, y, y_err=e, hyperpars=np.zeros(4),
-                           kernel=gp_mod.ChangePoint(kernels=[gp_mod.SquaredExponential, gp_mod.WhiteNoise]))
+    # a combination without a fused device path (a WhiteNoise region) goes through the plugin methods + dense device path
+    cpw = gp_mod.ChangePoint(kernels=[gp_mod.SquaredExponential, gp_mod.WhiteNoise])
+    thw = np.array([0.0, 0.0, np.log(0.3), np.log(0.1), 0.5, 0.05])
+    gpw = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=thw, kernel=cpw)
+    assert gpw._generic and np.isfinite(gpw.marginal_likelihood(thw)) and np.isfinite(gpw(x[:5])[0]).all()
 
 
 def test_ragged_large_size_vs_oracle(gp_mod):
@@ -950,3 +952,117 @@ def test_suite_detects_a_1e11_fault():
                          env=env, capture_output=True, text=True, timeout=600)
     assert run.returncode != 0, "a 1e-11 perturbation of potrf_diag's output went unnoticed:\n" + run.stdout[-2000:]
     assert "relative error" in run.stdout
+
+
+def test_config5_ladders_in_lockstep_at_stated_shape(gp_mod):
+    """BASELINE config 5 at its per-GPU shape: 8 ladders x 8 temperatures (64 chains) over the LML of an N = 2048,
+    d = 4 GP, advanced by `advance_ladders` (one batched device evaluation per proposal round of all 64 chains,
+    ragged retries included).  The trajectories are bit-identical to the same ladders advanced one at a time (8
+    chains per round), i.e. a chain does not see which other chains share its batches - which is what makes the
+    ladder-sharded multi-GPU run (sharding.tempering_run) independent of the number of ranks.
+    Reference: gibbs.py:627-656, parallel.py:190-281."""
+    import time
+
+    from inference_amd.mcmc import advance_ladders
+
+    n, d = 2048, 4
+    x, y, e = wl.synthetic_dataset(5, n, d)
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=wl.timing_theta(wl.SE, y, d))
+    gp.batch_independent_values(True)
+    steps, interval = 4, 2
+    together = [wl.cfg5_ladder(gp, k) for k in range(8)]
+    assert all(lad.batch_posterior is not None for lad in together)
+    t0 = time.perf_counter()
+    evals = advance_ladders(together, steps, swap_interval=interval)
+    dt = time.perf_counter() - t0
+    print(f"config 5 per-GPU shape: {evals} LML evaluations in {dt:.2f} s = {evals / dt:.0f} evals/s, "
+          f"{64 * steps / dt:.1f} chain steps/s")
+    assert evals >= 64 * steps * gp.n_hyperpars
+    alone = [wl.cfg5_ladder(gp, k) for k in range(8)]
+    for lad in alone:
+        lad.advance(steps, swap_interval=interval)
+    for a, b in zip(together, alone):
+        for ca, cb in zip(a.chains, b.chains):
+            assert np.array_equal(ca.get_sample(burn=0), cb.get_sample(burn=0))
+            assert np.array_equal(np.array(ca.probs), np.array(cb.probs))
+        assert np.array_equal(a.successful_swaps, b.successful_swaps)
+        assert np.array_equal(a.attempted_swaps, b.attempted_swaps)
+    # the chains moved and stayed inside the prior box
+    lo, hi = np.array(gp.hp_bounds).T
+    for lad in together:
+        for ch in lad.chains:
+            s = ch.get_sample(burn=0)
+            assert (s >= lo).all() and (s <= hi).all() and np.ptp(s, axis=0).min() > 0
+    # spot check of the log-probabilities against the oracle (tempered: prob = LML / T)
+    from oracle import gp_oracle as orc
+
+    ref = orc.OracleGp(x, y, e, kernel=orc.SE)
+    ch = together[3].chains[2]
+    check(ch.probs[-1] / ch.inv_temp, ref.marginal_likelihood(ch.get_last()), what="LML of a chain's last position")
+
+
+# ---------------------------------------------------------------------------------------
+# user-defined covariance functions through the plugin ABC (SURVEY.md section 8(b)): host builds the dense
+# matrices with the plugin's own methods, the device factorises / solves (gpmi_*_dense)
+# ---------------------------------------------------------------------------------------
+def test_plugin_kernel_through_the_abc_vs_reference(golden, gp_mod):
+    """A Matern-3/2 kernel written against `CovarianceFunction` only (workloads.Matern32Math): every public method of
+    GpRegressor, the seeded hyper-parameter search and an EI proposal (analytic gradient via gradient_terms) against
+    the reference running the same class (tests/golden/plugin.npz)."""
+    from inference_amd.gp.covariance import CovarianceFunction
+
+    class Matern32(wl.Matern32Math, CovarianceFunction):
+        pass
+
+    g = golden("plugin")
+    x, y, e, pts, thetas = wl.plugin_problem()
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=thetas[0], kernel=Matern32)
+    assert gp._generic and list(g["labels"]) == gp.hyperpar_labels
+    check(np.array(gp.hp_bounds, dtype=float), g["bounds"], 1e-12, "bounds")
+    check(gp.K_xx, g["K_xx"], 1e-14, "K_xx (host plugin)")
+    check(gp.L, g["L"], what="L")
+    check_each(gp.alpha, g["alpha"], what="alpha")
+    mu, sig = gp(pts)
+    check(mu, g["mu"], what="mu")
+    check(sig, g["sig"], what="sig")
+    pm, pc = gp.build_posterior(pts[:12])
+    check(pm, g["post_mu"], what="posterior mean")
+    check(pc, g["post_cov"], what="posterior covariance")
+    check(gp.build_posterior(pts[:12], mean_only=True), g["post_mu"], what="posterior mean only")
+    gm, gc = gp.gradient(pts[:12])
+    check(gm, g["grad_mu"], what="gradient mean")
+    check(gc, g["grad_cov"], what="gradient covariance")
+    sm, sv = gp.spatial_derivatives(pts[:12])
+    check(sm, g["sd_mu"], what="d mu / dx")
+    check(sv, g["sd_var"], what="d var / dx")
+    lm, ls = gp.loo_predictions()
+    check(lm, g["loo_mu"], what="loo mean")
+    check(ls, g["loo_sig"], what="loo sigma")
+    check([gp.marginal_likelihood(t) for t in thetas], g["lml"], what="lml")
+    check(gp.marginal_likelihood_batch(thetas), g["lml"], what="lml batch")
+    for t, v, gr in zip(thetas, g["lml2"], g["grad"]):
+        a, b = gp.marginal_likelihood_gradient(t)
+        check(a, v, what="lml (gradient call)")
+        check_each(b, gr, what="lml gradient")
+    check([gp.loo_likelihood(t) for t in thetas], g["loo"], what="loo likelihood")
+    for t, v, gr in zip(thetas, g["loo2"], g["loo_grad"]):
+        a, b = gp.loo_likelihood_gradient(t)
+        check(a, v, what="loo (gradient call)")
+        check_each(b, gr, what="loo gradient")
+    np.random.seed(17)
+    gps = gp_mod.GpRegressor(x, y, y_err=e, kernel=Matern32, n_starts=3)
+    v = gps.marginal_likelihood(gps.hyperpars)
+    assert abs(v - float(g["search_lml"])) <= 1e-8 * abs(float(g["search_lml"]))
+    bx, by, bounds = _bo_problem()
+    opt = gp_mod.GpOptimiser(bx, by, bounds=bounds, hyperpars=g["bo_theta"], kernel=Matern32)
+    np.random.seed(41)
+    prop = np.array(opt.propose_evaluation())
+    val = float(opt.acquisition.opt_func(prop))
+    assert abs(val - float(g["bo_value"])) <= 1e-8 * max(abs(float(g["bo_value"])), 1.0)
+    assert np.abs(prop - g["bo_proposal"]).max() < 1e-6
+    # a Cholesky failure on the dense path keeps the reference's conventions (regression.py:540-542, 241)
+    bad = thetas[0].copy()
+    bad[1] = 400.0
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert gp.marginal_likelihood(bad) == -1e50 and any("Cholesky" in str(k.message) for k in w)

@@ -131,3 +131,96 @@ def linv_thetas(name, kid, white_noise=False):
             th.append(np.log(0.05) + 0.3 * i)
         out.append(np.array(th))
     return out
+
+
+def cfg5_ladder(gp, k: int, n_temps: int = 8, t_max: float = 100.0):
+    """Ladder k of BASELINE config 5: `n_temps` GibbsChains at temperatures
+    10**linspace(0, log10(t_max), n_temps) over the hyper-parameters of `gp` (flat box prior = hp_bounds), posterior
+    = gp.marginal_likelihood, every random generator seeded from k so that a run does not depend on how the ladders
+    are grouped or sharded."""
+    import random
+
+    from numpy.random import default_rng
+
+    from inference_amd.mcmc import GibbsChain, ParallelTempering
+
+    start = np.array([0.5 * (a + b) for a, b in gp.hp_bounds])
+    start[0] = gp.y.mean()
+    widths = np.array([0.05 * (b - a) for a, b in gp.hp_bounds])
+    chains = []
+    for t_i, temp in enumerate(10.0 ** np.linspace(0.0, np.log10(t_max), n_temps)):
+        ch = GibbsChain(posterior=gp.marginal_likelihood, start=start, widths=widths, temperature=float(temp),
+                        display_progress=False)
+        for i, b in enumerate(gp.hp_bounds):
+            ch.set_boundaries(i, b)
+        ch.rng = default_rng(100_000 * k + 100 * t_i)
+        for i, par in enumerate(ch.params):
+            par.rng = default_rng(100_000 * k + 100 * t_i + 1 + i)
+        chains.append(ch)
+    pt = ParallelTempering(chains)
+    pt.rng = default_rng(7_000_000 + k)
+    pt.pair_choice = random.Random(9_000_000 + k).choice
+    return pt
+
+
+class Matern32Math:
+    """A covariance function that is NOT one of the library's device kernels: Matern-3/2 with one length-scale per
+    dimension, K(u, v) = a^2 (1 + sqrt3 r) exp(-sqrt3 r), r^2 = sum_k ((u_k - v_k) / l_k)^2, theta = [ln a, ln l_1..d],
+    written against the plugin contract only (covariance.py:8-44).  Mixed with the reference's CovarianceFunction it
+    generates tests/golden/plugin.npz, mixed with this package's it exercises the dense device entry points."""
+
+    def __init__(self, hyperpar_bounds=None):
+        self.bounds = hyperpar_bounds
+
+    def pass_spatial_data(self, x):
+        self.x = np.asarray(x, dtype=float)
+        d = self.x.shape[1]
+        self.n_params = d + 1
+        self.hyperpar_labels = ["Matern32 log-amplitude"] + [f"Matern32 log-scale {i}" for i in range(d)]
+        self.dx2 = (self.x[:, None, :] - self.x[None, :, :]) ** 2
+
+    def estimate_hyperpar_bounds(self, y):
+        s = np.log(np.std(y))
+        span = np.ptp(self.x, axis=0)
+        self.bounds = [(s - 4, s + 4)] + [(np.log(w) - 4, np.log(w) + 2) for w in span]
+
+    @staticmethod
+    def _k_of_r(a2, r):
+        return a2 * (1 + np.sqrt(3.0) * r) * np.exp(-np.sqrt(3.0) * r)
+
+    def __call__(self, u, v, theta):
+        a2, l = np.exp(2 * theta[0]), np.exp(theta[1:])
+        r = np.sqrt((((u[:, None, :] - v[None, :, :]) / l[None, None, :]) ** 2).sum(axis=2))
+        return self._k_of_r(a2, r)
+
+    def build_covariance(self, theta):
+        a2, l = np.exp(2 * theta[0]), np.exp(theta[1:])
+        r = np.sqrt((self.dx2 / l[None, None, :] ** 2).sum(axis=2))
+        return self._k_of_r(a2, r) + 1e-10 * a2 * np.eye(self.x.shape[0])
+
+    def covariance_and_gradients(self, theta):
+        a2, l = np.exp(2 * theta[0]), np.exp(theta[1:])
+        z = self.dx2 / l[None, None, :] ** 2
+        r = np.sqrt(z.sum(axis=2))
+        K = self._k_of_r(a2, r) + 1e-10 * a2 * np.eye(self.x.shape[0])
+        e = 3.0 * a2 * np.exp(-np.sqrt(3.0) * r)
+        return K, [2.0 * K] + [z[:, :, k] * e for k in range(l.size)]
+
+    def gradient_terms(self, v, x, theta):
+        a2, l = np.exp(2 * theta[0]), np.exp(theta[1:])
+        dx = x - v[None, :]
+        r = np.sqrt(((dx / l[None, :]) ** 2).sum(axis=1))
+        A = 3.0 * dx / (l[None, :] ** 2 * (1 + np.sqrt(3.0) * r)[:, None])
+        return A.T, 3.0 * a2 / l**2
+
+
+def plugin_problem():
+    n, d = 80, 2
+    rng = np.random.default_rng(8080)
+    x = rng.uniform(0, 2, (n, d))
+    y = np.sin(2 * x[:, 0]) * np.cos(1.5 * x[:, 1]) + 0.3 * x[:, 0] + 0.05 * rng.normal(size=n)
+    e = np.full(n, 0.05)
+    pts = rng.uniform(0, 2, (30, d))
+    base = np.array([y.mean(), np.log(y.std()), np.log(0.8), np.log(1.1)])
+    thetas = np.array([base + 0.15 * rng.standard_normal(4) for _ in range(3)])
+    return x, y, e, pts, thetas
