@@ -1,0 +1,125 @@
+"""
+Many L-BFGS-B minimisations advanced in lockstep, one batched objective evaluation per round.
+
+`GpOptimiser.multistart_bfgs` (reference: inference/gp/optimisation.py:202-223) starts one
+`scipy.optimize.fmin_l_bfgs_b` run per training point; each of its iterations evaluates the acquisition
+function and its gradient at ONE point, i.e. two M = 1 device calls (predict + spatial derivatives) that
+cost what M = 1000 costs.  Here every run is the same SciPy L-BFGS-B (the Fortran-derived `setulb` routine
+driven through its reverse-communication interface, exactly the loop of scipy.optimize._lbfgsb_py), but all
+runs that are waiting for an objective value are served by one batched call `fun_batch(X) -> (f, G)`.
+The iterates of a run are those of `fmin_l_bfgs_b` up to the last bits in which a batched and a single
+device evaluation of the same point may differ.
+
+The driver uses SciPy's private `_lbfgsb.setulb`; if that entry point is missing or its signature differs
+(other SciPy versions) the runs fall back to `fmin_l_bfgs_b` one after another on the same batched objective.
+"""
+import numpy as np
+from scipy.optimize import fmin_l_bfgs_b
+
+
+class _Run:
+    """Reverse-communication state of one L-BFGS-B run (scipy/optimize/_lbfgsb_py.py, _minimize_lbfgsb)."""
+
+    def __init__(self, x0, low, upp, nbd, m, maxls):
+        n = x0.size
+        self.x = np.array(np.clip(x0, low_or(-np.inf, low, nbd, 1), low_or(np.inf, upp, nbd, 3)), dtype=np.float64)
+        self.f = np.array(0.0, dtype=np.float64)
+        self.g = np.zeros(n, dtype=np.float64)
+        self.wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, np.float64)
+        self.iwa = np.zeros(3 * n, dtype=np.int32)
+        self.task = np.zeros(2, dtype=np.int32)
+        self.ln_task = np.zeros(2, dtype=np.int32)
+        self.lsave = np.zeros(4, dtype=np.int32)
+        self.isave = np.zeros(44, dtype=np.int32)
+        self.dsave = np.zeros(29, dtype=np.float64)
+        self.nfev = 0
+        self.nit = 0
+        self.done = False
+
+
+def low_or(inf, bound, nbd, one_sided):
+    """bound where the variable has that side bounded (nbd 2 = both, 1 = lower only, 3 = upper only), else +-inf."""
+    return np.where((nbd == 2) | (nbd == one_sided), bound, inf)
+
+
+def _encode_bounds(bounds, n):
+    nbd = np.zeros(n, np.int32)
+    low, upp = np.zeros(n), np.zeros(n)
+    for i, (lo, hi) in enumerate(bounds):
+        has_lo = lo is not None and np.isfinite(lo)
+        has_hi = hi is not None and np.isfinite(hi)
+        if has_lo:
+            low[i] = lo
+        if has_hi:
+            upp[i] = hi
+        nbd[i] = {(False, False): 0, (True, False): 1, (True, True): 2, (False, True): 3}[(has_lo, has_hi)]
+    return low, upp, nbd
+
+
+def lockstep_lbfgsb(fun_batch, starts, bounds, pgtol=1e-5, factr=1e7, m=10, maxfun=15000, maxiter=15000, maxls=20):
+    """Minimise from every row of `starts`; `fun_batch(X (B, n)) -> (f (B,), G (B, n))`.
+    Returns a list of `(x, f, info)` in the order of `starts`, `info` with the keys of fmin_l_bfgs_b's dict
+    ('warnflag', 'funcalls', 'nit', 'grad')."""
+    starts = np.atleast_2d(np.asarray(starts, dtype=float))
+    n = starts.shape[1]
+    try:
+        from scipy.optimize import _lbfgsb
+
+        setulb = _lbfgsb.setulb
+    except (ImportError, AttributeError):
+        setulb = None
+    if setulb is not None:
+        try:
+            return _drive(setulb, fun_batch, starts, bounds, n, pgtol, factr, m, maxfun, maxiter, maxls)
+        except TypeError:
+            pass  # another SciPy: different setulb signature
+
+    def single(x):
+        f, g = fun_batch(np.asarray(x, dtype=float)[None, :])
+        return float(f[0]), np.asarray(g[0], dtype=float)
+
+    out = []
+    for x0 in starts:
+        x, f, d = fmin_l_bfgs_b(single, x0, approx_grad=False, bounds=bounds, pgtol=pgtol, factr=factr, m=m,
+                                maxfun=maxfun, maxiter=maxiter, maxls=maxls)
+        out.append((x, float(f), d))
+    return out
+
+
+def _drive(setulb, fun_batch, starts, bounds, n, pgtol, factr, m, maxfun, maxiter, maxls):
+    low, upp, nbd = _encode_bounds(bounds, n)
+    runs = [_Run(x0, low, upp, nbd, m, maxls) for x0 in starts]
+    active = list(range(len(runs)))
+    while active:
+        waiting = []
+        for k in active:
+            r = runs[k]
+            while True:
+                setulb(m, r.x, low, upp, nbd, r.f, r.g, factr, pgtol, r.wa, r.iwa, r.task, r.lsave, r.isave, r.dsave,
+                       maxls, r.ln_task)
+                if r.task[0] == 3:  # wants f and g at the current x
+                    waiting.append(k)
+                    break
+                if r.task[0] == 1:  # new iteration
+                    r.nit += 1
+                    if r.nit >= maxiter:
+                        r.task[0], r.task[1] = 5, 504
+                    elif r.nfev > maxfun:
+                        r.task[0], r.task[1] = 5, 502
+                    continue
+                r.done = True
+                break
+        if waiting:
+            X = np.array([runs[k].x for k in waiting])
+            f, G = fun_batch(X)
+            for k, fk, gk in zip(waiting, np.asarray(f, dtype=float), np.asarray(G, dtype=float)):
+                r = runs[k]
+                r.f = np.array(float(fk), dtype=np.float64)
+                r.g = np.array(gk, dtype=np.float64).reshape(n)
+                r.nfev += 1
+        active = waiting
+    out = []
+    for r in runs:
+        warnflag = 0 if r.task[0] == 4 else (1 if (r.nfev > maxfun or r.nit >= maxiter) else 2)
+        out.append((r.x.copy(), float(r.f), {"grad": r.g.copy(), "funcalls": r.nfev, "nit": r.nit, "warnflag": warnflag}))
+    return out

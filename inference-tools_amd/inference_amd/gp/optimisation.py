@@ -123,7 +123,20 @@ class GpOptimiser:
         )
 
     def multistart_bfgs(self):
-        runs = [self.launch_bfgs(x0) for x0 in self.acquisition.starting_positions(self.bounds)]
+        """One L-BFGS-B run (pgtol 1e-10) per starting position, best result wins (optimisation.py:202-223).  The
+        reference runs them one after another (or over a multiprocessing.Pool); here all runs advance in lockstep
+        (`_lockstep.lockstep_lbfgsb`): every round evaluates the acquisition function and its gradient for all
+        runs still iterating in ONE batched device call, so a proposal at N = 4096 training points costs tens of
+        device calls instead of ~10^5 single-point ones.  Acquisition objects without a batched gradient keep
+        the serial path."""
+        starts = self.acquisition.starting_positions(self.bounds)
+        batch = getattr(self.acquisition, "opt_func_gradient_batch", None)
+        if batch is None:
+            runs = [self.launch_bfgs(x0) for x0 in starts]
+        else:
+            from inference_amd.gp._lockstep import lockstep_lbfgsb
+
+            runs = lockstep_lbfgsb(batch, np.array(starts), self.bounds, pgtol=1e-10)
         where, lowest, _ = min(runs, key=lambda run: float(run[1]))
         return where, float(lowest)
 
