@@ -473,6 +473,7 @@ int gpmi_destroy(gpmi_ctx* c) {
   }
   if (c->stamp_pool) (void)hipFree(c->stamp_pool);
   if (c->dev_masked) (void)hipStreamDestroy(c->dev_masked);
+  if (c->flow_gate) (void)hipEventDestroy(c->flow_gate);
   if (c->trsm_panel) (void)hipFree(c->trsm_panel);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->t0) (void)hipEventDestroy(c->t0);

@@ -27,26 +27,40 @@ __device__ inline double wave_sum(double v) {
 // vector doubles as the flag array: it is pre-filled with a NaN payload no computation produces and a
 // consumer polls the elements it needs (agent-scope loads, which bypass the per-XCD L2; the
 // producer's agent-scope stores write through), so one memory round trip per step is all that is
-// left on the critical path.  Workgroup k only ever waits for workgroups with a lower index, which
-// the dispatcher starts first: no deadlock whatever the number of resident workgroups.  The
-// summation order is fixed, so results are bit-reproducible.
+// left on the critical path.  The summation order is fixed, so results are bit-reproducible.
+//
+// Progress.  Workgroup k only ever waits for workgroups with a lower index of the SAME launch.  HIP promises
+// no dispatch order, so the argument is residency, not order: a sweep never has more workgroups in flight
+// than the chip holds resident at once (FLOW_THREADS = 512 threads, ~67 KiB of LDS: two per CU, 512 on the
+// chip), hence every workgroup of the launch - the producers a poller waits for included - is resident or
+// already finished, whatever order the dispatcher (one per XCD) picked.  The host side enforces it:
+// sweeps_in_flight() below serialises sweeps of different lanes once their workgroups would not all fit
+// (a batched sweep carries its whole batch in one launch, in-order per XCD queue, lowest unfinished index
+// always dispatchable).  Should a poll still time out (a bug, not a wait) the workgroup gives up for good:
+// every later poll of that lane returns at once, it publishes what it has, and its consumers - which then
+// read a non-sentinel value - do the same, so the launch drains in O(1) polls per workgroup and the host
+// reports GPMI_ERR_INTERNAL instead of a hung GPU.
 constexpr unsigned long long FLOW_SENTINEL = 0xFFF8DEADBEEF0000ull;
 constexpr int FLOW_THREADS = 512;
-constexpr int FLOW_SPIN_LIMIT = 1 << 24;  // > 1 s of polling: a bug, not a wait; bail out instead of hanging the GPU
+constexpr int FLOW_SPIN_LIMIT = 1 << 22;  // ~1 s of s_sleep + L2-bypassing load per lane
 
-__device__ inline double flow_poll(const double* p, int* err) {
+// `dead` (per lane, starts false): set once a poll has timed out or another workgroup reported a failure
+__device__ inline double flow_poll(const double* p, int* err, bool& dead) {
   const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
   unsigned long long bits = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int spins = 0;
-  while (bits == FLOW_SENTINEL) {
+  while (bits == FLOW_SENTINEL && !dead) {
     __builtin_amdgcn_s_sleep(1);
     bits = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (++spins > FLOW_SPIN_LIMIT) {
+    ++spins;
+    // every 4096 spins: has another workgroup of this sweep already given up?
+    if ((spins & 4095) == 0 && err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) dead = true;
+    if (spins > FLOW_SPIN_LIMIT) {
       if (err) atomicCAS(err, 0, GPMI_ERR_INTERNAL);
-      return 0.0;
+      dead = true;
     }
   }
-  return __longlong_as_double((long long)bits);
+  return (bits == FLOW_SENTINEL) ? 0.0 : __longlong_as_double((long long)bits);
 }
 
 __device__ inline void flow_publish(double* p, double v) {
@@ -100,14 +114,15 @@ __global__ __launch_bounds__(FLOW_THREADS) void trsv_fwd_flow_kernel(
     // half B is in flight, then half A of block j + 1 is requested before half B is consumed
     const double* base = L + (int64_t)(k * NB + wave * 16) * ld + 2 * lane;
     d2_t ha[8], hb[8];
+    bool dead = false;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ha[i] = *reinterpret_cast<const d2_t*>(base + (int64_t)i * ld);
     for (int j = 0; j < nmain; ++j) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         hb[i] = *reinterpret_cast<const d2_t*>(base + (int64_t)(8 + i) * ld + (int64_t)j * NB);
-      const double v0 = flow_poll(v + (int64_t)j * NB + 2 * lane, err);
-      const double v1 = flow_poll(v + (int64_t)j * NB + 2 * lane + 1, err);
+      const double v0 = flow_poll(v + (int64_t)j * NB + 2 * lane, err, dead);
+      const double v1 = flow_poll(v + (int64_t)j * NB + 2 * lane + 1, err, dead);
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] = fma(ha[i][0], v0, fma(ha[i][1], v1, acc[i]));
       if (j + 1 < nmain) {
@@ -169,6 +184,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void trsv_bwd_flow_kernel(
     // rows wave + 8 i of a block: i = 0..7 in buffer ha, i = 8..15 in hb (alternating as in the forward sweep)
     const double* base = L + (int64_t)wave * ld + (int64_t)k * NB + 2 * lane;
     d2_t ha[8], hb[8];
+    bool dead = false;
     {
       const double* pj = base + (int64_t)(nt - 1) * NB * ld;
 #pragma unroll
@@ -183,7 +199,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void trsv_bwd_flow_kernel(
       }
       // a_j into LDS (double-buffered: a slow wave may still read the previous block's values)
       double* aj = ain[t & 1];
-      if (tid < NB) aj[tid] = flow_poll(a + (int64_t)j * NB + tid, err);
+      if (tid < NB) aj[tid] = flow_poll(a + (int64_t)j * NB + tid, err, dead);
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -344,23 +360,51 @@ __global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restric
 
 }  // namespace
 
+// Serialise sweeps of different streams so that their workgroups are always all resident together (see the
+// progress argument above): the chip holds 2 x ncu flow workgroups; a sweep of nt >= FLOW_GATE_MIN workgroups
+// (N > 4096: the sizes that run one lane per evaluation, gpmi_lml_batch) queues behind the previous such sweep of
+// the context through one event, whichever lane issues it, so at most one of them (<= 2 x ncu workgroups for
+// N <= 65536) is in flight beside any number of small ones.  They are HBM-bound and sub-millisecond: nothing is
+// lost by not overlapping them.
+constexpr int64_t FLOW_GATE_MIN = 32;
+static void flow_gate_enter(gpmi_ctx* c, hipStream_t s, int64_t workgroups) {
+  if (workgroups <= FLOW_GATE_MIN) return;
+  if (!c->flow_gate) {
+    if (hipEventCreateWithFlags(&c->flow_gate, hipEventDisableTiming) != hipSuccess) {
+      c->flow_gate = nullptr;
+      return;
+    }
+  } else if (c->flow_gate_stream != s) {
+    (void)hipStreamWaitEvent(s, c->flow_gate, 0);
+  }
+}
+static void flow_gate_leave(gpmi_ctx* c, hipStream_t s, int64_t workgroups) {
+  if (workgroups <= FLOW_GATE_MIN || !c->flow_gate) return;
+  (void)hipEventRecord(c->flow_gate, s);
+  c->flow_gate_stream = s;
+}
+
 void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
                   const double* invD, const double* r, double* out, int* err, const BatchShape& bs) {
   const int nt = (int)(np / NB);
+  flow_gate_enter(c, s, (int64_t)nt);
   ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)np * np, 4.0 * np * np);
   hipLaunchKernelGGL(flow_fill_kernel, dim3((unsigned)((np + 255) / 256), 1, (unsigned)bs.count), dim3(256), 0, s,
                      out, np, bs.sVec);
   hipLaunchKernelGGL(trsv_fwd_flow_kernel, dim3((unsigned)nt, 1, (unsigned)bs.count), dim3(FLOW_THREADS), 0, s, L,
                      ld, invD, r, out, err, bs.sMat, bs.sInv, bs.sVec);
+  flow_gate_leave(c, s, (int64_t)nt);
 }
 
 void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
                    const double* invD, const double* r, double* out, int* err) {
   const int nt = (int)(np / NB);
+  flow_gate_enter(c, s, (int64_t)nt);
   ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)np * np, 4.0 * np * np);
   hipLaunchKernelGGL(flow_fill_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, out, np, (int64_t)0);
   hipLaunchKernelGGL(trsv_bwd_flow_kernel, dim3((unsigned)nt), dim3(FLOW_THREADS), 0, s, L, ld, invD, r, out, err,
                      nt);
+  flow_gate_leave(c, s, (int64_t)nt);
 }
 
 void build_inv2(hipStream_t s, const double* L, int64_t np, int64_t ld, const double* invD, double* inv2,
