@@ -17,9 +17,20 @@ directory in /tmp (inference_amd.sharding.FileRendezvous): torch itself is NOT i
 importing it loads torch's bundled HIP / HSA runtime beside the system ROCm 7.2 one, and RCCL then
 binds to the uninitialised copy.
 
+`python bench.py --gpus N` without a launcher starts its own N ranks (launch_ranks): the parent never touches
+the GPU, it spawns N fresh interpreters with RANK / LOCAL_RANK / WORLD_SIZE set and relays rank 0's line.
+
 Extra objects on the JSON line:
-  roofline      the potrf trailing SYRK/GEMM update (fp64 MFMA bound): algorithmic FLOP per launch
-                divided by the HIP-event duration of each launch on its own stream (gpmi_profile_*)
+  roofline      the potrf trailing SYRK/GEMM update (fp64 MFMA bound), the dominant kernel: algorithmic FLOP of
+                every launch divided by its duration, measured live inside the timed region by in-kernel
+                s_memrealtime stamps (first workgroups' start -> last workgroup's end behind its epilogue stores;
+                HIP events on the look-ahead streams would perturb the overlap).  `all_trailing` adds the launches
+                that run other tile shapes (64 x 64 remainders, launches below 384 tiles); `clock_ghz` is the shader
+                clock held during those launches (s_memtime / s_memrealtime): the update is bound by the chip's
+                power budget, `frac_at_clock` is the fraction of the MFMA peak AT THAT CLOCK.  `traffic` is HBM
+                bytes per launch from the PMC passes of the same command committed under profiles/ (separate
+                rocprofv3 --pmc runs cannot be part of this run); `kernels` lists the other kernels of a step
+                (K-build, the two triangular sweeps, the predict TRSM) from an extra, un-timed pass with events.
   cpu_baseline  the CPU oracle (NumPy/SciPy restatement of the reference, kind "port") timed on the
                 host cores on a bounded sample of the same workload (rank 0, N=1 only)
 """
@@ -108,16 +119,53 @@ def cpu_baseline(n_cpu, d, m_cpu, runs=3):
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
-    (profiles/r01_pmc.json, written by tools/pmc_bench.sh + tools/make_profiles.py: rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced
-    reads on gfx950); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["kernels"]["update128"]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    """(HBM bytes per launch of the dominant kernel, file it comes from): the committed PMC passes of this same
+    command (profiles/rNN_pmc.json, written by tools/pmc_bench.sh + tools/make_profiles.py: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
+    coalesced reads on gfx950); (None, None) if absent."""
+    for name in ("r02_pmc.json", "r01_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["kernels"]["update128"]["hbm_bytes_per_launch"], "profiles/" + name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable with a plain copy)
+
+
+def kernel_rows(eng, step, _lib, N, M):
+    """Per-kernel roofline rows of the rest of a step from an extra pass with HIP events around the launches (it
+    perturbs the overlap of the factorisation, so it runs AFTER the timed region and is not part of `value`)."""
+    eng.profile_enable(True)
+    eng.profile_reset()
+    for _ in range(2):
+        step()
+    eng.sync()
+    kb, sv, ts, pn = (eng.profile_read(k) for k in (_lib.PROF_KBUILD, _lib.PROF_SOLVE, _lib.PROF_TRSM, _lib.PROF_PANEL))
+    eng.profile_enable(0)
+    rows = []
+
+    def hbm(name, p, what):
+        if p["ms"] > 0:
+            a = p["bytes"] / (p["ms"] * 1e-3) / 1e9
+            rows.append({"kernel": name, "bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": a / PEAK_HBM_GBS, "launches": p["launches"], "avg_ms": p["ms"] / p["launches"], "bytes": what})
+
+    hbm("kbuild_kernel<true> (K-build, lower tiles) + kbuild_kernel<false> (cross-covariance of the query points)", kb,
+        "4 N^2 B per fit (lower tiles written once) + 8 M N B per predict")
+    hbm("trsv_fwd_flow_kernel + trsv_bwd_flow_kernel (alpha = L^-T L^-1 (y - mu))", sv, "4 N^2 B per sweep (L read once)")
+    if ts["ms"] > 0:
+        a = ts["flops"] / (ts["ms"] * 1e-3) / 1e12
+        rows.append({"kernel": "trsm_rows_forward (predict: M right-hand sides, gemm_nt_kernel<0, *>)", "bound": "mfma",
+                     "achieved": a, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": a / PEAK_FP64_MFMA_TFLOPS,
+                     "launches": ts["launches"], "avg_ms": ts["ms"] / ts["launches"], "flops": "M N^2 per predict"})
+    if pn["ms"] > 0:
+        rows.append({"kernel": "panel chain (potrf_diag_kernel + panel TRSM + inner K=128 updates; 32 CUs, hidden behind the "
+                     "trailing update while >= 44 tile rows remain)", "bound": "latency", "launches": pn["launches"],
+                     "total_ms_per_step": pn["ms"] / 2})
+    return rows
 
 
 def launch_ranks(n_ranks):
@@ -242,6 +290,8 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
     if os.environ.get("BENCH_STEP_TIMES") and rank == 0:  # debugging aid: host-side completion time of each step
         print("step ms:", [round((b - a) * 1e3, 2) for a, b in zip([t0] + marks[:-1], marks)], file=sys.stderr)
     prof = eng.profile_read(_lib.PROF_SYRK)
+    prof_rest = eng.profile_read(_lib.PROF_SYRK_REST)
+    clock = eng.profile_clock()
     eng.profile_enable(0)
 
     if world > 1:
@@ -252,6 +302,10 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
 
     if rank == 0:
         ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
+        all_ms, all_fl = prof["ms"] + prof_rest["ms"], prof["flops"] + prof_rest["flops"]
+        ach_all = all_fl / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0
+        peak_at_clock = PEAK_FP64_MFMA_TFLOPS * clock / 2.4 if clock > 0 else None
+        traffic, traffic_src = pmc_traffic()
         line = {
             "metric": f"GpRegressor fit+predict wall-time and GFLOP/s at N={N}, d={d}; % fp64 MFMA peak",
             "value": value,
@@ -273,19 +327,33 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
             },
             "roofline": {
                 "kernel": "gemm_nt_kernel<1, 0, 0, 128, 128> = <TILES_LOWER, OP_SUB, NT, 128x128> (potrf trailing SYRK update, K=512; the full rounds of every launch with >= 384 tiles)",
-                "timing": "in-kernel s_memrealtime stamps (first workgroups' start / last workgroup's end of each launch)",
+                "timing": "in-kernel s_memrealtime stamps per launch: first workgroups' start -> last workgroup's end behind its epilogue stores",
                 "cu_mask": "launches of the look-ahead regime run on 224 of 256 CUs (the other 32 factor the next panel)",
                 "bound": "mfma",
                 "achieved": ach,
                 "peak": PEAK_FP64_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": ach / PEAK_FP64_MFMA_TFLOPS,
-                "traffic": pmc_traffic(),
+                "traffic": traffic,
+                "traffic_source": f"{traffic_src}: separate rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run" if traffic_src else None,
                 "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
                 "flop_per_launch_avg": prof["flops"] / max(prof["launches"], 1),
+                "clock_ghz": clock,
+                "peak_at_clock": peak_at_clock,
+                "frac_at_clock": (ach / peak_at_clock) if peak_at_clock else None,
+                "all_trailing": {
+                    "what": "every trailing-update launch of the factorisation: the 128x128-tile kernel above plus the 64x64-tile remainders and the launches below 384 tiles (gemm_nt_kernel<1, 0, 0, 64, 64>)",
+                    "achieved": ach_all,
+                    "frac": ach_all / PEAK_FP64_MFMA_TFLOPS,
+                    "launches": prof["launches"] + prof_rest["launches"],
+                    "ms_per_step": all_ms / max(args.steps, 1),
+                    "flop_per_step": all_fl / max(args.steps, 1),
+                },
             },
         }
+        if world == 1:
+            line["roofline"]["kernels"] = kernel_rows(eng, step, _lib, N, M)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(4096, d, 256)  # ~10-15 s of host work in all
         print(json.dumps(line), flush=True)

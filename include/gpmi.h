@@ -110,6 +110,9 @@ int gpmi_set_streams(gpmi_ctx* ctx, int n_streams);
  *       (GibbsChain retries make the batches ragged, reference gibbs.py:635-648) need for trajectories that are
  *       bit-identical however the chains are grouped.  0 (default): a single evaluation uses the lane path. */
 #define GPMI_OPT_LOCKSTEP_ALWAYS 1
+/*   GPMI_OPT_RESERVE_POINTS   r >= 0, read by the NEXT gpmi_set_data: room for r more training points in the padded
+ *       device matrices (identity in the padding: the factor is unaffected), to be filled by gpmi_append_point */
+#define GPMI_OPT_RESERVE_POINTS 2
 int gpmi_set_option(gpmi_ctx* ctx, int option, int value);
 
 /* Replaces GpRegressor.marginal_likelihood_gradient (regression.py:544-567):
@@ -252,6 +255,18 @@ int gpmi_comm_init(gpmi_ctx* ctx, int rank, int world, const char* id_128);
 int gpmi_comm_allgather(gpmi_ctx* ctx, const double* send_host, double* recv_host, int64_t count);
 int gpmi_comm_destroy(gpmi_ctx* ctx);
 
+/* Append ONE training point to the fitted model at unchanged hyper-parameters in O(n^2): the new row of the Cholesky
+ * factor is l = L^-1 k(X, x_new), l_nn = sqrt(k_nn - l.l) (one triangular sweep), alpha is re-solved (two sweeps).
+ * The reference has no counterpart: GpOptimiser.add_evaluation re-fits from scratch (optimisation.py:177-186,
+ * O(n^3) per added point even when the hyper-parameters are kept).  Needs a fit by gpmi_fit (SE / RQ, diagonal
+ * data errors) and free capacity (GPMI_OPT_RESERVE_POINTS).
+ *   x_new_host : d values    mu_host : n + 1 prior means (the old points' first)    alpha_host : n + 1 out
+ *   info : 0, or n + 1 if the enlarged matrix is not positive definite (the model is then left unchanged) */
+int gpmi_append_point(gpmi_ctx* ctx, const double* x_new_host, double y_new, double noise_var_new,
+                      const double* mu_host, double* alpha_host, double* logdet_host, int* info);
+/* points the handle has room for (n + free capacity) */
+int gpmi_capacity(gpmi_ctx* ctx, int64_t* capacity);
+
 /* ---- dense entry points: covariance functions that only implement the plugin ABC -------------------------
  * Reference: CovarianceFunction (inference/gp/covariance.py:8-44) is an open plugin contract and GpRegressor
  * (regression.py:134-155) accepts any object implementing it.  For a kernel the library has no device code for, the
@@ -285,12 +300,16 @@ int gpmi_solve_rows(gpmi_ctx* ctx, const double* Q_host, int64_t m, double* X_ho
  * HIP-event timing on the handle's own stream (torch.cuda.Event would not see it). */
 int gpmi_timer_start(gpmi_ctx* ctx);
 int gpmi_timer_stop(gpmi_ctx* ctx, float* ms);
-/* per-kernel-class accounting: when enabled every launch of the class is bracketed by events */
+/* per-kernel-class accounting: when enabled every launch of the class is bracketed by events; the two
+ * trailing-update classes (SYRK, SYRK_REST) are timed by in-kernel stamps instead and cost nothing */
 #define GPMI_PROF_KBUILD 0  /* covariance build            (HBM-write bound) */
 #define GPMI_PROF_SYRK 1    /* potrf trailing SYRK/GEMM    (fp64 MFMA bound) */
 #define GPMI_PROF_PANEL 2   /* potrf diagonal block + panel TRSM (latency bound) */
-#define GPMI_PROF_SOLVE 3   /* triangular solves / reductions */
-#define GPMI_PROF_NCLASS 4
+#define GPMI_PROF_SOLVE 3   /* single right-hand side triangular sweeps (HBM-read bound) */
+#define GPMI_PROF_SYRK_REST 4 /* trailing-update launches that do not run the 128 x 128-tile kernel: the 64 x 64-tile
+                                 remainder of a split launch and the launches with fewer than 384 tiles */
+#define GPMI_PROF_TRSM 5    /* many right-hand side solves: predict, posterior, L^-T (fp64 MFMA bound) */
+#define GPMI_PROF_NCLASS 6
 /* on = 0: off; 1: every class; otherwise a class bitmask shifted left by one (2 << klass) */
 int gpmi_profile_enable(gpmi_ctx* ctx, int on);
 /* accumulated since the last reset: launches, total ms, algorithmic flops and bytes */

@@ -394,17 +394,18 @@ __global__ void stamp_init_kernel(unsigned long long* pool, int slots) {
 }
 }  // namespace
 
-unsigned long long* prof_stamp_slot(gpmi_ctx* c, double flops, double bytes) {
+unsigned long long* prof_stamp_slot(gpmi_ctx* c, double flops, double bytes, int klass) {
   if (!((c->prof_mask >> GPMI_PROF_SYRK) & 1) || !c->stamp_pool) return nullptr;
   if ((int)c->stamp_flops.size() >= GPMI_STAMP_SLOTS) return nullptr;
   c->stamp_flops.push_back(flops);
   c->stamp_bytes.push_back(bytes);
+  c->stamp_class.push_back(klass);
   return c->stamp_pool + (size_t)GPMI_STAMP_WORDS * (c->stamp_flops.size() - 1);
 }
 
 ProfScope::ProfScope(gpmi_ctx* ctx, hipStream_t st, int klass, double flops, double bytes)
     : c(ctx), s(st), slot(nullptr) {
-  if (!((c->prof_mask >> klass) & 1) || klass == GPMI_PROF_SYRK) return;
+  if (!((c->prof_mask >> klass) & 1) || klass == GPMI_PROF_SYRK || klass == GPMI_PROF_SYRK_REST) return;
   if (c->prof_used == c->prof_slots.size()) {
     ProfSlot ns{};
     if (hipEventCreate(&ns.e0) != hipSuccess || hipEventCreate(&ns.e1) != hipSuccess) return;
@@ -506,7 +507,7 @@ int gpmi_set_data(gpmi_ctx* c, const double* x, const double* y, const double* n
   free_data(c);
   c->n = n;
   c->d = d;
-  c->np = round_up(n, GPMI_NB);
+  c->np = round_up(n + c->reserve, GPMI_NB);
   c->ld = c->np + 32;  // keep rows 256-byte aligned but off a power-of-two pitch
   HIPCHK(c, hipMalloc(&c->x, sizeof(double) * c->np * d));
   HIPCHK(c, hipMalloc(&c->y, sizeof(double) * c->np));
@@ -540,8 +541,12 @@ int gpmi_set_streams(gpmi_ctx* c, int n_streams) {
 
 int gpmi_set_option(gpmi_ctx* c, int option, int value) {
   if (!c) return GPMI_ERR_ARG;
-  ARGCHK(c, option == GPMI_OPT_LOCKSTEP_ALWAYS, "unknown option");
-  c->lockstep_always = value != 0;
+  ARGCHK(c, option == GPMI_OPT_LOCKSTEP_ALWAYS || option == GPMI_OPT_RESERVE_POINTS, "unknown option");
+  if (option == GPMI_OPT_LOCKSTEP_ALWAYS) c->lockstep_always = value != 0;
+  if (option == GPMI_OPT_RESERVE_POINTS) {
+    ARGCHK(c, value >= 0, "reserve must be >= 0");
+    c->reserve = value;
+  }
   return GPMI_OK;
 }
 
@@ -1111,7 +1116,7 @@ static int dev_stream(gpmi_ctx* c, hipStream_t* s) {
 
 int gpmi_profile_enable(gpmi_ctx* c, int on) {
   if (!c) return GPMI_ERR_ARG;
-  c->prof_mask = (on == 1) ? 0xF : (unsigned)on >> 1;
+  c->prof_mask = (on == 1) ? ((1u << GPMI_PROF_NCLASS) - 1u) : (unsigned)on >> 1;
   if (((c->prof_mask >> GPMI_PROF_SYRK) & 1) && !c->stamp_pool) {
     if (int rc = set_device(c)) return rc;
     HIPCHK(c, hipMalloc(&c->stamp_pool, sizeof(unsigned long long) * GPMI_STAMP_WORDS * GPMI_STAMP_SLOTS));
@@ -1160,16 +1165,18 @@ static int profile_collect(gpmi_ctx* c) {
         c->prof_clock_cycles += (double)(w[16 + j] >> 32);
         c->prof_clock_ticks += (double)(w[16 + j] & 0xffffffffull);
       }
-      c->prof_ms[GPMI_PROF_SYRK] += (double)(t1 - t0) * 1e-5;  // 10 ns ticks -> ms
-      c->prof_flops[GPMI_PROF_SYRK] += c->stamp_flops[i];
-      c->prof_bytes[GPMI_PROF_SYRK] += c->stamp_bytes[i];
-      c->prof_launches[GPMI_PROF_SYRK] += 1;
+      const int kl = c->stamp_class[i];
+      c->prof_ms[kl] += (double)(t1 - t0) * 1e-5;  // 10 ns ticks -> ms
+      c->prof_flops[kl] += c->stamp_flops[i];
+      c->prof_bytes[kl] += c->stamp_bytes[i];
+      c->prof_launches[kl] += 1;
     }
     hipLaunchKernelGGL(stamp_init_kernel, dim3(GPMI_STAMP_SLOTS / 256), dim3(256), 0, s0, c->stamp_pool,
                        GPMI_STAMP_SLOTS);
     HIPCHK(c, hipStreamSynchronize(s0));
     c->stamp_flops.clear();
     c->stamp_bytes.clear();
+    c->stamp_class.clear();
   }
   return GPMI_OK;
 }
@@ -1853,6 +1860,111 @@ int gpmi_linv_posterior(gpmi_ctx* c, int kernel, const double* theta, int n_thet
   for (int64_t i = 0; i < c->n; ++i) mean[i] += mu[i];
   INFOCHK(c, L.h_info[0]);
   if (info) *info = L.h_info[0];
+  return GPMI_OK;
+}
+
+}  // extern "C"
+
+// ---- append one training point at fixed hyper-parameters (O(n^2)) ------------------------------------------------
+namespace {
+
+// row n of L <- [l_0 .. l_{n-1}, sqrt(knn - l.l)]; red[0] = the new pivot (<= 0: not positive definite, nothing written)
+__global__ __launch_bounds__(1024) void append_row_kernel(double* __restrict__ L, int64_t ld, int64_t n,
+                                                          const double* __restrict__ l, double knn,
+                                                          double* __restrict__ red) {
+  __shared__ double part[16];
+  __shared__ double pivot;
+  double s = 0.0;
+  for (int64_t j = threadIdx.x; j < n; j += 1024) s = fma(l[j], l[j], s);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += part[w];
+    pivot = knn - t;
+    red[0] = pivot;
+  }
+  __syncthreads();
+  if (!(pivot > 0.0)) return;
+  for (int64_t j = threadIdx.x; j < n; j += 1024) L[n * ld + j] = l[j];
+  if (threadIdx.x == 0) L[n * ld + n] = sqrt(pivot);
+}
+
+// inverse of the 128 x 128 diagonal block that holds row n: only its row i = n - r0 changes (the rows below are
+// still identity rows): invD[i][t] = (delta_it - sum_{c<i} T[i][c] invD[c][t]) / T[i][i]
+__global__ void append_invd_kernel(const double* __restrict__ L, int64_t ld, int64_t n, double* __restrict__ invD,
+                                   const double* __restrict__ red) {
+  if (!(red[0] > 0.0)) return;
+  const int64_t r0 = n / GPMI_NB * GPMI_NB;
+  const int i = (int)(n - r0), t = threadIdx.x;
+  double* D = invD + (n / GPMI_NB) * GPMI_NB * GPMI_NB;
+  double acc = (t == i) ? 1.0 : 0.0;
+  for (int cc = 0; cc < i; ++cc) acc = fma(-L[n * ld + r0 + cc], D[cc * GPMI_NB + t], acc);
+  D[i * GPMI_NB + t] = acc / L[n * ld + n];
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpmi_capacity(gpmi_ctx* c, int64_t* capacity) {
+  if (!c || !capacity) return GPMI_ERR_ARG;
+  *capacity = c->np;
+  return GPMI_OK;
+}
+
+int gpmi_append_point(gpmi_ctx* c, const double* x_new, double y_new, double noise_var_new, const double* mu,
+                      double* alpha_out, double* logdet_out, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->fitted && c->fit_params.kernel >= 0 && c->mix_nk == 0, "gpmi_append_point needs a fit by gpmi_fit (SE / RQ)");
+  ARGCHK(c, !c->ycov, "gpmi_append_point: diagonal data errors only");
+  ARGCHK(c, x_new && mu, "x_new / mu is NULL");
+  ARGCHK(c, c->n < c->np, "no capacity left: set GPMI_OPT_RESERVE_POINTS before gpmi_set_data");
+  if (int rc = set_device(c)) return rc;
+  Lane& L = c->lanes[0];
+  hipStream_t s = L.stream;
+  const int64_t n = c->n;
+  const KParams p = c->fit_params;
+  if (int rc = ensure_query_ws(c, GPMI_NB)) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->x + n * c->d, x_new, sizeof(double) * c->d, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->pts, x_new, sizeof(double) * c->d, hipMemcpyHostToDevice, s));
+  // k = K(x_new, X) against the n points present (zeros beyond), then l = L^-1 k (rows >= n of L are identity rows)
+  launch_kbuild_cross(s, p, c->pts, 1, GPMI_NB, c->x, n, c->np, c->Q, c->ld);
+  double* lvec = L.vec + 2 * c->np;
+  HIPCHK(c, hipMemsetAsync(L.info, 0, sizeof(int), s));
+  trsv_forward(c, s, L.A, c->np, c->ld, L.invD, c->Q, lvec, L.info);
+  // K_nn = a^2 (1 + 1e-12) + WhiteNoise + data variance (covariance.py:254-255, regression.py:239)
+  const double knn = p.a2 * (1.0 + 1e-12) + p.extra_diag + noise_var_new;
+  hipLaunchKernelGGL(append_row_kernel, dim3(1), dim3(1024), 0, s, L.A, c->ld, n, lvec, knn, L.red + 4);
+  hipLaunchKernelGGL(append_invd_kernel, dim3(1), dim3(GPMI_NB), 0, s, L.A, c->ld, n, L.invD, L.red + 4);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(L.h_red + 4, L.red + 4, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  if (!(L.h_red[4] > 0.0)) {
+    if (info) *info = (int)(n + 1);
+    return GPMI_OK;  // nothing was written: the fitted model is unchanged
+  }
+  // the point is in: data vectors, then alpha = L^-T L^-1 (y - mu) and the log-determinant as in gpmi_fit
+  HIPCHK(c, hipMemcpyAsync(c->y + n, &y_new, sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->noise + n, &noise_var_new, sizeof(double), hipMemcpyHostToDevice, s));
+  c->n = n + 1;
+  L.inv2_valid = false;
+  double* mu_dev = L.vec + 3 * c->np;
+  HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
+  launch_residual(s, c->y, mu_dev, 0.0, L.vec + 2 * c->np, c->n, c->np);
+  trsv_forward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, L.vec, L.info);
+  launch_lml_reduce(s, L.vec, L.A, c->ld, c->np, L.red);
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, c->alpha, L.info);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (alpha_out) HIPCHK(c, hipMemcpyAsync(alpha_out, c->alpha, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  INFOCHK(c, L.h_info[0]);
+  if (logdet_out) *logdet_out = L.h_red[1];
+  if (info) *info = 0;
   return GPMI_OK;
 }
 

@@ -132,11 +132,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   // atomicMin / atomicMax on one address from ~8000 workgroups cost 1 ms per step, and an atomic issued
   // at the start sat in front of the first operand loads in the wave's in-order memory queue.)
   const bool stamp_first = g.stamp && tid == 0 && blockIdx.x < 8 && blockIdx.z == 0;
+  if (stamp_first) g.stamp[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+  // eight workgroups from the middle of the launch (the chip fully loaded, the clock settled) time their own
+  // lifetime in shader cycles and in wall time: the clock the launch runs at
+  const unsigned mid = gridDim.x >> 1;
+  const bool stamp_clock = g.stamp && tid == 0 && blockIdx.x >= mid && blockIdx.x < mid + 8 && blockIdx.z == 0;
   unsigned long long c_start = 0, r_start = 0;
-  if (stamp_first) {
+  if (stamp_clock) {
     r_start = __builtin_amdgcn_s_memrealtime();
     c_start = __builtin_amdgcn_s_memtime();
-    g.stamp[blockIdx.x] = r_start;
   }
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -248,12 +252,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   for (int kt = 1; kt < nk; ++kt) kstep(kt);
 
   // End stamp (only the workgroups that can be the launch's last: dispatch is in order and tiles are uniform,
-  // so the last one to finish is among the last two rounds of 512).  s_memrealtime takes ~1.5 us to return:
-  // it is requested before the epilogue so that the stores hide it, which dates the stamp at the end of the
-  // MFMA loop; the launch's duration is under-stated by the epilogue of one tile (~2 us, 0.25 % at 800 us).
+  // so the last one to finish is among the last two rounds of 512), taken behind the epilogue stores.
   const bool stamp_end = g.stamp && tid == 0 && blockIdx.x + 1024 >= gridDim.x;
-  unsigned long long t_end = 0;
-  if (stamp_end) t_end = __builtin_amdgcn_s_memrealtime();
 
   // epilogue: stores only; each instruction covers 4 rows x 128 contiguous bytes
 #pragma unroll
@@ -262,12 +262,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) GPMI_C_STORE(acc[i][j][r], &Cg[(int64_t)(i * 16 + fk + 4 * r) * g.ldc + j * 16 + fr]);
-  if (stamp_end) g.stamp[8 + (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 7)] = t_end;
-  // shader clock seen by the launch's first eight workgroups over their own lifetime: cycles (s_memtime) in the
-  // high word, 10 ns ticks (s_memrealtime) in the low word -> clock = cycles / ticks x 100 MHz
-  if (stamp_first)
-    g.stamp[16 + blockIdx.x] = ((__builtin_amdgcn_s_memtime() - c_start) << 32) |
-                               ((__builtin_amdgcn_s_memrealtime() - r_start) & 0xffffffffull);
+  if (stamp_end) {
+    // after this wave's own epilogue stores have been acknowledged: the stamp then dates the end of the workgroup as
+    // rocprofv3 sees it (the first version took the time before the stores and under-stated a launch by 2-3 %)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    g.stamp[8 + (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 7)] = __builtin_amdgcn_s_memrealtime();
+  }
+  // cycles (s_memtime) in the high word, 10 ns ticks (s_memrealtime) in the low word -> clock = cycles / ticks x 100 MHz
+  if (stamp_clock)
+    g.stamp[16 + blockIdx.x - mid] = ((__builtin_amdgcn_s_memtime() - c_start) << 32) |
+                                     ((__builtin_amdgcn_s_memrealtime() - r_start) & 0xffffffffull);
 }
 
 }  // namespace
@@ -358,7 +362,7 @@ int64_t gemm_split_point(int64_t T, int ncu, int k) {
 
 void launch_gemm_nt_split(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc, const double* A,
                           int64_t lda, const double* B, int64_t ldb, int ntr, int ntc, int k, int64_t nfull,
-                          unsigned long long* stamp) {
+                          unsigned long long* stamp, unsigned long long* stamp_rest) {
   if (tiles == TILES_LOWER && ntc > ntr) ntc = ntr;
   const int64_t T = (tiles == TILES_RECT) ? (int64_t)ntr * ntc
                                           : (int64_t)ntc * (ntc + 1) / 2 + (int64_t)(ntr - ntc) * ntc;
@@ -368,7 +372,7 @@ void launch_gemm_nt_split(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, 
     return;
   }
   launch_gemm_part(s, tiles, op, false, 0, C, ldc, A, lda, B, ldb, ntr, ntc, k, stamp, one, 1, nfull);
-  launch_gemm_part(s, tiles, op, false, 0, C, ldc, A, lda, B, ldb, ntr, ntc, k, nullptr, one, 2, nfull);
+  launch_gemm_part(s, tiles, op, false, 0, C, ldc, A, lda, B, ldb, ntr, ntc, k, stamp_rest, one, 2, nfull);
 }
 
 void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc,

@@ -96,6 +96,7 @@ struct gpmi_ctx {
   std::vector<Lane> lanes;
   bool fitted = false;
   bool lockstep_always = false;  // GPMI_OPT_LOCKSTEP_ALWAYS
+  int64_t reserve = 0;           // GPMI_OPT_RESERVE_POINTS: extra rows of padding at the next gpmi_set_data
   KParams fit_params{};
   double* alpha = nullptr;  // np (device) — fitted alpha
   // prediction workspace
@@ -144,20 +145,21 @@ struct gpmi_ctx {
   // device-stamped launches (trailing-update class): {min start, max end} per launch
   unsigned long long* stamp_pool = nullptr;
   std::vector<double> stamp_flops, stamp_bytes;
+  std::vector<int> stamp_class;
   std::vector<ProfSlot> prof_slots;
   size_t prof_used = 0;
   double prof_clock_cycles = 0.0, prof_clock_ticks = 0.0;  // shader cycles / 10 ns ticks over stamped workgroups
-  double prof_ms[GPMI_PROF_NCLASS] = {0, 0, 0, 0};
-  double prof_flops[GPMI_PROF_NCLASS] = {0, 0, 0, 0};
-  double prof_bytes[GPMI_PROF_NCLASS] = {0, 0, 0, 0};
-  int64_t prof_launches[GPMI_PROF_NCLASS] = {0, 0, 0, 0};
+  double prof_ms[GPMI_PROF_NCLASS] = {};
+  double prof_flops[GPMI_PROF_NCLASS] = {};
+  double prof_bytes[GPMI_PROF_NCLASS] = {};
+  int64_t prof_launches[GPMI_PROF_NCLASS] = {};
 };
 
 // instrumentation helpers (api.hip)
 constexpr int GPMI_STAMP_SLOTS = 16384;
 constexpr int GPMI_STAMP_WORDS = 24;  // per launch: 8 start words + 8 end words (one per XCD) + 8 clock words, see gemm_f64.hip
 // next stamp slot (GPMI_STAMP_WORDS words) for a trailing-update launch, or nullptr when that class is not profiled
-unsigned long long* prof_stamp_slot(gpmi_ctx* c, double flops, double bytes);
+unsigned long long* prof_stamp_slot(gpmi_ctx* c, double flops, double bytes, int klass = GPMI_PROF_SYRK);
 struct ProfScope {
   gpmi_ctx* c;
   hipStream_t s;
@@ -225,7 +227,7 @@ void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_
 int64_t gemm_split_point(int64_t T, int ncu, int k);
 void launch_gemm_nt_split(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc, const double* A,
                           int64_t lda, const double* B, int64_t ldb, int ntr, int ntc, int k, int64_t nfull,
-                          unsigned long long* stamp = nullptr);
+                          unsigned long long* stamp = nullptr, unsigned long long* stamp_rest = nullptr);
 
 // general form: b_kmajor -> B is (k x cols) row-major; kskip = 1 (TILES_LOWER) -> contraction starts at
 // the tile row's first column, kskip = 2 -> it ends with the tile column (B lower triangular)

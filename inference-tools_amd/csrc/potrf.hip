@@ -434,13 +434,22 @@ void update_columns(gpmi_ctx* c, hipStream_t s, double* A, int64_t ld, int nt, i
   const int64_t tiles = (int64_t)cols * (cols + 1) / 2 + (int64_t)(rows - cols) * cols;
   // the tiles of a nearly empty last round (of `ncu` tiles) run as 64 x 64 tiles in a second launch
   const int64_t nfull = gemm_split_point(tiles, ncu, kw);
-  // per-launch timing (bench roofline) of the 128 x 128-tile kernel only: launches with fewer than
-  // 384 tiles run the 64 x 64 variant (launch_gemm) and are a different kernel in rocprof's tables
-  unsigned long long* stamp =
-      tiles >= 384 ? prof_stamp_slot(c, (double)nfull * 2.0 * NB * NB * kw,
-                                     (double)nfull * 16.0 * NB * NB + 8.0 * rows * NB * kw)
-                   : nullptr;
-  launch_gemm_nt_split(s, TILES_LOWER, OP_SUB, C, ld, P, ld, P, ld, rows, cols, kw, nfull, stamp);
+  // per-launch timing (bench roofline), every launch: the 128 x 128-tile kernel (launches with >= 384 tiles, their
+  // full rounds) in class SYRK - the dominant kernel -, the 64 x 64-tile remainders and the launches with fewer
+  // tiles (a different kernel in rocprof's tables) in class SYRK_REST
+  const bool big = tiles >= 384 && kw > 128;
+  const int64_t nmain = big ? nfull : 0;
+  unsigned long long* stamp = nullptr;
+  unsigned long long* stamp_rest = nullptr;
+  if (nmain > 0)
+    stamp = prof_stamp_slot(c, (double)nmain * 2.0 * NB * NB * kw, (double)nmain * 16.0 * NB * NB + 8.0 * rows * NB * kw);
+  if (tiles > nmain)
+    stamp_rest = prof_stamp_slot(c, (double)(tiles - nmain) * 2.0 * NB * NB * kw, (double)(tiles - nmain) * 16.0 * NB * NB,
+                                 GPMI_PROF_SYRK_REST);
+  if (big)
+    launch_gemm_nt_split(s, TILES_LOWER, OP_SUB, C, ld, P, ld, P, ld, rows, cols, kw, nfull, stamp, stamp_rest);
+  else
+    launch_gemm_nt_split(s, TILES_LOWER, OP_SUB, C, ld, P, ld, P, ld, rows, cols, kw, nfull, stamp_rest);
 }
 
 }  // namespace

@@ -455,7 +455,7 @@ void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, 
   const int nt = (int)(np / NB), mt_all = (int)(mp / NB);
   const int OBT = GPMI_OB / NB;
   const int64_t ldp = GPMI_OB + 32;
-  ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)mp * np * np, 4.0 * np * np);
+  ProfScope ps(c, s, GPMI_PROF_TRSM, (double)mp * np * np, 4.0 * np * np);
   for (int J = 0; J < nt; J += OBT) {
     const int Je = (J + OBT < nt) ? J + OBT : nt;
     const int w = Je - J;
@@ -482,7 +482,7 @@ void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, 
 void trsm_rows_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
                         const double* invD, double* Q, int64_t mp) {
   const int nt = (int)(np / NB), mt = (int)(mp / NB);
-  ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)mp * np * np, 4.0 * np * np);
+  ProfScope ps(c, s, GPMI_PROF_TRSM, (double)mp * np * np, 4.0 * np * np);
   for (int k = nt - 1; k >= 0; --k) {
     double* Qk = Q + (int64_t)k * NB;
     // Q[:, k] <- Q[:, k] * invD_k          (B = invD_k is k-major here)

@@ -12,11 +12,13 @@ from inference_amd._lib import as_f64, dptr
 
 
 class GpEngine:
-    def __init__(self, x, y, noise_var=None, y_cov=None, device=None):
+    def __init__(self, x, y, noise_var=None, y_cov=None, device=None, reserve=0):
         self.h = _lib.Handle(device)
         self.x = as_f64(x)
         self.y = as_f64(y)
         self.n, self.d = self.x.shape
+        if reserve:
+            self.h.call("gpmi_set_option", _lib.OPT_RESERVE_POINTS, int(reserve))
         nv = None if noise_var is None else as_f64(noise_var)
         yc = None if y_cov is None else as_f64(y_cov)
         self.h.call("gpmi_set_data", dptr(self.x), dptr(self.y), dptr(nv), dptr(yc), self.n, self.d)
@@ -126,6 +128,24 @@ class GpEngine:
         q = np.empty(self.n)
         self.h.call("gpmi_lml_grad_qdiag", dptr(q))
         return q
+
+    def capacity(self):
+        cap = C.c_int64(0)
+        self.h.call("gpmi_capacity", C.byref(cap))
+        return cap.value
+
+    def append_point(self, x_new, y_new, noise_var_new, mu):
+        """Append one training point at the fitted hyper-parameters (gpmi_append_point): (alpha, logdet, info)."""
+        xn, mu = as_f64(np.ravel(x_new)), as_f64(mu)
+        alpha = np.empty(self.n + 1)
+        logdet, info = C.c_double(0.0), C.c_int(0)
+        self.h.call("gpmi_append_point", dptr(xn), float(y_new), float(noise_var_new), dptr(mu), dptr(alpha),
+                    C.byref(logdet), C.byref(info))
+        if info.value == 0:
+            self.x = np.vstack([self.x, xn[None, :]])
+            self.y = np.append(self.y, float(y_new))
+            self.n += 1
+        return alpha, logdet.value, info.value
 
     def set_option(self, option, value):
         self.h.call("gpmi_set_option", int(option), int(value))

@@ -20,8 +20,8 @@ LIB_PATH = os.environ.get("GPMI_LIB") or os.path.join(_HERE, "lib", "libgpmi.so"
 
 KERNEL_SE = 0
 KERNEL_RQ = 1
-PROF_KBUILD, PROF_SYRK, PROF_PANEL, PROF_SOLVE = 0, 1, 2, 3
-OPT_LOCKSTEP_ALWAYS = 1
+PROF_KBUILD, PROF_SYRK, PROF_PANEL, PROF_SOLVE, PROF_SYRK_REST, PROF_TRSM = 0, 1, 2, 3, 4, 5
+OPT_LOCKSTEP_ALWAYS, OPT_RESERVE_POINTS = 1, 2
 
 
 class GpmiUnavailable(RuntimeError):
@@ -75,6 +75,8 @@ SIGNATURES = {
     "gpmi_linv_lml": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _ip]),
     "gpmi_linv_lml_grad": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_linv_posterior": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _ip]),
+    "gpmi_append_point": (C.c_int, [_vp, _dp, C.c_double, C.c_double, _dp, _dp, _dp, _ip]),
+    "gpmi_capacity": (C.c_int, [_vp, C.POINTER(_i64)]),
     "gpmi_fit_dense": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_lml_dense": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_loo_dense": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),

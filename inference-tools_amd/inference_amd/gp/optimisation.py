@@ -38,6 +38,10 @@ class GpOptimiser:
     :param hyperpars: optional fixed hyper-parameters for the first fit.
     :param kernel, mean, cross_val, optimizer, n_processes: forwarded to `GpRegressor`.
     :param acquisition: acquisition class or instance (default `ExpectedImprovement`).
+    :param reuse_hyperpars: (extension, default False = the reference's behaviour) keep the hyper-parameters of
+        the first fit when evaluations are added: `add_evaluation` then appends the point to the fitted model
+        in O(N^2) (`GpRegressor.add_point`) instead of searching the hyper-parameters again and re-factorising
+        (O(N^3) per likelihood evaluation, optimisation.py:177-186).
     """
 
     def __init__(
@@ -53,6 +57,7 @@ class GpOptimiser:
         acquisition: AcquisitionFunction = ExpectedImprovement,
         optimizer: str = "bfgs",
         n_processes: int = 1,
+        reuse_hyperpars: bool = False,
     ):
         coords = np.asarray(x)
         self.x = coords.reshape([coords.size, 1]) if coords.ndim == 1 else coords
@@ -65,6 +70,7 @@ class GpOptimiser:
         self.cross_val = cross_val
         self.optimizer = optimizer
         self.n_processes = n_processes
+        self.reuse_hyperpars = bool(reuse_hyperpars)
 
         self.acquisition = acquisition() if isclass(acquisition) else acquisition
         self.acquisition_max_history = []
@@ -84,6 +90,7 @@ class GpOptimiser:
             cross_val=self.cross_val,
             optimizer=self.optimizer,
             n_processes=self.n_processes,
+            reserve=256 if self.reuse_hyperpars else 0,
         )
         self.acquisition.update_gp(self.gp)
 
@@ -109,7 +116,11 @@ class GpOptimiser:
                 raise ValueError(msg.NEW_Y_ERR_REQUIRED)
             self.y_err = np.append(self.y_err, error)
 
-        self._fit_gp()
+        if self.reuse_hyperpars:
+            self.gp.add_point(point, value, error)
+            self.acquisition.update_gp(self.gp)
+        else:
+            self._fit_gp()
         self.mu_max = self.y.max()
 
     # -- acquisition maximisers (optimisation.py:192-223) ------------------------------------

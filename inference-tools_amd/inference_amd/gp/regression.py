@@ -51,6 +51,7 @@ class GpRegressor:
         ranks; in a single process they run one after another on the device.
     :param int n_starts: number of L-BFGS-B starting positions.
     :param device: (extension) HIP device index; default ``LOCAL_RANK`` / 0.
+    :param reserve: (extension) room for this many more training points on the device, see ``add_point``.
     """
 
     def __init__(
@@ -67,6 +68,7 @@ class GpRegressor:
         n_processes: int = 1,
         n_starts: int = None,
         device: int = None,
+        reserve: int = 0,
     ):
         self.x, self.y = self._coerce_training_data(x, y)
         self.n_points = self.y.size
@@ -102,6 +104,7 @@ class GpRegressor:
         self._het_slice = None if self._generic else heteroscedastic_slice(self.cov)
         self._fit_noise = None
         self._device = device
+        self._reserve = int(reserve)
         self._engine = None
         self._K_cache = None
         self._L_cache = None
@@ -147,7 +150,8 @@ class GpRegressor:
     def engine(self) -> GpEngine:
         if self._engine is None:
             self._engine = GpEngine(
-                self.x, self.y, noise_var=self._noise_var, y_cov=self._y_cov, device=self._device
+                self.x, self.y, noise_var=self._noise_var, y_cov=self._y_cov, device=self._device,
+                reserve=getattr(self, "_reserve", 0)
             )
         return self._engine
 
@@ -272,6 +276,44 @@ class GpRegressor:
             raise LinAlgError("Matrix is not positive definite")  # numpy.linalg.cholesky, regression.py:241
         self.alpha = alpha
         self._logdet = logdet
+
+    def add_point(self, x_new, y_new, y_err_new=None):
+        """(extension) Append one training point and re-fit at the CURRENT hyper-parameters.
+
+        With a SquaredExponential / RationalQuadratic kernel (optionally + WhiteNoise), diagonal data errors and
+        free device capacity (`reserve`) this is an O(N^2) update of the fitted state: one new row of the Cholesky
+        factor (a triangular sweep) and a fresh alpha (two sweeps) - `gpmi_append_point`.  In every other case
+        the model is rebuilt and re-fitted at the same hyper-parameters (O(N^3), what the reference always does:
+        optimisation.py:177-186 builds a new GpRegressor per added evaluation)."""
+        x_new = np.asarray(x_new, dtype=float).reshape(1, self.n_dimensions)
+        y_new = float(np.asarray(y_new).squeeze())
+        if (self._noise_var is None) != (y_err_new is None) and self._y_cov is None:
+            raise ValueError("y_err_new must be given exactly when the model was built with y_err")
+        var_new = 0.0 if y_err_new is None else float(np.asarray(y_err_new).squeeze()) ** 2
+        fast = (not self._generic and self._mix is None and self._het_slice is None and self._y_cov is None
+                and self._engine is not None and self.engine.n < self.engine.capacity())
+        self.x = np.vstack([self.x, x_new])
+        self.y = np.append(self.y, y_new)
+        if self._noise_var is not None:
+            self._noise_var = np.append(self._noise_var, var_new)
+        self.n_points = self.y.size
+        self.cov.pass_spatial_data(self.x)
+        self.mean.pass_spatial_data(self.x)  # Linear / Quadratic means are centred on the data: all prior means move
+        self._K_cache = self._L_cache = None
+        if not fast:
+            if self._y_cov is not None:
+                raise NotImplementedError("add_point with a dense y_cov: rebuild the regressor instead")
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = None
+            self._reserve = max(getattr(self, "_reserve", 0), 128)
+            self.set_hyperparameters(self.hyperpars)
+            return
+        self.mu = self.mean.build_mean(self.mean_hyperpars)
+        alpha, logdet, info = self.engine.append_point(x_new[0], y_new, var_new, self.mu)
+        if info != 0:
+            raise LinAlgError("Matrix is not positive definite")
+        self.alpha, self._logdet = alpha, logdet
 
     def check_error_data(self, y_err, y_cov):
         """Validate the data-error arguments (regression.py:246-322).  Returns

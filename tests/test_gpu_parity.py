@@ -1080,3 +1080,56 @@ def test_four_lanes_at_full_size(gp_mod):
     gp.engine.set_streams(4)
     for _ in range(2):
         check(gp.marginal_likelihood_batch(thetas), single, 1e-12, "four lanes vs one at a time")
+
+
+# ---------------------------------------------------------------------------------------
+# appending evaluations at fixed hyper-parameters: O(N^2) update of the factor
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kid,n0,mean", [(wl.SE, 250, "const"), (wl.RQ, 383, "linear"), (wl.SE, 128, "const")])
+def test_append_point_equals_fit_from_scratch(gp_mod, kid, n0, mean):
+    """`GpRegressor.add_point` (gpmi_append_point: a new row of L by one triangular sweep + fresh alpha) against a
+    from-scratch fit on the enlarged data, point after point across a tile boundary (n0 = 383 -> 384 -> 385, 128 ->
+    129): L, alpha, LML, predictions; a LinearMean (centred on the data: every prior mean moves with each point)."""
+    d, extra = 3, 5
+    x, y, e = wl.synthetic_dataset(90 + n0, n0 + extra, d)
+    mean_cls = gp_mod.LinearMean if mean == "linear" else gp_mod.ConstantMean
+    th_cov = wl.timing_theta(kid, y, d)[1:]
+    th = np.concatenate([[y.mean()] + ([0.1, -0.2, 0.05] if mean == "linear" else []), th_cov])
+    kw = dict(kernel=kernel_cls(gp_mod, kid), mean=mean_cls)
+    gp = gp_mod.GpRegressor(x[:n0], y[:n0], y_err=e[:n0], hyperpars=th, reserve=extra, **kw)
+    pts = wl.query_points(91, 40, d)
+    for k in range(extra):
+        n = n0 + k
+        gp.add_point(x[n], y[n], e[n])
+        ref = gp_mod.GpRegressor(x[: n + 1], y[: n + 1], y_err=e[: n + 1], hyperpars=th, **kw)
+        check_each(gp.alpha, ref.alpha, 1e-11, what="alpha after append")
+        check(gp._logdet, ref._logdet, 1e-12, what="log-determinant after append")
+        mu, sig = gp(pts)
+        rmu, rsig = ref(pts)
+        check(mu, rmu, 1e-11, what="mu after append")
+        check(sig, rsig, 1e-11, what="sigma after append")
+    check(gp.L, ref.L, 1e-11, what="L after appends")
+    check(gp.marginal_likelihood(th), ref.marginal_likelihood(th), 1e-12, what="LML on the appended data")
+    lm, ls = gp.loo_predictions()
+    rm, rs = ref.loo_predictions()
+    check(lm, rm, 1e-10, what="loo mean after appends")
+    # capacity exhausted (reserve rounded up to the tile): the next append re-fits from scratch, same result
+    gp2 = gp_mod.GpRegressor(x[:128], y[:128], y_err=e[:128], hyperpars=th, **kw)  # no reserve, n = capacity
+    gp2.add_point(x[128], y[128], e[128])
+    ref2 = gp_mod.GpRegressor(x[:129], y[:129], y_err=e[:129], hyperpars=th, **kw)
+    check_each(gp2.alpha, ref2.alpha, 1e-11, what="alpha after a re-fitting append")
+
+
+def test_gp_optimiser_reusing_hyperparameters(gp_mod):
+    """GpOptimiser(reuse_hyperpars=True): add_evaluation appends in O(N^2) and the model equals a fresh regressor on
+    all evaluations at the same hyper-parameters."""
+    bx, by, bounds = _bo_problem()
+    th = np.array([by.mean(), np.log(by.std()), np.log(2.0), np.log(2.0)])
+    opt = gp_mod.GpOptimiser(bx, by, bounds=bounds, hyperpars=th, reuse_hyperpars=True)
+    np.random.seed(2)
+    for _ in range(3):
+        nx = opt.propose_evaluation()
+        opt.add_evaluation(nx, float(np.sin(nx[0]) + 0.1 * nx[1]))
+    assert opt.y.size == by.size + 3 and np.array_equal(opt.gp.hyperpars, th)
+    ref = gp_mod.GpRegressor(opt.x, opt.y, hyperpars=th)
+    check_each(opt.gp.alpha, ref.alpha, 1e-9, what="alpha of the appended optimiser model")  # y_err = None: cond(K) ~ 1e10

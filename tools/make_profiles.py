@@ -1,37 +1,50 @@
-"""Copy the judged summaries of a gpurun profiling session from gpurun_out/ into profiles/ (tracked).
-usage: python tools/make_profiles.py <tag>   e.g. r01   (expects gpurun_out/prof_<tag>e, pmc_<tag>e.json, bench_<tag>e.json)"""
+"""Copy the judged summaries of a profiling session (tools/profile_round.sh <tag>, run through gpurun) from
+gpurun_out/prof_<tag>/ into profiles/ (tracked).   usage: python tools/make_profiles.py <tag>   e.g. r02"""
 import csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-go = os.path.join(ROOT, "gpurun_out")
+go = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 pr = os.path.join(ROOT, "profiles")
-stats = glob.glob(os.path.join(go, f"prof_{tag}e", "*", "*kernel_stats.csv"))[0]
-shutil.copy(stats, os.path.join(pr, f"{tag}_bench_kernel_stats.csv"))
-bench = json.loads(open(os.path.join(go, f"bench_{tag}e.json")).read().strip().splitlines()[-1])
+
+
+def stats_of(sub):
+    f = glob.glob(os.path.join(go, sub, "*", "*kernel_stats.csv"))
+    return f[0] if f else None
+
+
+for sub in ("bench", "cfg2", "cfg3", "cfg4", "cfg5", "lmlgrad", "pt"):
+    st = stats_of(sub)
+    if st:
+        shutil.copy(st, os.path.join(pr, f"{tag}_{sub}_kernel_stats.csv"))
+for name in ("cfg2.txt", "cfg3.txt", "cfg4.txt", "cfg5.txt", "lmlgrad.txt", "pt.json", "propose.json", "bench_timeline.txt"):
+    src = os.path.join(go, name)
+    if os.path.exists(src) and os.path.getsize(src):
+        shutil.copy(src, os.path.join(pr, f"{tag}_{name}"))
+bench = json.loads(open(os.path.join(go, "bench.json")).read().strip().splitlines()[-1])
 json.dump(bench, open(os.path.join(pr, f"{tag}_bench.json"), "w"), indent=1)
 
-# rocprof average of the stamped launches (the last `steps` fits of the traced run) for the cross-check
-trace = glob.glob(os.path.join(go, f"prof_{tag}e", "*", "*kernel_trace.csv"))[0]
-rows = list(csv.DictReader(open(trace)))
-ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
-fits = [i for i, k in enumerate(ks) if "kbuild_kernel<true>" in k[2]]
-last = ks[fits[-5]:]
-def avg_us(sub):
-    sel = [k for k in last if sub in k[2]]
-    return len(sel), sum(k[1] - k[0] for k in sel) / max(len(sel), 1) / 1e3
-n_upd, upd_us = avg_us("gemm_nt_kernel<1, 0, 0, 128, 128>")
+# rocprofv3's average duration of the dominant kernel over the traced run, beside the bench's own stamps
+rows = list(csv.DictReader(open(stats_of("bench"))))
+upd = next(r for r in rows if "gemm_nt_kernel<1, 0, 0, 128, 128>" in r["Name"])
+upd_us = float(upd["AverageNs"]) / 1e3
 
-pmc = json.load(open(os.path.join(go, f"pmc_{tag}e.json")))
+pmc = json.load(open(os.path.join(go, "pmc.json")))
+
+
 def mean(k, c):
     return pmc[k][c]["mean"]
+
+
 KB = 1024.0
 out = {
     "command": "rocprofv3 --pmc <one group per pass> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline  (tools/pmc_bench.sh; passes: FETCH_SIZE | WRITE_SIZE | SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 | TCC_HIT_sum TCC_MISS_sum | GRBM_GUI_ACTIVE)",
     "correction": "FETCH_SIZE x 2 (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md), WRITE_SIZE exact; both in KiB",
     "kernels": {},
-    "cross_check": {"rocprof_kernel_trace_avg_us_of_stamped_launches": upd_us, "launches": n_upd,
-                    "bench_stamp_avg_us": bench["roofline"]["avg_launch_ms"] * 1e3},
+    "cross_check": {"rocprof_kernel_stats_avg_us_of_the_dominant_kernel": upd_us, "launches": int(upd["Calls"]),
+                    "bench_stamp_avg_us": bench["roofline"]["avg_launch_ms"] * 1e3,
+                    "bench_achieved_tflops": bench["roofline"]["achieved"],
+                    "achieved_tflops_with_rocprof_avg": bench["roofline"]["flop_per_launch_avg"] / (upd_us * 1e-6) / 1e12},
 }
 for key, name in (("update128", "gemm_nt_kernel<1, 0, 0, 128, 128> (trailing update)"),
                   ("kbuild", "kbuild_kernel<true> (covariance build, lower tiles)"),
@@ -51,4 +64,5 @@ for key, name in (("update128", "gemm_nt_kernel<1, 0, 0, 128, 128> (trailing upd
         ent["mfma_flop_per_launch"] = mean(key, "SQ_INSTS_VALU_MFMA_MOPS_F64") * 512.0
     out["kernels"][key] = ent
 json.dump(out, open(os.path.join(pr, f"{tag}_pmc.json"), "w"), indent=1)
-print(json.dumps(out, indent=1))
+print(json.dumps(out["cross_check"], indent=1))
+print(json.dumps(out["kernels"]["update128"], indent=1))

@@ -1,0 +1,26 @@
+#!/bin/bash
+# One GPU session that produces every profile artefact of a round under gpurun_out/prof_<tag>/ ; copy into profiles/ with
+#   python tools/make_profiles.py <tag>
+# usage (on the GPU box, through gpurun):  tools/profile_round.sh r02
+tag=${1:-r02}
+out=gpurun_out/prof_$tag
+mkdir -p $GRAFT_REPO_ROOT/$out
+cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+# 1. headline: kernel trace + stats of the bench command, then the bench line itself (un-profiled)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline > $out/bench_traced.json 2> $out/bench_traced.err
+python3 tools/timeline_full.py $out/bench $out/bench_timeline.txt > /dev/null 2>&1
+timeout 300 python3 bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err
+# 2. the other BASELINE configurations and the LML-gradient path: per-kernel stats of the same public calls
+for cfg in cfg2 cfg3 cfg4 cfg5; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$cfg -- python3 tools/config_bench.py $cfg > $out/$cfg.txt 2> $out/$cfg.err
+done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/lmlgrad -- python3 tools/grad_times.py 16384 > $out/lmlgrad.txt 2> $out/lmlgrad.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/pt -- python3 tools/config5_bench.py 10 > $out/pt.json 2> $out/pt.err
+timeout 300 python3 tools/propose_bench.py 4096 32 > $out/propose.json 2> $out/propose.err
+# keep the stats, drop the bulky traces (gpurun_out is capped at 64 MiB)
+find $out -name "*kernel_trace.csv" -delete
+find $out -name "*agent_info.csv" -delete
+# 3. HBM traffic / MFMA counters of the headline's dominant kernel: separate --pmc passes
+tools/pmc_bench.sh $out/pmc > $out/pmc.json 2> $out/pmc.err
+find $out/pmc -name "*counter_collection.csv" -delete
+ls -R $out | head -80
