@@ -94,6 +94,8 @@ class _StationaryDeviceKernel(CovarianceFunction):
 
     def pass_spatial_data(self, x: ndarray):
         self.x = np.ascontiguousarray(x, dtype=float)
+        if self._engine is not None:
+            self._engine.close()
         self._engine = None
         d = self.x.shape[1]
         self.n_params = d + 1 + self._n_shape_params
@@ -114,16 +116,33 @@ class _StationaryDeviceKernel(CovarianceFunction):
             self._engine = GpEngine(self.x, np.zeros(self.x.shape[0]))
         return self._engine
 
-    def __call__(self, u: ndarray, v: ndarray, theta: ndarray) -> ndarray:
+    def _cross_engine(self, v):
+        """Device context holding the points `v` of the second argument of `__call__`: the training points (already
+        uploaded: the `build_covariance` context) or the last other point set, kept until a different one arrives -
+        a plugin user calling `cov(u, x, theta)` in a loop does not pay a context (streams, buffers) per call."""
         from inference_amd._engine import GpEngine
 
+        if self.x is not None and v.shape == self.x.shape and np.array_equal(v, self.x):
+            return self._own_engine()
+        cached = getattr(self, "_cross", None)
+        if cached is not None and cached[0].shape == v.shape and np.array_equal(cached[0], v):
+            return cached[1]
+        if cached is not None:
+            cached[1].close()
+        eng = GpEngine(v, np.zeros(v.shape[0]))
+        self._cross = (v.copy(), eng)
+        return eng
+
+    def __call__(self, u: ndarray, v: ndarray, theta: ndarray) -> ndarray:
         u = np.ascontiguousarray(u, dtype=float)
         v = np.ascontiguousarray(v, dtype=float)
-        eng = GpEngine(v, np.zeros(v.shape[0]))
-        try:
-            return eng.cross_covariance(self._gpmi_kernel, theta, u)
-        finally:
-            eng.close()
+        return self._cross_engine(v).cross_covariance(self._gpmi_kernel, theta, u)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()  # device contexts do not pickle: re-created on demand
+        state["_engine"] = None
+        state.pop("_cross", None)
+        return state
 
     def build_covariance(self, theta: ndarray) -> ndarray:
         return self._own_engine().covariance(self._gpmi_kernel, theta)

@@ -446,9 +446,10 @@ class GpRegressor:
         theta = np.asarray(theta, dtype=float)
         if self._generic:
             return self._generic_loo(theta, want_gradient=True)
-        self._no_mixture("loo_likelihood_gradient")
-        if self._het_slice is not None:
-            raise NotImplementedError("loo_likelihood_gradient: HeteroscedasticNoise has no device gradient yet")
+        if self._mix is not None or self._het_slice is not None:
+            # no fused contraction for these: the device factorises / inverts the dense K (gpmi_loo_dense) and each
+            # component of the gradient is an O(N^2) contraction with that component's own derivative
+            return self._dense_loo_gradient(theta)
         theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
         mu, grad_mu = self.mean.mean_and_gradients(theta[self.mean_slice])
         alpha, ikdiag, pvec, g_stat, trace_q, info = self.engine.loo_grad(self._kernel_id, theta_stat, extra, mu)
@@ -525,6 +526,10 @@ class GpRegressor:
             return self._generic_lml_gradient(theta)
         theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
         mu, grad_mu = self.mean.mean_and_gradients(theta[self.mean_slice])
+        if self._mix is not None and self._mix.n_kernels != 2:
+            # the fused window-parameter row sums cover two regions (the case in which the reference's expression,
+            # covariance.py:588-593, is exact); more regions take the dense device path with the plugin's own dK
+            return self._dense_lml_gradient(theta)
         if self._mix is not None:
             lml, g_stat, alpha, trace_q, info = self._mixture_gradient(theta_stat, extra, mu)
         else:
@@ -548,9 +553,6 @@ class GpRegressor:
         from the device contraction on the weight-scaled inverse, the window parameters from the device row
         sums h_m(i) = sum_j Q_ij K_m,ij g_m(j) contracted here with d g_m / d phi."""
         cp = self._mix
-        if cp.n_kernels != 2:
-            raise NotImplementedError("ChangePoint gradients on the device: two regions only (the reference's "
-                                      "expression, covariance.py:588-593, is exact for two)")
         kernels, thetas, g = self._mix_args(theta_cp)
         lml, g_sub, hrows, alpha, info = self.engine.lml_grad_mix(kernels, thetas, g, extra, mu)
         self._mix_fit_stale = True
@@ -627,6 +629,56 @@ class GpRegressor:
         grad = zeros(self.n_hyperpars)
         grad[self.mean_slice] = array([(pvec * dmu).sum() for dmu in grad_mu])
         grad[self.cov_slice] = array([pvec @ (dK @ alpha) - (dK * W).sum() for dK in grad_K])
+        return LOO, grad
+
+    def _component_gradients(self, theta_cov, contract, diag_terms):
+        """Gradient of an objective with respect to every covariance parameter from per-component pieces:
+        `contract(dK)` for a component with dense derivative matrices (its own covariance_and_gradients),
+        `diag_terms` = the per-point quantity t_i with d objective / d K_ii = t_i for the diagonal components
+        (WhiteNoise: 2 sigma^2 sum t_i, covariance.py:171-175; HeteroscedasticNoise: 2 sigma_i^2 t_i, :682-686)."""
+        from inference_amd.gp.covariance import CompositeCovariance, HeteroscedasticNoise, WhiteNoise
+
+        comps = list(zip(self.cov.components, self.cov.slices)) if isinstance(self.cov, CompositeCovariance) \
+            else [(self.cov, slice(0, self.cov.n_params))]
+        grad = zeros(self.cov.n_params)
+        for comp, slc in comps:
+            th = theta_cov[slc]
+            if isinstance(comp, HeteroscedasticNoise):
+                grad[slc] = 2.0 * np.exp(2 * th) * diag_terms
+            elif isinstance(comp, WhiteNoise):
+                grad[slc] = 2.0 * np.exp(2 * th[0]) * diag_terms.sum()
+            else:
+                grad[slc] = [contract(dK) for dK in comp.covariance_and_gradients(th)[1]]
+        return grad
+
+    def _dense_lml_gradient(self, theta):
+        """regression.py:544-567 for covariance objects without a fused gradient kernel: K(theta) from the object's own
+        build (device kernels composed on the host), K^-1 and alpha from the device (gpmi_lml_dense)."""
+        theta_cov = theta[self.cov_slice]
+        mu, grad_mu = self.mean.mean_and_gradients(theta[self.mean_slice])
+        lml, alpha, iK, info = self.engine.lml_dense(self._dense_K(theta_cov), mu, want_alpha=True, want_inverse=True)
+        if info != 0:
+            raise LinAlgError("Matrix is not positive definite")
+        Q = alpha[:, None] * alpha[None, :] - iK
+        grad = zeros(self.n_hyperpars)
+        grad[self.mean_slice] = array([(alpha * dmu).sum() for dmu in grad_mu])
+        grad[self.cov_slice] = self._component_gradients(theta_cov, lambda dK: 0.5 * (Q * dK.T).sum(), 0.5 * np.diag(Q))
+        return lml, grad
+
+    def _dense_loo_gradient(self, theta):
+        """regression.py:489-526 for the same objects: alpha, diag(K^-1), p = K^-1 c1 and W = K^-1 diag(c2) K^-1
+        from the device (gpmi_loo_dense), d LOO / d theta_j = p . (dK_j alpha) - sum dK_j o W on the host."""
+        theta_cov = theta[self.cov_slice]
+        mu, grad_mu = self.mean.mean_and_gradients(theta[self.mean_slice])
+        alpha, ikdiag, pvec, W, info = self.engine.loo_dense(self._dense_K(theta_cov), mu, True)
+        if info != 0:
+            raise LinAlgError("Matrix is not positive definite")
+        var = 1.0 / ikdiag
+        LOO = float(-0.5 * (var * alpha**2 + np.log(var)).sum())
+        grad = zeros(self.n_hyperpars)
+        grad[self.mean_slice] = array([(pvec * dmu).sum() for dmu in grad_mu])
+        grad[self.cov_slice] = self._component_gradients(
+            theta_cov, lambda dK: pvec @ (dK @ alpha) - (dK * W).sum(), pvec * alpha - np.diag(W))
         return LOO, grad
 
     def _gradient_pieces(self, p):

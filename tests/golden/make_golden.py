@@ -23,6 +23,9 @@ Cases
   linv       GpLinearInverter: 1-D deconvolution (32 x 64) and 2-D tomography (300 x 400), SE / RQ / SE+WhiteNoise
   search     the stochastic callers under numpy.random.seed: multistart_bfgs (start positions, theta*, LML(theta*); LML and
              LOO objectives), differential_evo, AcquisitionFunction.starting_positions, GpOptimiser.propose_evaluation
+  cpx        the gradients the fused device paths do not cover, served by the dense device path: ChangePoint over THREE
+             regions (LML and LOO gradients), LOO gradients of two-region ChangePoint (+ WhiteNoise) and of
+             SE + HeteroscedasticNoise
   plugin     a user-defined covariance function written against the plugin ABC only (Matern-3/2, workloads.Matern32Math):
              every public GpRegressor method, the seeded hyper-parameter search and an EI proposal
   means      LinearMean / QuadraticMean: labels, bounds, fit, predict, LML, LML gradient (mean-parameter components
@@ -500,6 +503,47 @@ def case_search():
     return out
 
 
+def case_cpx():
+    out = {}
+    n, d = 200, 2
+    rng = np.random.default_rng(4242)
+    x = rng.uniform(0, 1, (n, d))
+    y = np.where(x[:, 0] < 0.5, np.sin(3 * x[:, 0] + x[:, 1]), np.sin(25 * x[:, 0]) * np.cos(9 * x[:, 1])) + 0.05 * rng.normal(size=n)
+    e = np.full(n, 0.05)
+    out.update(x=x, y=y, y_err=e)
+    # three regions
+    cov3 = ChangePoint(kernels=[SquaredExponential, SquaredExponential, RationalQuadratic])
+    th3 = np.array([[0.05 * k, -0.2, np.log(0.4), np.log(0.8), -0.1, np.log(0.08), np.log(0.2), 0.1, 0.3, np.log(0.3), np.log(0.5),
+                     0.33 + 0.02 * k, 0.05, 0.66, 0.04 + 0.01 * k] for k in range(2)])
+    gp = GpRegressor(x, y, y_err=e, kernel=cov3, hyperpars=th3[0])
+    out["cp3_thetas"] = th3
+    out["cp3_labels"] = np.array(gp.hyperpar_labels)
+    res = [gp.marginal_likelihood_gradient(t) for t in th3]
+    out["cp3_lml"], out["cp3_grad"] = np.array([r[0] for r in res]), np.array([r[1] for r in res])
+    res = [gp.loo_likelihood_gradient(t) for t in th3]
+    out["cp3_loo"], out["cp3_loo_grad"] = np.array([r[0] for r in res]), np.array([r[1] for r in res])
+    # two regions: LOO gradient
+    for tag, subs, wn in (("sese", (wl.SE, wl.SE), False), ("sesewn", (wl.SE, wl.SE), True)):
+        cov = ChangePoint(kernels=[kernel_cls(k) for k in subs])
+        if wn:
+            cov = cov + WhiteNoise()
+        th = [0.1, -0.1, np.log(0.4), np.log(0.8), -0.2, np.log(0.08), np.log(0.16), 0.48, 0.07]
+        if wn:
+            th.append(np.log(0.03))
+        th = np.array(th)
+        gp = GpRegressor(x, y, y_err=e, kernel=cov, hyperpars=th)
+        v, g = gp.loo_likelihood_gradient(th)
+        out[f"{tag}_theta"], out[f"{tag}_loo"], out[f"{tag}_loo_grad"] = th, np.array(v), g
+    # heteroscedastic noise: LOO gradient (N = 96: the reference materialises 96 dense gradient matrices)
+    xh, yh, eh = wl.synthetic_dataset(77, 96, 1)
+    rngh = np.random.default_rng(771)
+    thh = np.concatenate([wl.timing_theta(wl.SE, yh, 1), np.log(0.1) + 0.3 * rngh.standard_normal(96)])
+    gp = GpRegressor(xh, yh, y_err=eh, kernel=SquaredExponential() + HeteroscedasticNoise(), hyperpars=thh)
+    v, g = gp.loo_likelihood_gradient(thh)
+    out["het_theta"], out["het_loo"], out["het_loo_grad"] = thh, np.array(v), g
+    return out
+
+
 def case_plugin():
     """A covariance function that only implements the ABC (covariance.py:8-44) through the reference's classes."""
     from inference.gp import GpOptimiser
@@ -588,6 +632,7 @@ IDX_TOMO = np.arange(0, 400, 7)  # 58 rows / columns of the 400 x 400 posterior 
 
 CASES = {
     "search": case_search,
+    "cpx": case_cpx,
     "plugin": case_plugin,
     "means": case_means,
     "cp": case_cp,

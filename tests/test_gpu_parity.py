@@ -698,7 +698,7 @@ def test_change_point_vs_reference(golden, gp_mod, tag, subs, wn):
 
 def test_change_point_search_and_limits(gp_mod):
     """Hyper-parameter search through the mixture path (L-BFGS-B with the analytic gradient); three regions
-    work for fit / predict / LML but not for the gradient; sub-kernels without device code take the dense path."""
+    work for fit / predict / LML / gradient (dense device path); sub-kernels without device code take the dense path."""
     rng = np.random.default_rng(11)
     x = np.sort(rng.uniform(0, 1, 120)).reshape(-1, 1)
     y = np.where(x[:, 0] < 0.5, np.sin(4 * x[:, 0]), np.sin(40 * x[:, 0])) + 0.05 * rng.normal(size=120)
@@ -714,8 +714,16 @@ def test_change_point_search_and_limits(gp_mod):
     th3 = np.array([0.0, 0.0, np.log(0.3), 0.0, np.log(0.05), 0.0, np.log(0.3), 0.35, 0.03, 0.7, 0.03])
     gp3 = gp_mod.GpRegressor(x, y, y_err=e, kernel=cp3, hyperpars=th3)
     assert np.isfinite(gp3.marginal_likelihood(th3)) and np.isfinite(gp3(x[:5])[0]).all()
-    with pytest.raises(NotImplementedError):
-        gp3.marginal_likelihood_gradient(th3)
+    # three regions: the gradient comes from the dense device path; its sub-kernel components are exact (finite
+    # differences), the window components follow the reference's expression (tests/golden/cpx.npz pins them)
+    _, g3 = gp3.marginal_likelihood_gradient(th3)
+    for i in (1, 2, 4, 6):
+        h = 1e-6
+        tp, tm = th3.copy(), th3.copy()
+        tp[i] += h
+        tm[i] -= h
+        fd = (gp3.marginal_likelihood(tp) - gp3.marginal_likelihood(tm)) / (2 * h)
+        assert abs(fd - g3[i]) <= 1e-4 * max(abs(fd), 1.0)  # finite-difference noise at LML ~ -1e3 is ~2e-5
     # a combination without a fused device path (a WhiteNoise region) goes through the plugin methods + dense device path
     cpw = gp_mod.ChangePoint(kernels=[gp_mod.SquaredExponential, gp_mod.WhiteNoise])
     thw = np.array([0.0, 0.0, np.log(0.3), np.log(0.1), 0.5, 0.05])
@@ -1133,3 +1141,65 @@ def test_gp_optimiser_reusing_hyperparameters(gp_mod):
     assert opt.y.size == by.size + 3 and np.array_equal(opt.gp.hyperpars, th)
     ref = gp_mod.GpRegressor(opt.x, opt.y, hyperpars=th)
     check_each(opt.gp.alpha, ref.alpha, 1e-9, what="alpha of the appended optimiser model")  # y_err = None: cond(K) ~ 1e10
+
+
+# ---------------------------------------------------------------------------------------
+# gradients without a fused device kernel: dense device path + the objects' own derivative matrices
+# ---------------------------------------------------------------------------------------
+def test_three_region_change_point_and_loo_gradients_vs_reference(golden, gp_mod):
+    """ChangePoint over three regions (LML and LOO gradients), LOO gradients of two-region ChangePoint (+ WhiteNoise)
+    and of SE + HeteroscedasticNoise: K^-1, alpha, p, W from the device (gpmi_lml_dense / gpmi_loo_dense), the
+    contraction with each component's own dK on the host - against the reference (tests/golden/cpx.npz)."""
+    g = golden("cpx")
+    x, y, e = g["x"], g["y"], g["y_err"]
+    cov3 = gp_mod.ChangePoint(kernels=[gp_mod.SquaredExponential, gp_mod.SquaredExponential, gp_mod.RationalQuadratic])
+    th3 = g["cp3_thetas"]
+    gp = gp_mod.GpRegressor(x, y, y_err=e, kernel=cov3, hyperpars=th3[0])
+    assert list(g["cp3_labels"]) == gp.hyperpar_labels
+    for t, v, gr, lv, lg in zip(th3, g["cp3_lml"], g["cp3_grad"], g["cp3_loo"], g["cp3_loo_grad"]):
+        a, b = gp.marginal_likelihood_gradient(t)
+        check(a, v, what="3-region lml")
+        check_each(b, gr, what="3-region lml gradient")
+        a, b = gp.loo_likelihood_gradient(t)
+        check(a, lv, what="3-region loo")
+        check_each(b, lg, what="3-region loo gradient")
+    for tag, wn in (("sese", False), ("sesewn", True)):
+        cov = gp_mod.ChangePoint(kernels=[gp_mod.SquaredExponential, gp_mod.SquaredExponential])
+        if wn:
+            cov = cov + gp_mod.WhiteNoise()
+        th = g[f"{tag}_theta"]
+        gp2 = gp_mod.GpRegressor(x, y, y_err=e, kernel=cov, hyperpars=th)
+        a, b = gp2.loo_likelihood_gradient(th)
+        check(a, g[f"{tag}_loo"], what="2-region loo")
+        check_each(b, g[f"{tag}_loo_grad"], what="2-region loo gradient")
+    xh, yh, eh = wl.synthetic_dataset(77, 96, 1)
+    thh = g["het_theta"]
+    gph = gp_mod.GpRegressor(xh, yh, y_err=eh, kernel=gp_mod.SquaredExponential() + gp_mod.HeteroscedasticNoise(), hyperpars=thh)
+    a, b = gph.loo_likelihood_gradient(thh)
+    check(a, g["het_loo"], what="heteroscedastic loo")
+    check_each(b, g["het_loo_grad"], what="heteroscedastic loo gradient (99 components)")
+    # cross_val=True search now works for these kernels too
+    np.random.seed(6)
+    gcv = gp_mod.GpRegressor(xh, yh, y_err=eh, kernel=gp_mod.SquaredExponential() + gp_mod.WhiteNoise(), cross_val=True, n_starts=2)
+    assert np.isfinite(gcv.loo_likelihood(gcv.hyperpars))
+
+
+def test_kernel_call_reuses_its_device_context(gp_mod):
+    """`cov(u, v, theta)` keeps one device context per point set instead of creating one per call."""
+    x, y, e = wl.synthetic_dataset(3, 200, 2)
+    cov = gp_mod.SquaredExponential()
+    cov.pass_spatial_data(x)
+    th = np.array([0.1, -0.3, 0.2])
+    u = wl.query_points(3, 7, 2)
+    a = cov(u, x, th)
+    eng = cov._own_engine()
+    b = cov(u, x, th)
+    assert cov._own_engine() is eng and np.array_equal(a, b) and getattr(cov, "_cross", None) is None
+    other = wl.query_points(4, 50, 2)
+    c1 = cov(u, other, th)
+    held = cov._cross[1]
+    c2 = cov(u[:3], other, th)
+    assert cov._cross[1] is held and np.array_equal(c1[:3], c2)
+    from oracle import gp_oracle as orc
+
+    check(c1, orc.kernel_cross(wl.SE, u, other, th), 1e-13, "cross-covariance against another point set")
