@@ -88,6 +88,10 @@ bool ensure_masked_pair(gpmi_ctx* c, Lane& L, int k) {
   MaskedPair& mp = g_pool[{c->device, k}];
   if (!mp.tried) {
     mp.tried = true;
+    if (const char* e = std::getenv("GPMI_PANEL_CUS")) {  // tuning aid: CUs of the panel stream (a multiple of 8, < 32 or 32)
+      const int v = std::atoi(e);
+      if (v >= 8 && v <= 32 && v % 8 == 0) c->pair_cus[k] = v;
+    }
     std::vector<uint32_t> panel((size_t)ncu / 32, 0u), upd((size_t)ncu / 32, 0xffffffffu);
     const uint32_t bits = (c->pair_cus[k] >= 32) ? 0xffffffffu : ((1u << c->pair_cus[k]) - 1u);
     panel[0] = bits;

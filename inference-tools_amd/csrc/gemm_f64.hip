@@ -18,6 +18,8 @@
 //   A: lane l holds A[i = l & 15][k = l >> 4]      B: lane l holds B[k = l >> 4][j = l & 15]
 //   D: 4 values per lane, D[row = (l >> 4) + 4 r][col = l & 15]
 // It issues every 64 cycles per SIMD: 256 CUs x 4 SIMDs x 2048 FLOP / 64 clk x 2.4 GHz = 78.6 TFLOP/s.
+#include <cstdlib>
+
 #include "gpmi_internal.h"
 
 // C tiles are read once and written once per launch: those accesses are marked non-temporal so that they do not
@@ -274,6 +276,141 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
                                      ((__builtin_amdgcn_s_memrealtime() - r_start) & 0xffffffffull);
 }
 
+
+// ---- 128 x 128 tiles with K-contiguous operands: operand ring fed by LDS-DMA ---------------------------------------------------------------
+// Same 128 x 128 tile, C -= A B^T, but the operand slabs go from global memory straight into a ring of DMA_STAGES
+// 8-deep LDS stages with global_load_lds_dwordx4 (no staging registers, no LDS store instructions), three stages
+// ahead of the MFMAs instead of one 16-deep slab.  The loads and their waits are inline assembly: the compiler
+// orders every ds_read behind `s_waitcnt vmcnt(0)` when it knows of an LDS-DMA in flight, which would drain the ring
+// at every barrier.  Piece (row r, k pair q) of a stage lives in 16-byte slot 4 r + ((q + 2 (r >> 2)) & 3): conflict-
+// free ds_read_b128 fragments (lane (fr, fk) reads pair fk of row fr: the four 4-lane quads of a read group land on
+// four different slot positions).  The A fragments are negated after the LDS read (the DMA path cannot negate on the way in).
+constexpr int DMA_BK = 8;
+#ifndef GPMI_DMA_STAGES
+#define GPMI_DMA_STAGES 4
+#endif
+constexpr int DMA_STAGES = GPMI_DMA_STAGES;
+constexpr int DMA_OP_DOUBLES = 128 * DMA_BK;  // one operand of one stage: 8 KiB
+
+__device__ inline void dma_wait(int newer) {
+  // wait until at most `newer` younger vector-memory operations of this wave are outstanding
+  if (newer >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (newer >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (newer >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int TILES, int OP>
+__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmArgs g) {
+  __shared__ double smem[DMA_STAGES * 2 * DMA_OP_DOUBLES];
+  int ti, tj;
+  // k-skipped launches have tiles of very different length: dealt round-robin over the XCDs (see gemm_nt_kernel)
+  tile_of<TILES>(g.kskip ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x), g.ntr, g.ntc, ti, tj);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool stamp_first = g.stamp && tid == 0 && blockIdx.x < 8;
+  if (stamp_first) g.stamp[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+  const unsigned mid = gridDim.x >> 1;
+  const bool stamp_clock = g.stamp && tid == 0 && blockIdx.x >= mid && blockIdx.x < mid + 8;
+  unsigned long long c_start = 0, r_start = 0;
+  if (stamp_clock) {
+    r_start = __builtin_amdgcn_s_memrealtime();
+    c_start = __builtin_amdgcn_s_memtime();
+  }
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int kbeg = (g.kskip == 1) ? ti * 128 : 0;
+  const int kend = (g.kskip == 2 && (tj + 1) * 128 < g.k) ? (tj + 1) * 128 : g.k;
+  const double* __restrict__ Ag = g.A + (int64_t)ti * 128 * g.lda + kbeg;
+  const double* __restrict__ Bg = g.B + (int64_t)tj * 128 * g.ldb + kbeg;
+  // this thread's two pieces per operand and stage: p = i * 256 + tid -> row p >> 2, slot p & 3
+  const int row0 = tid >> 2, slot = tid & 3;
+  const int q0 = (slot - 2 * ((row0 >> 2) & 3)) & 3;          // rows row0 and row0 + 64 have the same (row >> 2) & 3
+  const double* a_src0 = Ag + (int64_t)row0 * g.lda + 2 * q0;
+  const double* a_src1 = a_src0 + (int64_t)64 * g.lda;
+  const double* b_src0 = Bg + (int64_t)row0 * g.ldb + 2 * q0;
+  const double* b_src1 = b_src0 + (int64_t)64 * g.ldb;
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;  // LDS byte address of the ring (address space 3 pointers are offsets)
+  const unsigned wave_off = (unsigned)__builtin_amdgcn_readfirstlane(wave * 64 * 16);
+  auto issue = [&](int st, int k0) {
+    const unsigned base = lds0 + (unsigned)st * (2 * DMA_OP_DOUBLES * 8) + wave_off;
+    const double* p0 = a_src0 + k0;
+    const double* p1 = a_src1 + k0;
+    const double* p2 = b_src0 + k0;
+    const double* p3 = b_src1 + k0;
+    asm volatile(
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+        "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+        "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off"
+        :
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(base), "s"(base + 256 * 16), "s"(base + DMA_OP_DOUBLES * 8),
+          "s"(base + DMA_OP_DOUBLES * 8 + 256 * 16)
+        : "memory");
+  };
+  const int nk = (kend - kbeg) / DMA_BK;
+  for (int st = 0; st < DMA_STAGES - 1 && st < nk; ++st) issue(st, st * DMA_BK);
+
+  double* Cg = g.C + ((int64_t)ti * 128 + wr * 64) * g.ldc + (int64_t)tj * 128 + wc * 64;
+  d4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[i][j][r] = (OP == OP_SUB) ? GPMI_C_LOAD(&Cg[(int64_t)(i * 16 + fk + 4 * r) * g.ldc + j * 16 + fr]) : 0.0;
+
+  const int rslot = (fk + 2 * (fr >> 2)) & 3;
+  const int a_off = ((wr * 64 + fr) * 4 + rslot) * 2;                      // doubles
+  const int b_off = DMA_OP_DOUBLES + ((wc * 64 + fr) * 4 + rslot) * 2;
+  auto stage = [&](int kt) {
+    const int ahead = nk - 1 - kt;  // stages issued after this one
+    // the first stages also have the 64 C loads behind them: any vmcnt <= 63 covers the stage (in-order return)
+    dma_wait(4 * (ahead < DMA_STAGES - 2 ? ahead : DMA_STAGES - 2));
+    __syncthreads();
+#ifdef GPMI_DMA_ISSUE_EARLY
+    if (kt + DMA_STAGES - 1 < nk) issue((kt + DMA_STAGES - 1) % DMA_STAGES, (kt + DMA_STAGES - 1) * DMA_BK);
+#endif
+    const double* sa = smem + (kt % DMA_STAGES) * 2 * DMA_OP_DOUBLES;
+    d2_t a[4], b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      a[t] = *reinterpret_cast<const d2_t*>(sa + a_off + t * 16 * 4 * 2);
+      if (OP == OP_SUB) a[t] = -a[t];  // C - A B^T
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const d2_t*>(sa + b_off + t * 16 * 4 * 2);
+#ifndef GPMI_DMA_ISSUE_EARLY
+    if (kt + DMA_STAGES - 1 < nk) issue((kt + DMA_STAGES - 1) % DMA_STAGES, (kt + DMA_STAGES - 1) * DMA_BK);
+#endif
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][h], b[j][h], acc[i][j], 0, 0, 0);
+  };
+  // first stage peeled off the loop: its MFMAs wait for their own accumulator tile only, the C tile streams in
+  // under them instead of in front of the loop
+  stage(0);
+  for (int kt = 1; kt < nk; ++kt) stage(kt);
+  const bool stamp_end = g.stamp && tid == 0 && blockIdx.x + 1024 >= gridDim.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) GPMI_C_STORE(acc[i][j][r], &Cg[(int64_t)(i * 16 + fk + 4 * r) * g.ldc + j * 16 + fr]);
+  if (stamp_end) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    g.stamp[8 + (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 7)] = __builtin_amdgcn_s_memrealtime();
+  }
+  if (stamp_clock)
+    g.stamp[16 + blockIdx.x - mid] = ((__builtin_amdgcn_s_memtime() - c_start) << 32) |
+                                     ((__builtin_amdgcn_s_memrealtime() - r_start) & 0xffffffffull);
+}
+
 }  // namespace
 
 namespace {
@@ -314,6 +451,19 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
   if (part == 2) nwg = 4 * (big - nfull);
   if (nwg <= 0) return;
   dim3 grid((unsigned)nwg, 1, (unsigned)bt.count), block(256);
+  // full 128 x 128 tiles with K-contiguous operands take the LDS-DMA ring kernel (GPMI_GEMM_NO_DMA=1: the
+  // register-staged kernel everywhere, for A/B timing)
+  static const bool no_dma = std::getenv("GPMI_GEMM_NO_DMA") != nullptr;
+  if (!no_dma && bm == 128 && bn == 128 && !b_kmajor && bt.count == 1 && part != 2 && k % 128 == 0) {
+    if (tiles == TILES_RECT) {
+      if (op == OP_SUB) hipLaunchKernelGGL((gemm_dma_kernel<TILES_RECT, OP_SUB>), grid, block, 0, s, g);
+      else hipLaunchKernelGGL((gemm_dma_kernel<TILES_RECT, OP_ASSIGN>), grid, block, 0, s, g);
+    } else {
+      if (op == OP_SUB) hipLaunchKernelGGL((gemm_dma_kernel<TILES_LOWER, OP_SUB>), grid, block, 0, s, g);
+      else hipLaunchKernelGGL((gemm_dma_kernel<TILES_LOWER, OP_ASSIGN>), grid, block, 0, s, g);
+    }
+    return;
+  }
 #define GPMI_LAUNCH(T, O, B, M, N) \
   hipLaunchKernelGGL((gemm_nt_kernel<T, O, B, M, N>), grid, block, 0, s, g)
   if (bm == 128) {
