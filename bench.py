@@ -326,7 +326,7 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                 "parallelism": f"{world} independent hyper-parameter evaluations (one per GPU), result all-gather: {gather}",
             },
             "roofline": {
-                "kernel": "gemm_nt_kernel<1, 0, 0, 128, 128> = <TILES_LOWER, OP_SUB, NT, 128x128> (potrf trailing SYRK update, K=512; the full rounds of every launch with >= 384 tiles)",
+                "kernel": "gemm_dma_kernel<1, 0> = <TILES_LOWER, OP_SUB>: 128x128 tiles, operands through an LDS-DMA ring (potrf trailing SYRK update, K=512; the full rounds of every launch with >= 384 tiles)",
                 "timing": "in-kernel s_memrealtime stamps per launch: first workgroups' start -> last workgroup's end behind its epilogue stores",
                 "cu_mask": "launches of the look-ahead regime run on 224 of 256 CUs (the other 32 factor the next panel)",
                 "bound": "mfma",

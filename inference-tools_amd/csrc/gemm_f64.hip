@@ -300,8 +300,11 @@ __device__ inline void dma_wait(int newer) {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#ifndef GPMI_DMA_WGS
+#define GPMI_DMA_WGS 2
+#endif
 template <int TILES, int OP>
-__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, GPMI_DMA_WGS) void gemm_dma_kernel(GemmArgs g) {
   __shared__ double smem[DMA_STAGES * 2 * DMA_OP_DOUBLES];
   int ti, tj;
   // k-skipped launches have tiles of very different length: dealt round-robin over the XCDs (see gemm_nt_kernel)
@@ -394,7 +397,14 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmArgs g) {
   // first stage peeled off the loop: its MFMAs wait for their own accumulator tile only, the C tile streams in
   // under them instead of in front of the loop
   stage(0);
-  for (int kt = 1; kt < nk; ++kt) stage(kt);
+  int kt = 1;
+  for (; kt + 3 < nk; kt += 4) {  // four stages per trip: the ring slot of a stage is a compile-time offset from kt's
+    stage(kt);
+    stage(kt + 1);
+    stage(kt + 2);
+    stage(kt + 3);
+  }
+  for (; kt < nk; ++kt) stage(kt);
   const bool stamp_end = g.stamp && tid == 0 && blockIdx.x + 1024 >= gridDim.x;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -428,7 +438,11 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
   // 64-row tiles for one-tile-column products (in place: a workgroup must own whole rows),
   // 64 x 64 tiles for the remaining short / small launches
   int bm = 128, bn = 128;
-  const bool small = part == 0 && ((k <= 128) || (big * bt.count < 384));
+  static const int64_t BIG_MIN = [] {
+    const char* e = std::getenv("GPMI_BIG_MIN");
+    return (int64_t)(e ? std::atoi(e) : 384);
+  }();
+  const bool small = part == 0 && ((k <= 128) || (big * bt.count < BIG_MIN));
   if (part == 2) {
     bm = 64;
     bn = 64;
@@ -504,9 +518,17 @@ void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, int k
 // is nearly empty wastes up to 70 us x ncu CUs.  When that round would be less than ~55 % full its tiles run
 // as 64 x 64 tiles instead (four times as many workgroups, spread over all CUs), in a second launch.
 int64_t gemm_split_point(int64_t T, int ncu, int k) {
-  if (k <= 128 || T < 384 || ncu <= 0) return T;  // these launches use the small tiles throughout
+  static const int64_t BIG_MIN = [] {
+    const char* e = std::getenv("GPMI_BIG_MIN");
+    return (int64_t)(e ? std::atoi(e) : 384);
+  }();
+  static const int64_t SPLIT_PCT = [] {
+    const char* e = std::getenv("GPMI_SPLIT_PCT");
+    return (int64_t)(e ? std::atoi(e) : 55);
+  }();
+  if (k <= 128 || T < BIG_MIN || ncu <= 0) return T;  // these launches use the small tiles throughout
   const int64_t rem = T % ncu;
-  if (rem == 0 || rem * 100 > (int64_t)ncu * 55) return T;
+  if (rem == 0 || rem * 100 > (int64_t)ncu * SPLIT_PCT) return T;
   return T - rem;
 }
 

@@ -437,7 +437,11 @@ void update_columns(gpmi_ctx* c, hipStream_t s, double* A, int64_t ld, int nt, i
   // per-launch timing (bench roofline), every launch: the 128 x 128-tile kernel (launches with >= 384 tiles, their
   // full rounds) in class SYRK - the dominant kernel -, the 64 x 64-tile remainders and the launches with fewer
   // tiles (a different kernel in rocprof's tables) in class SYRK_REST
-  const bool big = tiles >= 384 && kw > 128;
+  static const int64_t BIG_MIN = [] {
+    const char* e = std::getenv("GPMI_BIG_MIN");
+    return (int64_t)(e ? std::atoi(e) : 384);
+  }();
+  const bool big = tiles >= BIG_MIN && kw > 128;
   const int64_t nmain = big ? nfull : 0;
   unsigned long long* stamp = nullptr;
   unsigned long long* stamp_rest = nullptr;

@@ -26,7 +26,7 @@ json.dump(bench, open(os.path.join(pr, f"{tag}_bench.json"), "w"), indent=1)
 
 # rocprofv3's average duration of the dominant kernel over the traced run, beside the bench's own stamps
 rows = list(csv.DictReader(open(stats_of("bench"))))
-upd = next(r for r in rows if "gemm_nt_kernel<1, 0, 0, 128, 128>" in r["Name"])
+upd = next(r for r in rows if "gemm_dma_kernel<1, 0>" in r["Name"] or "gemm_nt_kernel<1, 0, 0, 128, 128>" in r["Name"])
 upd_us = float(upd["AverageNs"]) / 1e3
 
 pmc = json.load(open(os.path.join(go, "pmc.json")))
@@ -46,7 +46,7 @@ out = {
                     "bench_achieved_tflops": bench["roofline"]["achieved"],
                     "achieved_tflops_with_rocprof_avg": bench["roofline"]["flop_per_launch_avg"] / (upd_us * 1e-6) / 1e12},
 }
-for key, name in (("update128", "gemm_nt_kernel<1, 0, 0, 128, 128> (trailing update)"),
+for key, name in (("update128", "gemm_dma_kernel<1, 0> (trailing update, 128x128 tiles)"),
                   ("kbuild", "kbuild_kernel<true> (covariance build, lower tiles)"),
                   ("trsv_fwd", "trsv_fwd_flow_kernel (forward sweep)")):
     if key not in pmc:
