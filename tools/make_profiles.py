@@ -9,8 +9,8 @@ pr = os.path.join(ROOT, "profiles")
 
 
 def stats_of(sub):
-    f = glob.glob(os.path.join(go, sub, "*", "*kernel_stats.csv"))
-    return f[0] if f else None
+    f = sorted(glob.glob(os.path.join(go, sub, "*", "*kernel_stats.csv")), key=os.path.getmtime)
+    return f[-1] if f else None  # the newest: gpurun merges a session into what earlier sessions left behind
 
 
 for sub in ("bench", "cfg2", "cfg3", "cfg4", "cfg5", "lmlgrad", "pt"):

@@ -4,6 +4,7 @@
 # usage (on the GPU box, through gpurun):  tools/profile_round.sh r02
 tag=${1:-r02}
 out=gpurun_out/prof_$tag
+rm -rf $GRAFT_REPO_ROOT/$out
 mkdir -p $GRAFT_REPO_ROOT/$out
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 # 1. headline: kernel trace + stats of the bench command, then the bench line itself (un-profiled)
