@@ -227,6 +227,10 @@ def main():
     finally:
         if rdv is not None:
             rdv.close()
+        # destroy the device contexts here, while the interpreter is fully alive: under rocprofv3 a context that is
+        # only torn down during interpreter shutdown ended in a SIGSEGV inside the runtime's static destructors
+        # (after the profile had been written)
+        _lib._close_all_handles()
 
 
 def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, local_rank, rdv):

@@ -8,12 +8,11 @@
 //   instrumentation (per-class events, in-kernel stamps), device-pointer entry points (tools)
 //   mixture covariance (ChangePoint), per-point noise (HeteroscedasticNoise), linear inversion (GpLinearInverter)
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
-#include <mutex>
 
 #include "gpmi_internal.h"
 
@@ -63,32 +62,25 @@ int lane_streams(gpmi_ctx* c, Lane& L) {
 
 }  // namespace
 
-// CU-masked stream pair k of the look-ahead.  The pairs live in a process-wide pool, one per device, created the
-// first time any lane needs them and NEVER destroyed: hipStreamDestroy on a CU-masked stream blocks forever on
-// ROCm 7.2 unless the stream was synchronised twice before (tools/probe_exit.py), and streams beyond the runtime's
-// hardware-queue budget share queues anyway.  Contexts on one device share the pair; work of two contexts that
-// factorise at the same time is merely serialised on it.  Mask bits are dealt round-robin over the 8 XCDs (probed
-// with tools/cumask_probe.hip), so the first 8 m bits are m CUs on every XCD.  false: no masked streams on this
-// device / runtime, everything stays on the full-chip stream.
-namespace {
-struct MaskedPair {
-  hipStream_t sp = nullptr, su = nullptr;
-  bool tried = false;
-};
-std::mutex g_pool_mutex;
-std::map<std::pair<int, int>, MaskedPair> g_pool;  // (device, pair index) -> streams
-}  // namespace
-
+// CU-masked stream pair of the look-ahead: factor the next panel on pair_cus CUs (sp) while the trailing update
+// runs on all the others (su).  Mask bits are dealt round-robin over the 8 XCDs (probed with tools/cumask_probe.hip),
+// so the first 8 m bits are m CUs on every XCD.  The pair is created together with the lane's main stream, before any
+// work is queued, and destroyed with it: created later (on first use, with kernels already in flight on the lane)
+// hipStreamDestroy blocked forever on ROCm 7.2, and a pair that is never destroyed ends the process in a SIGSEGV
+// inside the runtime's static destructors when rocprofv3 is attached (tools/probe_exit.py).  Only the lanes that
+// can factorise with look-ahead get one: lane 0 (the fitted model) and lane 1 (single evaluations).
 bool ensure_masked_pair(gpmi_ctx* c, Lane& L, int k) {
-  if (L.masked_tried[k]) return L.sp[k] != nullptr;
-  L.masked_tried[k] = true;
+  (void)c;
+  return L.sp[k] != nullptr && L.su[k] != nullptr;
+}
+
+namespace {
+
+int lane_masked_streams(gpmi_ctx* c, Lane& L) {
   const int ncu = c->ncu;
-  if (ncu < 64 || ncu % 32 != 0) return false;
-  std::lock_guard<std::mutex> lock(g_pool_mutex);
-  MaskedPair& mp = g_pool[{c->device, k}];
-  if (!mp.tried) {
-    mp.tried = true;
-    if (const char* e = std::getenv("GPMI_PANEL_CUS")) {  // tuning aid: CUs of the panel stream (a multiple of 8, < 32 or 32)
+  if (ncu < 64 || ncu % 32 != 0) return GPMI_OK;
+  for (int k = 0; k < GPMI_NPAIRS; ++k) {
+    if (const char* e = std::getenv("GPMI_PANEL_CUS")) {  // tuning aid: CUs of the panel stream (8, 16, 24 or 32)
       const int v = std::atoi(e);
       if (v >= 8 && v <= 32 && v % 8 == 0) c->pair_cus[k] = v;
     }
@@ -96,21 +88,28 @@ bool ensure_masked_pair(gpmi_ctx* c, Lane& L, int k) {
     const uint32_t bits = (c->pair_cus[k] >= 32) ? 0xffffffffu : ((1u << c->pair_cus[k]) - 1u);
     panel[0] = bits;
     upd[0] = ~bits;
-    if (hipExtStreamCreateWithCUMask(&mp.sp, (uint32_t)panel.size(), panel.data()) != hipSuccess ||
-        hipExtStreamCreateWithCUMask(&mp.su, (uint32_t)upd.size(), upd.data()) != hipSuccess) {
-      mp.sp = mp.su = nullptr;  // a half-created pair is left alone (see above)
+    if (hipExtStreamCreateWithCUMask(&L.sp[k], (uint32_t)panel.size(), panel.data()) != hipSuccess ||
+        hipExtStreamCreateWithCUMask(&L.su[k], (uint32_t)upd.size(), upd.data()) != hipSuccess) {
+      if (L.sp[k]) (void)hipStreamDestroy(L.sp[k]);
+      if (L.su[k]) (void)hipStreamDestroy(L.su[k]);
+      L.sp[k] = L.su[k] = nullptr;  // no look-ahead: everything on the full-chip stream
       (void)hipGetLastError();
     }
   }
-  L.sp[k] = mp.sp;
-  L.su[k] = mp.su;
-  return L.sp[k] != nullptr;
+  return GPMI_OK;
 }
+
+}  // namespace
 
 namespace {
 
 int lane_alloc(gpmi_ctx* c, Lane& L) {
   if (int rc = lane_streams(c, L)) return rc;
+  // lanes[0] or lanes[1] (the lane has just been appended) of a problem large enough to ever enter the look-ahead
+  // regime: destroying a CU-masked stream takes the runtime about a second, which small models (a GpOptimiser
+  // builds a new regressor per added evaluation) should not pay
+  if (c->lanes.size() <= 2 && c->np >= 40 * GPMI_NB)
+    if (int rc = lane_masked_streams(c, L)) return rc;
   const int64_t nt = c->np / GPMI_NB;
   HIPCHK(c, hipMalloc(&L.A, sizeof(double) * c->np * c->ld));
   HIPCHK(c, hipMalloc(&L.invD, sizeof(double) * nt * GPMI_NB * GPMI_NB));
@@ -136,7 +135,21 @@ void lane_free(Lane& L) {
   if (L.ev_panel) (void)hipEventDestroy(L.ev_panel);
   if (L.ev_join) (void)hipEventDestroy(L.ev_join);
   if (L.ev_main) (void)hipEventDestroy(L.ev_main);
-  // the masked streams belong to the process-wide pool (ensure_masked_pair): not destroyed here
+  DBG_FREE("lane: destroy masked streams");
+  // hipStreamDestroy on a CU-masked stream blocks forever on ROCm 7.2 when it follows the stream's last
+  // synchronisation too closely (tools/probe_exit.py: 1 hang in 6 closes without the pause, 0 in 36 with 5 .. 300 ms; the round-1
+  // library only got away with it because loading librccl happened to sit in between)
+  if (L.sp[0] || L.su[0]) {
+    static const int pause_ms = [] {
+      const char* e = std::getenv("GPMI_DESTROY_PAUSE_MS");
+      return e ? std::atoi(e) : 50;
+    }();
+    std::this_thread::sleep_for(std::chrono::milliseconds(pause_ms));
+  }
+  for (int k = 0; k < GPMI_NPAIRS; ++k) {
+    if (L.sp[k]) (void)hipStreamDestroy(L.sp[k]);
+    if (L.su[k]) (void)hipStreamDestroy(L.su[k]);
+  }
   DBG_FREE("lane: free buffers");
   if (L.A) (void)hipFree(L.A);
   if (L.B2) (void)hipFree(L.B2);
@@ -467,6 +480,9 @@ int gpmi_create(int device, gpmi_ctx** out) {
 int gpmi_destroy(gpmi_ctx* c) {
   if (!c) return GPMI_OK;
   (void)hipSetDevice(c->device);
+  // every stream of the handle synchronised once here and once more in lane_free: hipStreamDestroy on a CU-masked
+  // stream that has only been synchronised once blocked forever on ROCm 7.2 (tools/probe_exit.py)
+  (void)gpmi_sync(c);
   DBG_FREE("comm destroy");
   (void)gpmi_comm_destroy(c);
   DBG_FREE("free data");

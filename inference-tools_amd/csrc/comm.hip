@@ -148,8 +148,10 @@ int gpmi_comm_allgather(gpmi_ctx* c, const double* send_host, double* recv_host,
 
 int gpmi_comm_destroy(gpmi_ctx* c) {
   if (!c) return GPMI_ERR_ARG;
-  Rccl* r = rccl();
-  if (r && c->comm) r->comm_destroy(c->comm);
+  if (c->comm) {  // librccl is only ever loaded by a handle that asked for a communicator
+    Rccl* r = rccl();
+    if (r) r->comm_destroy(c->comm);
+  }
   c->comm = nullptr;
   if (c->comm_buf) (void)hipFree(c->comm_buf);
   c->comm_buf = nullptr;

@@ -36,11 +36,10 @@ struct ProfSlot {
 // One independent evaluation lane: a stream with its own n x n scratch matrix and vectors.
 struct Lane {
   hipStream_t stream = nullptr;    // full-chip stream: covariance build, solves, small factorisations
-  // look-ahead pairs (CU-masked, disjoint; created on first use): pair k factors the next panel on
+  // look-ahead pairs (CU-masked, disjoint; lanes 0 and 1 only, created with the lane): pair k factors the next panel on
   // gpmi_ctx::pair_cus[k] CUs (sp) while the trailing update runs on all the others (su)
   hipStream_t sp[GPMI_NPAIRS] = {nullptr};
   hipStream_t su[GPMI_NPAIRS] = {nullptr};
-  bool masked_tried[GPMI_NPAIRS] = {false};
   hipEvent_t ev_la = nullptr, ev_panel = nullptr, ev_join = nullptr, ev_main = nullptr;
   double* A = nullptr;      // np x ld scratch (K then L)
   double* invD = nullptr;   // (np/128) x 128 x 128 inverses of the diagonal blocks
