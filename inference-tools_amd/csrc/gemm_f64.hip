@@ -75,8 +75,16 @@ __device__ inline int xcd_remap(int b, int nwg) {
 template <int TILES>
 __device__ inline void tile_of(int id, int ntr, int ntc, int& ti, int& tj) {
   if (TILES == TILES_RECT) {
-    ti = id / ntc;
-    tj = id - ti * ntc;
+    if (ntr <= 16 && ntc > ntr) {
+      // few tile rows, many columns (the many-right-hand-side solves: 8 x 124 tiles): column-major, so that the
+      // contiguous chunk of an XCD is a set of COLUMNS - its B panels (rows of L) are fetched once by that XCD alone,
+      // the few A panels are shared by all; row-major, every XCD streamed all of L's panel through its L2
+      tj = id / ntr;
+      ti = id - tj * ntr;
+    } else {
+      ti = id / ntc;
+      tj = id - ti * ntc;
+    }
   } else {
     int c0 = 0;
     for (;;) {
@@ -330,8 +338,16 @@ __global__ __launch_bounds__(256, GPMI_DMA_WGS) void gemm_dma_kernel(GemmArgs g)
   const int q0 = (slot - 2 * ((row0 >> 2) & 3)) & 3;          // rows row0 and row0 + 64 have the same (row >> 2) & 3
   const double* a_src0 = Ag + (int64_t)row0 * g.lda + 2 * q0;
   const double* a_src1 = a_src0 + (int64_t)64 * g.lda;
-  const double* b_src0 = Bg + (int64_t)row0 * g.ldb + 2 * q0;
-  const double* b_src1 = b_src0 + (int64_t)64 * g.ldb;
+  // B rows (= columns of C) are permuted on their way into LDS: LDS row 16 t + fr of a wave column block holds
+  // column 2 fr + t (t < 2) or 32 + 2 fr + t - 2 of that block, so that MFMA tiles (j, j + 1) of a lane are two
+  // ADJACENT columns of C: the C tile is read and written with 16-byte accesses, 256 contiguous bytes per row and
+  // instruction, half as many instructions as the 8-byte form
+  auto bperm = [](int R) {
+    const int t = (R >> 4) & 3, f = R & 15;
+    return (R & 64) + ((t & 2) << 4) + 2 * f + (t & 1);
+  };
+  const double* b_src0 = Bg + (int64_t)bperm(row0) * g.ldb + 2 * q0;
+  const double* b_src1 = Bg + (int64_t)bperm(row0 + 64) * g.ldb + 2 * q0;
   const unsigned lds0 = (unsigned)(uintptr_t)smem;  // LDS byte address of the ring (address space 3 pointers are offsets)
   const unsigned wave_off = (unsigned)__builtin_amdgcn_readfirstlane(wave * 64 * 16);
   auto issue = [&](int st, int k0) {
@@ -358,10 +374,15 @@ __global__ __launch_bounds__(256, GPMI_DMA_WGS) void gemm_dma_kernel(GemmArgs g)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc[i][j][r] = (OP == OP_SUB) ? GPMI_C_LOAD(&Cg[(int64_t)(i * 16 + fk + 4 * r) * g.ldc + j * 16 + fr]) : 0.0;
+      for (int r = 0; r < 4; ++r) {
+        d2_t cv = d2_t{0.0, 0.0};
+        if (OP == OP_SUB)
+          cv = GPMI_C_LOAD(reinterpret_cast<const d2_t*>(&Cg[(int64_t)(i * 16 + fk + 4 * r) * g.ldc + jp * 32 + 2 * fr]));
+        acc[i][2 * jp][r] = cv[0];
+        acc[i][2 * jp + 1][r] = cv[1];
+      }
 
   const int rslot = (fk + 2 * (fr >> 2)) & 3;
   const int a_off = ((wr * 64 + fr) * 4 + rslot) * 2;                      // doubles
@@ -409,9 +430,11 @@ __global__ __launch_bounds__(256, GPMI_DMA_WGS) void gemm_dma_kernel(GemmArgs g)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) GPMI_C_STORE(acc[i][j][r], &Cg[(int64_t)(i * 16 + fk + 4 * r) * g.ldc + j * 16 + fr]);
+      for (int r = 0; r < 4; ++r)
+        GPMI_C_STORE((d2_t{acc[i][2 * jp][r], acc[i][2 * jp + 1][r]}),
+                     reinterpret_cast<d2_t*>(&Cg[(int64_t)(i * 16 + fk + 4 * r) * g.ldc + jp * 32 + 2 * fr]));
   if (stamp_end) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     g.stamp[8 + (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 7)] = __builtin_amdgcn_s_memrealtime();
