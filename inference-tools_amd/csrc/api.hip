@@ -80,14 +80,15 @@ int lane_masked_streams(gpmi_ctx* c, Lane& L) {
   const int ncu = c->ncu;
   if (ncu < 64 || ncu % 32 != 0) return GPMI_OK;
   for (int k = 0; k < GPMI_NPAIRS; ++k) {
-    if (const char* e = std::getenv("GPMI_PANEL_CUS")) {  // tuning aid: CUs of the panel stream (8, 16, 24 or 32)
+    if (const char* e = std::getenv("GPMI_PANEL_CUS")) {  // tuning aid: CUs of the panel stream (a multiple of 8)
       const int v = std::atoi(e);
-      if (v >= 8 && v <= 32 && v % 8 == 0) c->pair_cus[k] = v;
+      if (v >= 8 && v <= ncu / 2 && v % 8 == 0) c->pair_cus[k] = v;
     }
     std::vector<uint32_t> panel((size_t)ncu / 32, 0u), upd((size_t)ncu / 32, 0xffffffffu);
-    const uint32_t bits = (c->pair_cus[k] >= 32) ? 0xffffffffu : ((1u << c->pair_cus[k]) - 1u);
-    panel[0] = bits;
-    upd[0] = ~bits;
+    for (int i = 0; i < c->pair_cus[k]; ++i) {
+      panel[(size_t)i / 32] |= 1u << (i % 32);
+      upd[(size_t)i / 32] &= ~(1u << (i % 32));
+    }
     if (hipExtStreamCreateWithCUMask(&L.sp[k], (uint32_t)panel.size(), panel.data()) != hipSuccess ||
         hipExtStreamCreateWithCUMask(&L.su[k], (uint32_t)upd.size(), upd.data()) != hipSuccess) {
       if (L.sp[k]) (void)hipStreamDestroy(L.sp[k]);
