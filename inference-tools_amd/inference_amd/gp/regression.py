@@ -287,7 +287,9 @@ class GpRegressor:
         optimisation.py:177-186 builds a new GpRegressor per added evaluation)."""
         x_new = np.asarray(x_new, dtype=float).reshape(1, self.n_dimensions)
         y_new = float(np.asarray(y_new).squeeze())
-        if (self._noise_var is None) != (y_err_new is None) and self._y_cov is None:
+        if self._y_cov is not None:
+            raise NotImplementedError("add_point with a dense y_cov: rebuild the regressor instead")
+        if (self._noise_var is None) != (y_err_new is None):
             raise ValueError("y_err_new must be given exactly when the model was built with y_err")
         var_new = 0.0 if y_err_new is None else float(np.asarray(y_err_new).squeeze()) ** 2
         fast = (not self._generic and self._mix is None and self._het_slice is None and self._y_cov is None
@@ -301,8 +303,6 @@ class GpRegressor:
         self.mean.pass_spatial_data(self.x)  # Linear / Quadratic means are centred on the data: all prior means move
         self._K_cache = self._L_cache = None
         if not fast:
-            if self._y_cov is not None:
-                raise NotImplementedError("add_point with a dense y_cov: rebuild the regressor instead")
             if self._engine is not None:
                 self._engine.close()
             self._engine = None
