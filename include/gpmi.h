@@ -301,7 +301,7 @@ int gpmi_solve_rows(gpmi_ctx* ctx, const double* Q_host, int64_t m, double* X_ho
 int gpmi_timer_start(gpmi_ctx* ctx);
 int gpmi_timer_stop(gpmi_ctx* ctx, float* ms);
 /* per-kernel-class accounting: when enabled every launch of the class is bracketed by events; the two
- * trailing-update classes (SYRK, SYRK_REST) are timed by in-kernel stamps instead and cost nothing */
+ * trailing-update classes (SYRK, SYRK_REST, SYRK_SLICE) are timed by in-kernel stamps instead and cost nothing */
 #define GPMI_PROF_KBUILD 0  /* covariance build            (HBM-write bound) */
 #define GPMI_PROF_SYRK 1    /* potrf trailing SYRK/GEMM    (fp64 MFMA bound) */
 #define GPMI_PROF_PANEL 2   /* potrf diagonal block + panel TRSM (latency bound) */
@@ -309,7 +309,9 @@ int gpmi_timer_stop(gpmi_ctx* ctx, float* ms);
 #define GPMI_PROF_SYRK_REST 4 /* trailing-update launches that do not run the 128 x 128-tile kernel: the 64 x 64-tile
                                  remainder of a split launch and the launches with fewer than 384 tiles */
 #define GPMI_PROF_TRSM 5    /* many right-hand side solves: predict, posterior, L^-T (fp64 MFMA bound) */
-#define GPMI_PROF_NCLASS 6
+#define GPMI_PROF_SYRK_SLICE 6 /* the tiles of a trailing update that run, concurrently with the rest, on the 32 CUs
+                                  reserved for the panel chain (same 128 x 128-tile kernel as SYRK) */
+#define GPMI_PROF_NCLASS 7
 /* on = 0: off; 1: every class; otherwise a class bitmask shifted left by one (2 << klass) */
 int gpmi_profile_enable(gpmi_ctx* ctx, int on);
 /* accumulated since the last reset: launches, total ms, algorithmic flops and bytes */

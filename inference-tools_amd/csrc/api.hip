@@ -57,6 +57,7 @@ int lane_streams(gpmi_ctx* c, Lane& L) {
   HIPCHK(c, hipEventCreateWithFlags(&L.ev_panel, hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&L.ev_main, hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&L.ev_slice, hipEventDisableTiming));
   return GPMI_OK;
 }
 
@@ -136,6 +137,7 @@ void lane_free(Lane& L) {
   if (L.ev_panel) (void)hipEventDestroy(L.ev_panel);
   if (L.ev_join) (void)hipEventDestroy(L.ev_join);
   if (L.ev_main) (void)hipEventDestroy(L.ev_main);
+  if (L.ev_slice) (void)hipEventDestroy(L.ev_slice);
   DBG_FREE("lane: destroy masked streams");
   // hipStreamDestroy on a CU-masked stream blocks forever on ROCm 7.2 when it follows the stream's last
   // synchronisation too closely (tools/probe_exit.py: 1 hang in 6 closes without the pause, 0 in 36 with 5 .. 300 ms; the round-1
@@ -423,7 +425,9 @@ unsigned long long* prof_stamp_slot(gpmi_ctx* c, double flops, double bytes, int
 
 ProfScope::ProfScope(gpmi_ctx* ctx, hipStream_t st, int klass, double flops, double bytes)
     : c(ctx), s(st), slot(nullptr) {
-  if (!((c->prof_mask >> klass) & 1) || klass == GPMI_PROF_SYRK || klass == GPMI_PROF_SYRK_REST) return;
+  if (!((c->prof_mask >> klass) & 1) || klass == GPMI_PROF_SYRK || klass == GPMI_PROF_SYRK_REST ||
+      klass == GPMI_PROF_SYRK_SLICE)
+    return;
   if (c->prof_used == c->prof_slots.size()) {
     ProfSlot ns{};
     if (hipEventCreate(&ns.e0) != hipSuccess || hipEventCreate(&ns.e1) != hipSuccess) return;

@@ -54,7 +54,8 @@ struct GemmArgs {
   int64_t sC, sA, sB;  // batch strides (doubles): problem blockIdx.z works on C + z sC, A + z sA, B + z sB
   // split > 0 (64 x 64 kernels only): this launch covers the 128 x 128 tiles [tile_base, ..) of the
   // (ntr / 2) x (ntc / 2) tile grid, four workgroups per tile (the tail of a launch whose other tiles run as
-  // full 128 x 128 tiles, see launch_gemm_nt_split)
+  // full 128 x 128 tiles, see launch_gemm_nt_split).  split == 0: the launch covers the tiles [tile_base, tile_base +
+  // gridDim.x) of the logical tile list (launch_gemm_nt_range; 0 for whole products)
   int split, tile_base;
 };
 
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     ti = 2 * bi + ((wid >> 1) & 1);
     tj = 2 * bj + (wid & 1);
   } else {
-    tile_of<TILES>(wid, g.ntr, g.ntc, ti, tj);
+    tile_of<TILES>(g.tile_base + wid, g.ntr, g.ntc, ti, tj);
   }
 
   const int tid = threadIdx.x;
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256, GPMI_DMA_WGS) void gemm_dma_kernel(GemmArgs g)
   __shared__ double smem[DMA_STAGES * 2 * DMA_OP_DOUBLES];
   int ti, tj;
   // k-skipped launches have tiles of very different length: dealt round-robin over the XCDs (see gemm_nt_kernel)
-  tile_of<TILES>(g.kskip ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x), g.ntr, g.ntc, ti, tj);
+  tile_of<TILES>(g.tile_base + (g.kskip ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x)), g.ntr, g.ntc, ti, tj);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool stamp_first = g.stamp && tid == 0 && blockIdx.x < 8;
   if (stamp_first) g.stamp[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
@@ -448,10 +449,11 @@ __global__ __launch_bounds__(256, GPMI_DMA_WGS) void gemm_dma_kernel(GemmArgs g)
 
 namespace {
 // part: 0 = the whole product; 1 = only the first `nfull` 128 x 128 tiles (as 128 x 128 tiles); 2 = only the
-// tiles from `nfull` on, as 64 x 64 tiles
+// tiles [nfull, nend) (nend < 0: to the last), as 64 x 64 tiles; 3 = the tiles [nfull, nend) as 128 x 128 tiles
 void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, int kskip, double* C,
                       int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb, int ntr,
-                      int ntc, int k, unsigned long long* stamp, const GemmBatch& bt, int part, int64_t nfull) {
+                      int ntc, int k, unsigned long long* stamp, const GemmBatch& bt, int part, int64_t nfull,
+                      int64_t nend = -1) {
   // ntr, ntc are in units of 128 rows / columns
   if (ntr <= 0 || ntc <= 0 || k <= 0) return;
   if (tiles == TILES_LOWER && ntc > ntr) ntc = ntr;
@@ -478,14 +480,16 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
     }
   }
   GemmArgs g{C, A, B, ldc, lda, ldb, ntr * (128 / bm), ntc * (128 / bn), k, kskip, stamp,
-             bt.sC, bt.sA, bt.sB, part == 2 ? 1 : 0, part == 2 ? (int)nfull : 0};
+             bt.sC, bt.sA, bt.sB, part == 2 ? 1 : 0, part >= 2 ? (int)nfull : 0};
   int64_t nwg;
   if (tiles == TILES_RECT)
     nwg = (int64_t)g.ntr * g.ntc;
   else
     nwg = (int64_t)g.ntc * (g.ntc + 1) / 2 + (int64_t)(g.ntr - g.ntc) * g.ntc;
   if (part == 1) nwg = nfull;
-  if (part == 2) nwg = 4 * (big - nfull);
+  if (nend < 0 || nend > big) nend = big;
+  if (part == 2) nwg = 4 * (nend - nfull);
+  if (part == 3) nwg = nend - nfull;
   if (nwg <= 0) return;
   dim3 grid((unsigned)nwg, 1, (unsigned)bt.count), block(256);
   // full 128 x 128 tiles with K-contiguous operands take the LDS-DMA ring kernel (GPMI_GEMM_NO_DMA=1: the
@@ -557,17 +561,29 @@ int64_t gemm_split_point(int64_t T, int ncu, int k) {
 
 void launch_gemm_nt_split(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc, const double* A,
                           int64_t lda, const double* B, int64_t ldb, int ntr, int ntc, int k, int64_t nfull,
-                          unsigned long long* stamp, unsigned long long* stamp_rest) {
+                          unsigned long long* stamp, unsigned long long* stamp_rest, int64_t nend) {
   if (tiles == TILES_LOWER && ntc > ntr) ntc = ntr;
   const int64_t T = (tiles == TILES_RECT) ? (int64_t)ntr * ntc
                                           : (int64_t)ntc * (ntc + 1) / 2 + (int64_t)(ntr - ntc) * ntc;
   const GemmBatch one{};
+  if (nend < 0 || nend > T) nend = T;
   if (nfull >= T) {
     launch_gemm_part(s, tiles, op, false, 0, C, ldc, A, lda, B, ldb, ntr, ntc, k, stamp, one, 0, 0);
     return;
   }
   launch_gemm_part(s, tiles, op, false, 0, C, ldc, A, lda, B, ldb, ntr, ntc, k, stamp, one, 1, nfull);
-  launch_gemm_part(s, tiles, op, false, 0, C, ldc, A, lda, B, ldb, ntr, ntc, k, stamp_rest, one, 2, nfull);
+  if (nend > nfull)
+    launch_gemm_part(s, tiles, op, false, 0, C, ldc, A, lda, B, ldb, ntr, ntc, k, stamp_rest, one, 2, nfull, nend);
+}
+
+// the tiles [first, first + count) of the logical tile list as full 128 x 128 tiles (a slice of a product whose other
+// tiles another stream computes)
+void launch_gemm_nt_range(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc, const double* A,
+                          int64_t lda, const double* B, int64_t ldb, int ntr, int ntc, int k, int64_t first,
+                          int64_t count, unsigned long long* stamp) {
+  if (count <= 0) return;
+  const GemmBatch one{};
+  launch_gemm_part(s, tiles, op, false, 0, C, ldc, A, lda, B, ldb, ntr, ntc, k, stamp, one, 3, first, first + count);
 }
 
 void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc,

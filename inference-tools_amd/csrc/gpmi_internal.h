@@ -40,7 +40,7 @@ struct Lane {
   // gpmi_ctx::pair_cus[k] CUs (sp) while the trailing update runs on all the others (su)
   hipStream_t sp[GPMI_NPAIRS] = {nullptr};
   hipStream_t su[GPMI_NPAIRS] = {nullptr};
-  hipEvent_t ev_la = nullptr, ev_panel = nullptr, ev_join = nullptr, ev_main = nullptr;
+  hipEvent_t ev_la = nullptr, ev_panel = nullptr, ev_join = nullptr, ev_main = nullptr, ev_slice = nullptr;
   double* A = nullptr;      // np x ld scratch (K then L)
   double* invD = nullptr;   // (np/128) x 128 x 128 inverses of the diagonal blocks
   double* B2 = nullptr;     // second np x ld matrix (L^-T for the gradient / LOO paths), allocated lazily
@@ -222,11 +222,16 @@ void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_
 
 // balanced form of launch_gemm_nt for big launches (gemm_f64.hip): the first `nfull` = gemm_split_point(T, ncu, k)
 // tiles run as 128 x 128 tiles, the tiles of the nearly empty last round as 64 x 64 tiles in a second launch;
-// `stamp` times the first launch only
+// `stamp` times the first launch only.  nend >= 0: the product stops at logical tile `nend` - the tiles from there on
+// are somebody else's (launch_gemm_nt_range on another stream)
 int64_t gemm_split_point(int64_t T, int ncu, int k);
 void launch_gemm_nt_split(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc, const double* A,
                           int64_t lda, const double* B, int64_t ldb, int ntr, int ntc, int k, int64_t nfull,
-                          unsigned long long* stamp = nullptr, unsigned long long* stamp_rest = nullptr);
+                          unsigned long long* stamp = nullptr, unsigned long long* stamp_rest = nullptr,
+                          int64_t nend = -1);
+void launch_gemm_nt_range(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc, const double* A,
+                          int64_t lda, const double* B, int64_t ldb, int ntr, int ntc, int k, int64_t first,
+                          int64_t count, unsigned long long* stamp = nullptr);
 
 // general form: b_kmajor -> B is (k x cols) row-major; kskip = 1 (TILES_LOWER) -> contraction starts at
 // the tile row's first column, kskip = 2 -> it ends with the tile column (B lower triangular)

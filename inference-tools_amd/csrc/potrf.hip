@@ -424,14 +424,16 @@ void factor_panel(gpmi_ctx* c, hipStream_t sp, double* A, int64_t ld, double* in
 
 // Update of the tile columns [t0, t1) (rows t0 .. nt, lower tiles) by the factored tile columns [ka, ke):
 // A[t0.., t0..t1) -= P P^T with P = A[t0.., ka..ke), K = (ke - ka) * 128.
+// `slice` > 0: the last `slice` tiles of the logical tile list are left out (update_slice applies them on another
+// stream)
 void update_columns(gpmi_ctx* c, hipStream_t s, double* A, int64_t ld, int nt, int t0, int t1, int ka, int ke,
-                    int ncu) {
+                    int ncu, int64_t slice = 0) {
   const int rows = nt - t0, cols = t1 - t0;
   const int kw = (ke - ka) * NB;
   if (rows <= 0 || cols <= 0 || kw <= 0) return;
   double* P = A + (int64_t)t0 * NB * ld + (int64_t)ka * NB;
   double* C = A + (int64_t)t0 * NB * ld + (int64_t)t0 * NB;
-  const int64_t tiles = (int64_t)cols * (cols + 1) / 2 + (int64_t)(rows - cols) * cols;
+  const int64_t tiles = (int64_t)cols * (cols + 1) / 2 + (int64_t)(rows - cols) * cols - slice;
   // the tiles of a nearly empty last round (of `ncu` tiles) run as 64 x 64 tiles in a second launch
   const int64_t nfull = gemm_split_point(tiles, ncu, kw);
   // per-launch timing (bench roofline), every launch: the 128 x 128-tile kernel (launches with >= 384 tiles, their
@@ -451,9 +453,51 @@ void update_columns(gpmi_ctx* c, hipStream_t s, double* A, int64_t ld, int nt, i
     stamp_rest = prof_stamp_slot(c, (double)(tiles - nmain) * 2.0 * NB * NB * kw, (double)(tiles - nmain) * 16.0 * NB * NB,
                                  GPMI_PROF_SYRK_REST);
   if (big)
-    launch_gemm_nt_split(s, TILES_LOWER, OP_SUB, C, ld, P, ld, P, ld, rows, cols, kw, nfull, stamp, stamp_rest);
+    launch_gemm_nt_split(s, TILES_LOWER, OP_SUB, C, ld, P, ld, P, ld, rows, cols, kw, nfull, stamp, stamp_rest, tiles);
   else
-    launch_gemm_nt_split(s, TILES_LOWER, OP_SUB, C, ld, P, ld, P, ld, rows, cols, kw, nfull, stamp_rest);
+    launch_gemm_nt_split(s, TILES_LOWER, OP_SUB, C, ld, P, ld, P, ld, rows, cols, kw, nfull, stamp_rest, nullptr, tiles);
+}
+
+// the last `slice` tiles of the same update (full 128 x 128 tiles, the dominant kernel; class SYRK_SLICE)
+void update_slice(gpmi_ctx* c, hipStream_t s, double* A, int64_t ld, int nt, int t0, int t1, int ka, int ke,
+                  int64_t slice) {
+  const int rows = nt - t0, cols = t1 - t0;
+  const int kw = (ke - ka) * NB;
+  double* P = A + (int64_t)t0 * NB * ld + (int64_t)ka * NB;
+  double* C = A + (int64_t)t0 * NB * ld + (int64_t)t0 * NB;
+  const int64_t tiles = (int64_t)cols * (cols + 1) / 2 + (int64_t)(rows - cols) * cols;
+  unsigned long long* stamp =
+      prof_stamp_slot(c, (double)slice * 2.0 * NB * NB * kw, (double)slice * 16.0 * NB * NB + 8.0 * rows * NB * kw,
+                      GPMI_PROF_SYRK_SLICE);
+  launch_gemm_nt_range(s, TILES_LOWER, OP_SUB, C, ld, P, ld, P, ld, rows, cols, kw, tiles - slice, slice, stamp);
+}
+
+// How many tiles of a trailing update the panel stream takes over.  The panel chain of the next panel leaves the
+// reserved CUs idle for the rest of the update (half of it while the trailing matrix is large); a slice of the
+// update's last tiles (the far-right column strips, which neither the next look-ahead update nor the next panel
+// touch) runs there behind the chain.  Cost model in microseconds, fitted to the measured timeline
+// (profiles/r02_bench_timeline.txt): 64.4 us per tile and CU pair slot at K = 512 (0.29 us per tile on 224 CUs, 2.0 on
+// 32), the chain 200 + 7.6 us per trailing tile row; the slice takes GPMI_SLICE_PCT % (default 100; 0: none) of the
+// balance point, rounded down to whole rounds of the reserved CUs.  Measured: 36.4 -> 35.9 ms per step at 100 and 130 %,
+// 37.0 at 160 % (the next update then waits for the slice); the 32 extra CUs lower the clock of the other 224 from
+// 2.364 to 2.352 GHz (the update runs at the chip's power limit), which is why the gain is a third of the idle time.
+int64_t slice_tiles(int rem, int64_t tiles_la, int64_t tiles_main, int kw, int ncu_main, int ncu_panel) {
+  static const int PCT = [] {
+    const char* e = std::getenv("GPMI_SLICE_PCT");
+    return e ? std::atoi(e) : 100;
+  }();
+  if (PCT <= 0 || kw != 4 * NB) return 0;
+  const double tile_us = 64.4 * 2.0;  // one CU works on two tiles at a time
+  const double per_main = tile_us / (2.0 * ncu_main), per_panel = tile_us / (2.0 * ncu_panel);
+  const double chain = 200.0 + 7.6 * rem;
+  const double su = 20.0 + (double)(tiles_la + tiles_main) * per_main;
+  double x = (su - chain) / (per_main + per_panel) * PCT / 100.0;
+  const int64_t round = 2 * ncu_panel;
+  int64_t n = x > 0 ? (int64_t)(x / round) * round : 0;
+  // never into the first column strip (8 tile columns): the next look-ahead update and panel work there
+  const int64_t safe = tiles_main - (int64_t)8 * rem;
+  if (n > safe) n = safe > 0 ? safe / round * round : 0;
+  return n;
 }
 
 }  // namespace
@@ -492,6 +536,7 @@ void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, dou
   factor_panel(c, sf, A, ld, invD, info, nt, 0, tile0(1));
   hipStream_t panel_stream = sf;  // where the latest panel was factored (ev_panel recorded behind it)
   hipStream_t main_stream = sf;   // where the latest trailing update ran (ev_main recorded behind it)
+  bool sliced = false;            // a slice of the latest update is in flight on the panel stream (ev_slice)
   (void)hipEventRecord(lane.ev_panel, sf);
   (void)hipEventRecord(lane.ev_main, sf);
   for (int p = 0; p + 1 < NP; ++p) {
@@ -502,22 +547,38 @@ void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, dou
     const int ncu = overlap ? c->ncu - c->pair_cus[0] : c->ncu;
     follow(su, panel_stream, lane.ev_panel);
     follow(su, main_stream, lane.ev_main);
+    int64_t slice = 0;
     if (overlap) {
-      update_columns(c, su, A, ld, nt, k1, tile0(p + 2), k0, k1, ncu);  // the columns of the next panel first
+      const int k2 = tile0(p + 2);
+      update_columns(c, su, A, ld, nt, k1, k2, k0, k1, ncu);  // the columns of the next panel first
       (void)hipEventRecord(lane.ev_la, su);
       (void)hipStreamWaitEvent(sp, lane.ev_la, 0);
-      update_columns(c, su, A, ld, nt, tile0(p + 2), nt, k0, k1, ncu);
+      const int w = k2 - k1, r2 = nt - k2;
+      slice = slice_tiles(rem, (int64_t)w * (w + 1) / 2 + (int64_t)(rem - w) * w, (int64_t)r2 * (r2 + 1) / 2,
+                          (k1 - k0) * NB, ncu, c->pair_cus[0]);
+      // the previous slice wrote tiles of this update's region
+      if (sliced) (void)hipStreamWaitEvent(su, lane.ev_slice, 0);
+      update_columns(c, su, A, ld, nt, k2, nt, k0, k1, ncu, slice);
       (void)hipEventRecord(lane.ev_main, su);
     } else {
+      if (sliced) (void)hipStreamWaitEvent(su, lane.ev_slice, 0);
       update_columns(c, su, A, ld, nt, k1, nt, k0, k1, ncu);
     }
+    sliced = false;
     main_stream = su;
     factor_panel(c, sp, A, ld, invD, info, nt, k1, tile0(p + 2));
     if (overlap) (void)hipEventRecord(lane.ev_panel, sp);
     panel_stream = sp;
+    if (slice > 0) {
+      // behind the panel chain on the reserved CUs; ordered after the previous update by ev_la (recorded behind it)
+      update_slice(c, sp, A, ld, nt, tile0(p + 2), nt, k0, k1, slice);
+      (void)hipEventRecord(lane.ev_slice, sp);
+      sliced = true;
+    }
   }
   follow(sf, panel_stream, lane.ev_panel);
   follow(sf, main_stream, lane.ev_main);
+  if (sliced) (void)hipStreamWaitEvent(sf, lane.ev_slice, 0);
 }
 
 void potrf_lower_batched(gpmi_ctx* c, hipStream_t s, double* A, int64_t np, int64_t ld, double* invD,
