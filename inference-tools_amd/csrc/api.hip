@@ -1186,11 +1186,18 @@ static int profile_collect(gpmi_ctx* c) {
         if (w[8 + j] > t1) t1 = w[8 + j];
       }
       if (t1 <= t0) continue;  // launch never ran
+      const int kl = c->stamp_class[i];
+      if (kl >= GPMI_PROF_NCLASS) {  // GPMI_CHAIN_TRACE (potrf.hip): 0 potrf_diag, 1 panel TRSM, 2 inner update
+        static unsigned long long origin = 0;
+        if (!origin || kl == GPMI_PROF_NCLASS + 3) origin = t0;
+        std::fprintf(stderr, "[chain] %d %.2f %.2f\n", kl - GPMI_PROF_NCLASS, (double)(t0 - origin) * 0.01,
+                     (double)(t1 - origin) * 0.01);
+        continue;
+      }
       for (int j = 0; j < 8; ++j) {
         c->prof_clock_cycles += (double)(w[16 + j] >> 32);
         c->prof_clock_ticks += (double)(w[16 + j] & 0xffffffffull);
       }
-      const int kl = c->stamp_class[i];
       c->prof_ms[kl] += (double)(t1 - t0) * 1e-5;  // 10 ns ticks -> ms
       c->prof_flops[kl] += c->stamp_flops[i];
       c->prof_bytes[kl] += c->stamp_bytes[i];
@@ -1277,13 +1284,14 @@ int gpmi_dev_potrf(gpmi_ctx* c, double* A, int64_t n, int64_t ld, int* info) {
   if (n == GPMI_NB && std::getenv("GPMI_DIAG_STAMPS")) {
     // tools only: phase cycle counts of one potrf_diag launch
     unsigned long long* dbg = nullptr;
-    HIPCHK(c, hipMalloc(&dbg, 6 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&dbg, GPMI_STAMP_WORDS * sizeof(unsigned long long)));
     launch_potrf_diag(s, A, ld, invD, dinfo, 0, dbg);
-    unsigned long long h[6];
+    unsigned long long hw[GPMI_STAMP_WORDS];
     HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
-    std::fprintf(stderr, "[potrf_diag cycles] load %llu | wave 0 waits at the barrier %llu | sub-diagonal panel + trailing tile %llu | end %llu | factor16 x8 %llu | %llu\n",
-                 h[0], h[1], h[2], h[3], h[4], h[5]);
+    HIPCHK(c, hipMemcpy(hw, dbg, sizeof(hw), hipMemcpyDeviceToHost));
+    const unsigned long long* h = hw + 16;
+    std::fprintf(stderr, "[potrf_diag] %.2f us | cycles: load %llu | wave 0 waits at the barrier %llu | sub-diagonal panel + trailing tile %llu | end %llu | factor16 x8 %llu | %llu\n",
+                 (double)(hw[8] - hw[0]) * 0.01, h[0], h[1], h[2], h[3], h[4], h[5]);
     (void)hipFree(dbg);
   } else
   potrf_lower(c, c->lanes[0], A, n, ld, invD, dinfo);

@@ -37,6 +37,10 @@ namespace {
 
 constexpr int BK = 16;
 constexpr int LDS_STRIDE = 18;  // doubles per staged row (16 + 2 pad)
+// operand slabs requested ahead of the MFMAs by the tiles smaller than 128 x 128 (see gemm_nt_kernel)
+#ifndef GPMI_SMALL_PF
+#define GPMI_SMALL_PF 4
+#endif
 
 struct GemmArgs {
   double* C;
@@ -169,31 +173,41 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   const int lkc_sw = lkc ^ ((((lrow & 15) >= 4) && ((lrow & 15) < 12)) ? 4 : 0);
   // k-major B: BN / 2 chunks per k-row, 512 / BN k-rows per pass
   const int nrow = tid / (BN / 2), nnc = (tid % (BN / 2)) * 2;
-  d2_t ra[TM], rb[TN];
-  auto gload = [&](int k0) {
+  // The small tiles serve launches that are bound by the time of ONE workgroup: a K loop of 8 .. 32 slabs, each a
+  // round trip to L2 or beyond (0.7 us) with a few MFMAs behind it.  They keep PF slabs in flight in a ring of staging
+  // registers (slot = slab % PF; the loop is unrolled PF times so that the slots are static) instead of one; the
+  // 128 x 128 tile (throughput-bound, 128 accumulator registers) keeps the single slab.
+  constexpr int PF = (BM * BN < 128 * 128) ? GPMI_SMALL_PF : 1;
+  d2_t ra[PF][TM], rb[PF][TN];
+  // per-lane byte offsets (32-bit: a tile spans < 2^32 bytes) against uniform slab bases: the loads take the
+  // SGPR-base + VGPR-offset form, no 64-bit address arithmetic per request
+  unsigned voa[TM], vob[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-      ra[i] = *reinterpret_cast<const d2_t*>(Ag + (int64_t)(lrow + 32 * i) * g.lda + k0 + lkc);
+  for (int i = 0; i < TM; ++i) voa[i] = (unsigned)(((int64_t)(lrow + 32 * i) * g.lda + lkc) * 8);
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      if (BKN)
-        rb[i] = *reinterpret_cast<const d2_t*>(Bg + (int64_t)(k0 + nrow + (512 / BN) * i) * g.ldb + nnc);
-      else
-        rb[i] = *reinterpret_cast<const d2_t*>(Bg + (int64_t)(lrow + 32 * i) * g.ldb + k0 + lkc);
-    }
+  for (int i = 0; i < TN; ++i)
+    vob[i] = BKN ? (unsigned)(((int64_t)(nrow + (512 / BN) * i) * g.ldb + nnc) * 8)
+                 : (unsigned)(((int64_t)(lrow + 32 * i) * g.ldb + lkc) * 8);
+  auto gload = [&](int k0, int slot) {
+    const char* ab = reinterpret_cast<const char*>(Ag + k0);
+    const char* bb = reinterpret_cast<const char*>(BKN ? Bg + (int64_t)k0 * g.ldb : Bg + k0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ra[slot][i] = *reinterpret_cast<const d2_t*>(ab + voa[i]);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) rb[slot][i] = *reinterpret_cast<const d2_t*>(bb + vob[i]);
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, int slot) {
     double* sa = smem + buf * BUF_DOUBLES;
     double* sb = sa + A_DOUBLES;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
-      *reinterpret_cast<d2_t*>(sa + (lrow + 32 * i) * LDS_STRIDE + lkc_sw) = (OP == OP_SUB) ? -ra[i] : ra[i];
+      *reinterpret_cast<d2_t*>(sa + (lrow + 32 * i) * LDS_STRIDE + lkc_sw) = (OP == OP_SUB) ? -ra[slot][i] : ra[slot][i];
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
       if (BKN)
-        *reinterpret_cast<d2_t*>(sb + (nrow + (512 / BN) * i) * LDS_STRIDE_KN + nnc) = rb[i];
+        *reinterpret_cast<d2_t*>(sb + (nrow + (512 / BN) * i) * LDS_STRIDE_KN + nnc) = rb[slot][i];
       else
-        *reinterpret_cast<d2_t*>(sb + (lrow + 32 * i) * LDS_STRIDE + lkc_sw) = rb[i];
+        *reinterpret_cast<d2_t*>(sb + (lrow + 32 * i) * LDS_STRIDE + lkc_sw) = rb[slot][i];
     }
   };
 
@@ -212,7 +226,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   // pending on an accumulator register, which keeps every vmcnt wait out of the loop proper (with a pending
   // C load at loop entry the compiler puts s_waitcnt vmcnt(0) in front of the MFMAs of the last
   // accumulators INSIDE the loop, i.e. a wait for the prefetch just issued, in every step).
-  gload(0);
+  const int nk = (kend - kbeg) / BK;
+  // requests beyond the last slab repeat it (an unconditional request keeps the loop free of branches around loads,
+  // which is what lets the compiler count the loads in flight instead of waiting for all of them)
+  const int klast = (nk - 1) * BK;
+  auto gload_clamped = [&](int kt, int slot) { gload(kt < nk ? kt * BK : klast, slot); };
+  // PF == 1 (128 x 128 tiles): slab 0 is requested BEFORE the C loads and the first step is peeled, see above.
+  // PF > 1: the C tile (16 loads per lane at most) goes first, so that the wait for slab 0 covers it and the loop
+  // starts in the state it has at its back edge (PF - 1 slabs in flight, nothing else).
+  if (PF == 1) gload(0, 0);
   d4_t acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -225,12 +247,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
         acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
       }
     }
-  sstore(0);
+  if (PF > 1) {
+    gload(0, 0);
+#pragma unroll
+    for (int p = 1; p < PF; ++p) gload_clamped(p, p);
+  }
+  sstore(0, 0);
   __syncthreads();
-  const int nk = (kend - kbeg) / BK;
-  auto kstep = [&](int kt) {
+  // step kt: slab kt is in LDS buffer kt & 1, slabs kt + 1 .. kt + PF - 1 are in flight or in their slots; slot
+  // kt % PF (slab kt went to LDS at the end of step kt - 1) takes the request for slab kt + PF
+  auto kstep = [&](int kt, int slot_free, int slot_next) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+    if (PF == 1) {
+      if (kt + 1 < nk) gload((kt + 1) * BK, 0);
+    } else {
+      gload_clamped(kt + PF, slot_free);
+    }
     const double* sa = smem + cur * BUF_DOUBLES;
     const double* sb = sa + A_DOUBLES;
     // lane (fr, fk) supplies k = 4 fk + q of the slab to MFMA step q (same map for A and B)
@@ -256,11 +288,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) sstore(cur ^ 1);
+    // PF > 1: unconditional (the last step stages a repeat of the last slab, which nobody reads)
+    if (PF > 1 || kt + 1 < nk) sstore(cur ^ 1, slot_next);
     __syncthreads();
   };
-  kstep(0);
-  for (int kt = 1; kt < nk; ++kt) kstep(kt);
+  if (PF == 1) {
+    kstep(0, 0, 0);
+    for (int kt = 1; kt < nk; ++kt) kstep(kt, 0, 0);
+  } else {
+    // groups of PF steps with static slots; the only branches are exits
+    for (int kb = 0; kb < nk; kb += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        if (kb + u >= nk) break;
+        kstep(kb + u, u, (1 + u) % PF);
+      }
+    }
+  }
 
   // End stamp (only the workgroups that can be the launch's last: dispatch is in order and tiles are uniform,
   // so the last one to finish is among the last two rounds of 512), taken behind the epilogue stores.
@@ -467,6 +511,10 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
     const char* e = std::getenv("GPMI_BIG_MIN");
     return (int64_t)(e ? std::atoi(e) : 384);
   }();
+  static const int64_t SMALL_M32_MAX = [] {
+    const char* e = std::getenv("GPMI_M32_MAX");
+    return (int64_t)(e ? std::atoi(e) : 192);
+  }();
   const bool small = part == 0 && ((k <= 128) || (big * bt.count < BIG_MIN));
   if (part == 2) {
     bm = 64;
@@ -477,6 +525,10 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
     } else if (!b_kmajor || op == OP_SUB) {
       bm = 64;
       bn = 64;
+      // fewer 64 x 64 tiles than three quarters of the CUs, and each of them long (K > 128: the products with the
+      // 512 x 512 inverse blocks on the chain of the many-right-hand-side solves, 128 workgroups x up to 13 us of
+      // MFMA time on one CU each): 32-row tiles put the same work on twice as many CUs
+      if (tiles == TILES_RECT && !b_kmajor && k > 128 && big * 4 * bt.count <= SMALL_M32_MAX) bm = 32;
     }
   }
   GemmArgs g{C, A, B, ldc, lda, ldb, ntr * (128 / bm), ntc * (128 / bn), k, kskip, stamp,
@@ -519,6 +571,8 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
     }
   } else if (bn == 128) {
     if (b_kmajor) GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 1, 64, 128); else GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0, 64, 128);
+  } else if (bm == 32) {
+    if (op == OP_SUB) GPMI_LAUNCH(TILES_RECT, OP_SUB, 0, 32, 64); else GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0, 32, 64);
   } else {
     if (tiles == TILES_RECT) {
       if (op == OP_SUB) {

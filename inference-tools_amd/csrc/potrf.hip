@@ -128,15 +128,17 @@ struct ElimStep<BS> {
 // same row operations applied to the identity give M^-1 (A = M D M^T); then
 // L[k][i] = U[i][k] / sqrt(p_i) and W = L^-1 = D^-1/2 M^-1 (to LDS for the panel phase and to the
 // diagonal block of invD in global memory); L itself also goes straight to the matrix in global memory.
+// `blk`: the block itself, lane (g = lane >> 4, k = lane & 15) element j = entry (4 j + g, k) - the D layout of the MFMA
+// that produced it (potrf_diag_kernel keeps it in registers from the trailing product to the elimination).
 __device__ inline void factor16(double* S, double* Wl, double* __restrict__ invD, double* __restrict__ A,
-                                int64_t ld, int kb, int* info, int col0, int lane) {
+                                int64_t ld, int kb, int* info, int col0, int lane, const d4_t& blk) {
   const int k = lane & 15, g = lane >> 4;
   const int base = kb * BS;
   Elim16 s;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int i = 4 * j + g;
-    s.a[j] = S[prow(base + i) + base + k];
+    s.a[j] = blk[j];
     s.e[j] = (i == k) ? 1.0 : 0.0;
   }
   s.k = k;
@@ -196,7 +198,9 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
   A += (int64_t)blockIdx.z * strideA;
   invD += (int64_t)blockIdx.z * strideInv;
   info += blockIdx.z;
-  // dbg != nullptr (tools only): cycle stamps of the phases, accumulated by wave 0
+  // dbg != nullptr (tools only; a 24-word stamp slot): word 0 / word 8 = wall clock (s_memrealtime) at the first
+  // instruction / behind the last store, words 16..21 = cycle counts of the phases, accumulated by wave 0
+  if (dbg && threadIdx.x == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
   unsigned long long t_prev = 0, acc_t[6] = {0, 0, 0, 0, 0, 0};
   auto lap = [&](int slot) {
     if (dbg) {
@@ -209,38 +213,49 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
   __shared__ double S[S_DOUBLES];
   __shared__ double Wl[2][BS * WP];
   __shared__ int sub_ready;   // wave 0: sub-diagonal tiles (k + 1, k) finished for k < sub_ready
-  __shared__ int panel_done;  // waves 1-3: 3 (k + 1) once every one of them has finished its panel tiles of column k
+  __shared__ int panel_done;  // waves 1-7: 7 (k + 1) once every one of them has finished its panel tiles of column k
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
   if (tid == 0) {
     sub_ready = 0;
     panel_done = 0;
   }
-  {
-    // coalesced 16-byte loads, all 16 of a thread in flight before the first LDS store: row = (tid >> 6) + 8 i,
-    // columns 2 (tid & 63) .. + 1.  Only the block-lower part is needed; the upper part of a diagonal
-    // 16-block is mirrored from the lower triangle of A (both copies written from the lower element).
-    const int cc = (tid & 63) * 2;
+  // Wave 0 starts the elimination chain at once: it fetches the first 16 x 16 block straight into the registers of
+  // factor16 (both triangles from the lower one).  Waves 1-7 meanwhile bring the block-lower part of the 128 x 128
+  // block into LDS (coalesced 16-byte loads, all of a thread's loads in flight before its first LDS store) -
+  // everything except block (0, 0), which wave 0 writes itself; the barrier of step 0 is the first point where
+  // anybody reads what somebody else loaded.
+  d4_t blk = {0.0, 0.0, 0.0, 0.0};  // wave 0: diagonal block kb, in factor16's layout
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = 4 * j + fk;  // entry (i, fr), from the lower triangle
+      blk[j] = A[(int64_t)(i > fr ? i : fr) * ld + (i > fr ? fr : i)];
+    }
+  } else {
+    // the strictly-upper 16-blocks of the inverse are zero (fire-and-forget stores, acknowledged while the loads are in flight)
+    for (int idx = tid - 64; idx < NB * NB / 2; idx += DIAG_THREADS - 64) {
+      const int r = idx >> 6, c = (idx & 63) * 2;
+      if ((c >> 4) > (r >> 4)) *reinterpret_cast<d2_t*>(invD + r * NB + c) = d2_t{0.0, 0.0};
+    }
+    // rows 16 .. 127, one 1 KiB row per wave and load, dealt round-robin to the seven waves (16 rows each); only the
+    // lower triangle is stored - the first readers of a diagonal 16-block (sub_chain, trailing_tile) take its upper
+    // entries from the mirror position
+    const int cc = lane * 2;
     d2_t v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int r = (tid >> 6) + 8 * i;
+      const int r = BS + (wave - 1) + DIAG_BULK * i;
       v[i] = (cc <= r) ? *reinterpret_cast<const d2_t*>(A + (int64_t)r * ld + cc) : d2_t{0.0, 0.0};
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int r = (tid >> 6) + 8 * i;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int c = cc + e;
-        if (c <= r) {
-          S[prow(r) + c] = v[i][e];
-          if ((c >> 4) == (r >> 4)) S[prow(c) + r] = v[i][e];  // mirror inside the diagonal block
-        }
-      }
+      const int r = BS + (wave - 1) + DIAG_BULK * i;
+      const int pr = prow(r) + cc;
+      if (cc <= r) S[pr] = v[i][0];
+      if (cc + 1 <= r) S[pr + 1] = v[i][1];
     }
   }
-  __syncthreads();
   lap(0);
 
   // A[ib][kb] <- A[ib][kb] * W_kb^T, to LDS and to the matrix in global memory
@@ -263,15 +278,18 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
     int rc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      rc[r] = prow(ib * BS + fk + 4 * r) + jb * BS + fr;
-      acc[r] = S[rc[r]];
+      const int i = fk + 4 * r;
+      rc[r] = prow(ib * BS + i) + jb * BS + fr;
+      // a diagonal tile is symmetric and only its lower triangle is kept up to date
+      acc[r] = S[(ib == jb && i < fr) ? prow(ib * BS + fr) + jb * BS + i : rc[r]];
     }
     const int ra = prow(ib * BS + fr) + kb * BS + fk, rb = prow(jb * BS + fr) + kb * BS + fk;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[ra + 4 * q], S[rb + 4 * q], acc, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) S[rc[r]] = acc[r];
+    for (int r = 0; r < 4; ++r)
+      if (ib != jb || fk + 4 * r >= fr) S[rc[r]] = acc[r];
   };
   auto wait_for = [&](int* counter, int target) {
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
@@ -281,6 +299,40 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
   auto signal = [&](int* counter, int add) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) __hip_atomic_fetch_add(counter, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  // wave 0, step kb: the sub-diagonal tile P = A[kb+1][kb] W^T and the trailing product of tile (kb+1, kb+1), without an
+  // LDS round trip between them: P is computed transposed (P^T = W A^T), which makes its D registers at once the A and
+  // the B operand of the trailing product (P[fr][fk + 4 q] = pt[q]); the result lands in factor16's layout and stays
+  // in registers.  (Same products, same summation order as panel_tile / trailing_tile.)
+  auto sub_chain_regs = [&](int kb, const d4_t& b, d4_t t) -> d4_t {
+    const double* W = Wl[kb & 1];
+    const int ib = kb + 1;
+    d4_t pt = {0.0, 0.0, 0.0, 0.0};
+    const int rb = prow(ib * BS + fr) + kb * BS + fk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      pt = __builtin_amdgcn_mfma_f64_16x16x4f64(W[fr * WP + fk + 4 * q], b[q], pt, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      S[rb + 4 * r] = pt[r];
+      A[(int64_t)(ib * BS + fr) * ld + kb * BS + fk + 4 * r] = pt[r];
+    }
+    signal(&sub_ready, 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t = __builtin_amdgcn_mfma_f64_16x16x4f64(-pt[q], pt[q], t, 0, 0, 0);
+    return t;
+  };
+  auto sub_chain = [&](int kb) -> d4_t {
+    const int ib = kb + 1;
+    d4_t t, b;
+    const int rb = prow(ib * BS + fr) + kb * BS + fk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = fk + 4 * r;  // entry (i, fr) of the symmetric tile: from the lower triangle
+      t[r] = S[prow(ib * BS + (i > fr ? i : fr)) + ib * BS + (i > fr ? fr : i)];
+      b[r] = S[rb + 4 * r];
+    }
+    return sub_chain_regs(kb, b, t);
   };
   // everything of step kb that is not on the elimination chain (waves 1-7)
   auto bulk = [&](int kb) {
@@ -338,32 +390,36 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
   };
 
   for (int kb = 0; kb < NBLK; ++kb) {
+    // The barrier of a step orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).  Global memory needs ordering
+    // for one thing: rows of the inverse are read back by bulk() in later steps.  The bulk waves fence their stores
+    // before the barrier; wave 0, whose diagonal block of step kb is first read in step kb + 2, fences at the TOP of
+    // its next step instead - by then the stores have long been acknowledged, and the 0.4 us of store latency a fence
+    // behind factor16 exposed in every step are off the chain.
     if (wave == 0) {
-      factor16(S, Wl[kb & 1], invD, A, ld, kb, info, col0, lane);
+      __threadfence_block();
+      factor16(S, Wl[kb & 1], invD, A, ld, kb, info, col0, lane, blk);
       lap(4);
-    } else if (kb > 0) {
-      bulk(kb - 1);
     } else {
-      // zero the strictly-upper 16-blocks of the inverse (nothing else to do during the first elimination)
-      for (int idx = tid - 64; idx < NB * NB / 2; idx += DIAG_THREADS - 64) {
-        const int r = idx >> 6, c = (idx & 63) * 2;
-        if ((c >> 4) > (r >> 4)) *reinterpret_cast<d2_t*>(invD + r * NB + c) = d2_t{0.0, 0.0};
-      }
+      if (kb > 0) bulk(kb - 1);
+      __threadfence_block();
     }
-    __threadfence_block();  // inverse rows written by bulk() are read back (through L2) in the next step
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     lap(1);
     if (wave == 0 && kb + 1 < NBLK) {
-      panel_tile(kb, kb + 1);
-      signal(&sub_ready, 1);
-      trailing_tile(kb, kb + 1, kb + 1);
+      blk = sub_chain(kb);
       lap(2);
     }
   }
   if (wave > 0) bulk(NBLK - 1);
   lap(3);
-  if (dbg && tid == 0)
-    for (int i = 0; i < 6; ++i) dbg[i] = acc_t[i];
+  if (dbg) {
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) {
+      for (int i = 0; i < 6; ++i) dbg[16 + i] = acc_t[i];
+      dbg[8] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
 }
 
 }  // namespace
@@ -396,6 +452,10 @@ namespace {
 // factor outer panel [J, Je): inner right-looking steps on stream sp
 void factor_panel(gpmi_ctx* c, hipStream_t sp, double* A, int64_t ld, double* invD, int* info, int nt,
                   int J, int Je) {
+  // GPMI_CHAIN_TRACE=1 (tools/chain_trace.py, with the profile enabled): in-kernel wall-clock stamps of every launch
+  // of the chain, printed by the next profile read
+  static const bool trace = std::getenv("GPMI_CHAIN_TRACE") != nullptr;
+  auto slot = [&](int tag) { return trace ? prof_stamp_slot(c, 0.0, 0.0, GPMI_PROF_NCLASS + tag) : nullptr; };
   for (int j = J; j < Je; ++j) {
     double* Ajj = A + (int64_t)j * NB * ld + (int64_t)j * NB;
     double* invDj = invD + (int64_t)j * NB * NB;
@@ -403,11 +463,11 @@ void factor_panel(gpmi_ctx* c, hipStream_t sp, double* A, int64_t ld, double* in
     {
       ProfScope ps(c, sp, GPMI_PROF_PANEL, (double)NB * NB * NB / 3.0 + 2.0 * below * NB * NB * NB,
                    8.0 * NB * NB * (2.0 + 2.0 * below));
-      launch_potrf_diag(sp, Ajj, ld, invDj, info, j * NB);
+      launch_potrf_diag(sp, Ajj, ld, invDj, info, j * NB, slot(0));
       if (below > 0) {
         // panel TRSM: A21 <- A21 * L11^-T  (in place: one tile column, see gemm_f64.hip)
         double* A21 = Ajj + (int64_t)NB * ld;
-        launch_gemm_nt(sp, TILES_RECT, OP_ASSIGN, A21, ld, A21, ld, invDj, NB, below, 1, NB);
+        launch_gemm_nt(sp, TILES_RECT, OP_ASSIGN, A21, ld, A21, ld, invDj, NB, below, 1, NB, slot(1));
       }
     }
     const int pc = Je - j - 1;  // remaining block columns of the outer panel
@@ -417,7 +477,7 @@ void factor_panel(gpmi_ctx* c, hipStream_t sp, double* A, int64_t ld, double* in
       double* C = A21 + NB;
       const double tiles = pc * (pc + 1) / 2.0 + (double)(below - pc) * pc;
       ProfScope ps(c, sp, GPMI_PROF_PANEL, tiles * 2.0 * NB * NB * NB, tiles * 16.0 * NB * NB);
-      launch_gemm_nt(sp, TILES_LOWER, OP_SUB, C, ld, A21, ld, A21, ld, below, pc, NB);
+      launch_gemm_nt(sp, TILES_LOWER, OP_SUB, C, ld, A21, ld, A21, ld, below, pc, NB, slot(2));
     }
   }
 }
