@@ -445,7 +445,6 @@ __global__ __launch_bounds__(256, GPMI_DMA_WGS) void gemm_dma_kernel(GemmArgs g)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       a[t] = *reinterpret_cast<const d2_t*>(sa + a_off + t * 16 * 4 * 2);
-      if (OP == OP_SUB) a[t] = -a[t];  // C - A B^T
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const d2_t*>(sa + b_off + t * 16 * 4 * 2);
@@ -458,7 +457,7 @@ __global__ __launch_bounds__(256, GPMI_DMA_WGS) void gemm_dma_kernel(GemmArgs g)
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][h], b[j][h], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][h], b[j][h], acc[i][j], 0, 0, OP == OP_SUB ? 1 : 0);  // f64 MFMA: the BLGP field is neg[A, B, C]: C - A B^T
   };
   // first stage peeled off the loop: its MFMAs wait for their own accumulator tile only, the C tile streams in
   // under them instead of in front of the loop
@@ -521,7 +520,9 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
     bn = 64;
   } else if (small && kskip != 1) {
     if (ntc == 1 && tiles == TILES_RECT && op == OP_ASSIGN) {
-      bm = 64;
+      // the panel TRSM: one 128-column strip, bound by the MFMA time of ONE workgroup (6.8 us for 64 rows at
+      // K = 128): 32-row tiles while that still leaves CUs idle
+      bm = (!b_kmajor && (int64_t)ntr * 2 * bt.count <= SMALL_M32_MAX) ? 32 : 64;
     } else if (!b_kmajor || op == OP_SUB) {
       bm = 64;
       bn = 64;
@@ -569,6 +570,8 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
     } else {
       if (op == OP_SUB) GPMI_LAUNCH(TILES_LOWER, OP_SUB, 0, 128, 128); else GPMI_LAUNCH(TILES_LOWER, OP_ASSIGN, 0, 128, 128);
     }
+  } else if (bn == 128 && bm == 32) {
+    GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0, 32, 128);
   } else if (bn == 128) {
     if (b_kmajor) GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 1, 64, 128); else GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0, 64, 128);
   } else if (bm == 32) {

@@ -571,8 +571,8 @@ void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, dou
   // overlap on a pair of CU-masked streams (disjoint CUs: a 75 KiB potrf_diag workgroup never finds a slot
   // on a chip saturated by GEMM workgroups): the update stream first updates the columns of panel p + 1
   // ("la"), the panel stream then factors them on 32 CUs while the update stream applies the rest on the
-  // other 224.  Below GPMI_LOOKAHEAD_MIN trailing tile rows the update is shorter than the panel chain and
-  // everything runs in order on the full-chip stream - and so does the very first panel (nothing to overlap
+  // other 224.  Below GPMI_LOOKAHEAD_MIN (60) trailing tile rows the update is shorter than the panel chain on its 32 CUs
+  // and everything runs in order on the full-chip stream - and so does the very first panel (nothing to overlap
   // it with: 0.49 instead of 0.92 ms).
   //   GPMI_LOOKAHEAD_MIN=<tile rows>  end of the look-ahead regime (0 disables it)
   // Measured and dropped: a second pair with 16 | 240 CUs for the early panels (the
@@ -584,7 +584,7 @@ void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, dou
   const int OBT = 4;  // tile columns per outer panel
   static const int LOOKAHEAD_MIN = [] {
     const char* e = std::getenv("GPMI_LOOKAHEAD_MIN");
-    const int v = e ? std::atoi(e) : 44;
+    const int v = e ? std::atoi(e) : 60;
     return v > 0 ? v : (1 << 30);
   }();
   const bool la_ok = allow_lookahead && nt - OBT >= LOOKAHEAD_MIN && ensure_masked_pair(c, lane, 0);
