@@ -163,7 +163,7 @@ def kernel_rows(eng, step, _lib, N, M):
                      "launches": ts["launches"], "avg_ms": ts["ms"] / ts["launches"], "flops": "M N^2 per predict"})
     if pn["ms"] > 0:
         rows.append({"kernel": "panel chain (potrf_diag_kernel + panel TRSM + inner K=128 updates; 32 CUs, hidden behind the "
-                     "trailing update while >= 44 tile rows remain)", "bound": "latency", "launches": pn["launches"],
+                     "trailing update during the look-ahead regime, >= 60 trailing tile rows)", "bound": "latency", "launches": pn["launches"],
                      "total_ms_per_step": pn["ms"] / 2})
     return rows
 

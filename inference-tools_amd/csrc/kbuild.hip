@@ -46,8 +46,18 @@ __device__ inline void kbuild_body(const KParams& p, const double* __restrict__ 
                                    const double* __restrict__ V, int64_t nv,
                                    const double* __restrict__ noise, double* __restrict__ out,
                                    int64_t ld, int lower_only) {
-  const int ti = blockIdx.y, tj = blockIdx.x;
-  if (SQUARE && lower_only && tj > ti) return;
+  int ti = blockIdx.y, tj = blockIdx.x;
+  if (SQUARE && lower_only == 2) {
+    // one-dimensional grid over the lower tiles only (row by row): id = ti (ti + 1) / 2 + tj.  (Half of a square
+    // grid's 61 504 workgroups at N = 16384 did nothing but start and exit: 0.48 -> 0.45 ms per build; the rest is the f64 exp, VALU-bound.)
+    const int id = blockIdx.x;
+    ti = (int)((sqrt(8.0 * id + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
+    while (ti * (ti + 1) / 2 > id) --ti;
+    tj = id - ti * (ti + 1) / 2;
+  } else if (SQUARE && lower_only && tj > ti) {
+    return;
+  }
   __shared__ double su[GPMI_MAX_D * KT];
   __shared__ double sv[GPMI_MAX_D * KT];
   const int tid = threadIdx.x;
@@ -122,9 +132,10 @@ __global__ void add_full_kernel(double* __restrict__ A, int64_t ld, const double
 
 void launch_kbuild_square(hipStream_t s, const KParams& p, const double* x, int64_t n, int64_t np,
                           const double* noise, double* A, int64_t ld, bool lower_only) {
-  dim3 grid((unsigned)(np / KT), (unsigned)(np / KT));
+  const unsigned nt = (unsigned)(np / KT);
+  dim3 grid = lower_only ? dim3(nt * (nt + 1) / 2) : dim3(nt, nt);
   hipLaunchKernelGGL(kbuild_kernel<true>, grid, dim3(256), 0, s, p, x, n, x, n, noise, A, ld,
-                     lower_only ? 1 : 0);
+                     lower_only ? 2 : 0);
 }
 
 void launch_kbuild_square_batched(hipStream_t s, const KParams* pdev, int batch, const double* x,
