@@ -290,8 +290,23 @@ int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const dou
   if (mix) {
     build_mix_square(c, s, *mix, L.A, false);
   } else {
-    ProfScope ps(c, s, GPMI_PROF_KBUILD, 0.0, 4.0 * c->np * c->np);
-    launch_kbuild_square(s, p, c->x, c->n, c->np, c->noise, L.A, c->ld, true);
+    // When the factorisation starts in its look-ahead regime the build is split: the first outer panel's columns on
+    // this stream, the tiles to their right on the update stream - where the first trailing update will follow them in
+    // stream order - so that the first panel (a 0.5 ms chain on an otherwise idle chip) is factored while they are
+    // built.  (Not while the K-build class is being timed by events on this stream.)
+    hipStream_t su = (!c->ycov && !((c->prof_mask >> GPMI_PROF_KBUILD) & 1))
+                         ? potrf_first_update_stream(c, L, c->np, allow_lookahead)
+                         : nullptr;
+    static const bool no_split = std::getenv("GPMI_KBUILD_NO_SPLIT") != nullptr;
+    if (su && !no_split) {
+      HIPCHK(c, hipEventRecord(L.ev_join, s));  // the matrix is free once everything queued so far is through
+      HIPCHK(c, hipStreamWaitEvent(su, L.ev_join, 0));
+      launch_kbuild_square_part(s, p, c->x, c->n, c->np, c->noise, L.A, c->ld, 1, GPMI_OB);
+      launch_kbuild_square_part(su, p, c->x, c->n, c->np, c->noise, L.A, c->ld, 2, GPMI_OB);
+    } else {
+      ProfScope ps(c, s, GPMI_PROF_KBUILD, 0.0, 4.0 * c->np * c->np);
+      launch_kbuild_square(s, p, c->x, c->n, c->np, c->noise, L.A, c->ld, true);
+    }
   }
   if (c->ycov) launch_add_full(s, L.A, c->ld, c->ycov, c->n);
   potrf_lower(c, L, L.A, c->np, c->ld, L.invD, L.info + slot, allow_lookahead);

@@ -172,6 +172,8 @@ struct ProfScope {
 // square covariance of the np x np padded problem (identity in the padding), lower tiles only if lower_only
 void launch_kbuild_square(hipStream_t s, const KParams& p, const double* x, int64_t n, int64_t np,
                           const double* noise, double* A, int64_t ld, bool lower_only);
+void launch_kbuild_square_part(hipStream_t s, const KParams& p, const double* x, int64_t n, int64_t np,
+                               const double* noise, double* A, int64_t ld, int part, int split_cols);
 // cross covariance U (mp x d, mu valid rows) vs V (np x d, n valid rows): out mp x ld, zeros in padding
 void launch_kbuild_cross(hipStream_t s, const KParams& p, const double* U, int64_t mu, int64_t mp,
                          const double* V, int64_t n, int64_t np, double* out, int64_t ld);
@@ -240,6 +242,7 @@ void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, int k
                  int ntc, int k, unsigned long long* stamp = nullptr, const GemmBatch& bt = GemmBatch());
 
 // potrf.hip
+hipStream_t potrf_first_update_stream(gpmi_ctx* c, Lane& lane, int64_t np, bool allow_lookahead);
 void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0,
                        unsigned long long* dbg = nullptr, const BatchShape& bs = BatchShape());
 // batched, in-order factorisation of bs.count matrices (small problems: no look-ahead)

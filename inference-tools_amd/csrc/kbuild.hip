@@ -47,6 +47,8 @@ __device__ inline void kbuild_body(const KParams& p, const double* __restrict__ 
                                    const double* __restrict__ noise, double* __restrict__ out,
                                    int64_t ld, int lower_only) {
   int ti = blockIdx.y, tj = blockIdx.x;
+  const int tile_off = lower_only >> 8;  // mode 2: the triangle starts at tile (tile_off, tile_off)
+  lower_only &= 0xff;
   if (SQUARE && lower_only == 2) {
     // one-dimensional grid over the lower tiles only (row by row): id = ti (ti + 1) / 2 + tj.  (Half of a square
     // grid's 61 504 workgroups at N = 16384 did nothing but start and exit: 0.48 -> 0.45 ms per build; the rest is the f64 exp, VALU-bound.)
@@ -54,7 +56,8 @@ __device__ inline void kbuild_body(const KParams& p, const double* __restrict__ 
     ti = (int)((sqrt(8.0 * id + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
     while (ti * (ti + 1) / 2 > id) --ti;
-    tj = id - ti * (ti + 1) / 2;
+    tj = id - ti * (ti + 1) / 2 + tile_off;
+    ti += tile_off;
   } else if (SQUARE && lower_only && tj > ti) {
     return;
   }
@@ -136,6 +139,21 @@ void launch_kbuild_square(hipStream_t s, const KParams& p, const double* x, int6
   dim3 grid = lower_only ? dim3(nt * (nt + 1) / 2) : dim3(nt, nt);
   hipLaunchKernelGGL(kbuild_kernel<true>, grid, dim3(256), 0, s, p, x, n, x, n, noise, A, ld,
                      lower_only ? 2 : 0);
+}
+
+// The lower tiles in two launches: part 1 = the first `split_cols` columns (all rows), part 2 = everything to the right
+// of them.  The fit starts factoring the first outer panel behind part 1 while part 2 is still being built on the
+// update stream (api.hip: enqueue_factor_and_forward).
+void launch_kbuild_square_part(hipStream_t s, const KParams& p, const double* x, int64_t n, int64_t np,
+                               const double* noise, double* A, int64_t ld, int part, int split_cols) {
+  const unsigned nt = (unsigned)(np / KT), sp = (unsigned)(split_cols / KT);
+  if (part == 1) {
+    hipLaunchKernelGGL(kbuild_kernel<true>, dim3(sp, nt), dim3(256), 0, s, p, x, n, x, n, noise, A, ld, 1);
+  } else if (nt > sp) {
+    const unsigned m = nt - sp;
+    hipLaunchKernelGGL(kbuild_kernel<true>, dim3(m * (m + 1) / 2), dim3(256), 0, s, p, x, n, x, n, noise, A, ld,
+                       2 | (int)(sp << 8));
+  }
 }
 
 void launch_kbuild_square_batched(hipStream_t s, const KParams* pdev, int batch, const double* x,

@@ -564,6 +564,28 @@ int64_t slice_tiles(int rem, int64_t tiles_la, int64_t tiles_main, int kw, int n
 
 bool ensure_masked_pair(gpmi_ctx* c, Lane& L, int k);  // api.hip
 
+namespace {
+constexpr int OUTER_TILES = 4;  // tile columns per outer panel
+//   GPMI_LOOKAHEAD_MIN=<tile rows>  end of the look-ahead regime (0 disables it)
+int lookahead_min() {
+  static const int v = [] {
+    const char* e = std::getenv("GPMI_LOOKAHEAD_MIN");
+    const int x = e ? std::atoi(e) : 60;
+    return x > 0 ? x : (1 << 30);
+  }();
+  return v;
+}
+}  // namespace
+
+// The stream the first trailing update of potrf_lower will run on when it is not the lane's own (the look-ahead
+// regime applies from the first panel on), else nullptr.  Work enqueued there beforehand precedes that update: the
+// fit builds the covariance tiles to the right of the first panel on it while the first panel is being factored.
+hipStream_t potrf_first_update_stream(gpmi_ctx* c, Lane& lane, int64_t np, bool allow_lookahead) {
+  const int nt = (int)(np / NB);
+  if (!allow_lookahead || nt - OUTER_TILES < lookahead_min() || !ensure_masked_pair(c, lane, 0)) return nullptr;
+  return lane.su[0];
+}
+
 void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, double* invD, int* info,
                  bool allow_lookahead) {
   // Right-looking over outer panels of 512 columns (4 tile columns), software-pipelined: step p applies
@@ -574,19 +596,14 @@ void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, dou
   // other 224.  Below GPMI_LOOKAHEAD_MIN (60) trailing tile rows the update is shorter than the panel chain on its 32 CUs
   // and everything runs in order on the full-chip stream - and so does the very first panel (nothing to overlap
   // it with: 0.49 instead of 0.92 ms).
-  //   GPMI_LOOKAHEAD_MIN=<tile rows>  end of the look-ahead regime (0 disables it)
   // Measured and dropped: a second pair with 16 | 240 CUs for the early panels (the
   // update is bound by the chip's power budget: 224, 240 and 256 CUs deliver the same FLOP/s, in-kernel clock
   // 2.05 / 1.97 GHz); trailing updates applied lazily with K = 1024 .. 2048 (in place the launches are already
   // split at round boundaries, which leaves +1 % for the larger K, and the narrower launches cost more).
   hipStream_t sf = lane.stream;
   const int nt = (int)(np / NB);
-  const int OBT = 4;  // tile columns per outer panel
-  static const int LOOKAHEAD_MIN = [] {
-    const char* e = std::getenv("GPMI_LOOKAHEAD_MIN");
-    const int v = e ? std::atoi(e) : 60;
-    return v > 0 ? v : (1 << 30);
-  }();
+  const int OBT = OUTER_TILES;
+  const int LOOKAHEAD_MIN = lookahead_min();
   const bool la_ok = allow_lookahead && nt - OBT >= LOOKAHEAD_MIN && ensure_masked_pair(c, lane, 0);
   auto follow = [](hipStream_t waiter, hipStream_t producer, hipEvent_t ev) {
     if (waiter != producer) (void)hipStreamWaitEvent(waiter, ev, 0);
