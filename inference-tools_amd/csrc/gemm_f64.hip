@@ -546,9 +546,12 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
   if (nwg <= 0) return;
   dim3 grid((unsigned)nwg, 1, (unsigned)bt.count), block(256);
   // full 128 x 128 tiles with K-contiguous operands take the LDS-DMA ring kernel (GPMI_GEMM_NO_DMA=1: the
-  // register-staged kernel everywhere, for A/B timing)
+  // register-staged kernel everywhere, for A/B timing).  Never for the lockstep batches (any stride set): the ring
+  // kernel feeds k = {0,2,4,6} / {1,3,5,7} of a stage to its two MFMAs, the register-staged kernels k = {q, 4+q, 8+q,
+  // 12+q} - the sums differ in the last bit, and which kernel a launch gets depends on the batch size; a lockstep
+  // value must not (tests: test_config5_ladders_in_lockstep_at_stated_shape)
   static const bool no_dma = std::getenv("GPMI_GEMM_NO_DMA") != nullptr;
-  if (!no_dma && bm == 128 && bn == 128 && !b_kmajor && bt.count == 1 && part != 2 && k % 128 == 0) {
+  if (!no_dma && bm == 128 && bn == 128 && !b_kmajor && bt.count == 1 && bt.sC == 0 && part != 2 && k % 128 == 0) {
     if (tiles == TILES_RECT) {
       if (op == OP_SUB) hipLaunchKernelGGL((gemm_dma_kernel<TILES_RECT, OP_SUB>), grid, block, 0, s, g);
       else hipLaunchKernelGGL((gemm_dma_kernel<TILES_RECT, OP_ASSIGN>), grid, block, 0, s, g);
