@@ -344,10 +344,18 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                 "unit": "TFLOP/s",
                 "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                 "traffic": traffic,
-                "traffic_source": f"{traffic_src}: separate rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run" if traffic_src else None,
+                "traffic_source": f"{traffic_src}: separate rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run; per launch, averaged over every launch of this kernel name (slices included: compare with same_kernel_name_all_launches.algorithmic_bytes_per_launch_avg)" if traffic_src else None,
                 "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
                 "flop_per_launch_avg": prof["flops"] / max(prof["launches"], 1),
+                # rocprofv3's kernel_stats row for this kernel NAME also holds the slice launches (same kernel on the panel
+                # stream's 32 CUs): the average to hold against that row, and against the per-launch PMC traffic
+                "same_kernel_name_all_launches": {
+                    "launches": prof["launches"] + prof_slice["launches"],
+                    "avg_launch_ms": (prof["ms"] + prof_slice["ms"]) / max(prof["launches"] + prof_slice["launches"], 1),
+                    "flop_per_launch_avg": (prof["flops"] + prof_slice["flops"]) / max(prof["launches"] + prof_slice["launches"], 1),
+                    "algorithmic_bytes_per_launch_avg": (prof["bytes"] + prof_slice["bytes"]) / max(prof["launches"] + prof_slice["launches"], 1),
+                },
                 "clock_ghz": clock,
                 "peak_at_clock": peak_at_clock,
                 "frac_at_clock": (ach / peak_at_clock) if peak_at_clock else None,

@@ -43,6 +43,7 @@ out = {
     "kernels": {},
     "cross_check": {"rocprof_kernel_stats_avg_us_of_the_dominant_kernel": upd_us, "launches": int(upd["Calls"]),
                     "bench_stamp_avg_us": bench["roofline"]["avg_launch_ms"] * 1e3,
+                    "bench_stamp_avg_us_all_launches_of_this_kernel_name": bench["roofline"].get("same_kernel_name_all_launches", {}).get("avg_launch_ms", float("nan")) * 1e3,
                     "bench_achieved_tflops": bench["roofline"]["achieved"],
                     "achieved_tflops_with_rocprof_avg": bench["roofline"]["flop_per_launch_avg"] / (upd_us * 1e-6) / 1e12},
 }
