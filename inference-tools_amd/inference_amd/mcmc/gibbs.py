@@ -215,33 +215,46 @@ def advance_lockstep(chains, n: int, batch_posterior):
     """Advance every chain by `n` Gibbs steps with batched posterior evaluations.
 
     `batch_posterior(thetas (B, P)) -> (B,)` must agree element-wise with each chain's own
-    `posterior`.  For every parameter the still-unaccepted chains propose together and are
-    evaluated in one call; accepted chains drop out of the round (the retry-until-accept loop of
-    gibbs.py:635-648 makes the work ragged).  Returns the number of posterior evaluations made."""
-    if not chains:
+    `posterior`.  Every round, every chain that still has work proposes a value for ITS current
+    parameter and all proposals are evaluated in one call; a chain whose proposal is accepted moves
+    on to its next parameter (and its next step) at once, one whose proposal is rejected retries
+    (the retry-until-accept loop of gibbs.py:635-648).  Chains therefore drift apart inside a call
+    and only meet again at its end - a chain draws from its own generators only and never sees the
+    others, so its trajectory is the one it would follow alone - and the batches stay full until the
+    first chains finish, instead of shrinking 64 -> 1 for every parameter.
+    Returns the number of posterior evaluations made."""
+    if not chains or n <= 0:
         return 0
     P = chains[0].n_parameters
     evals = 0
-    for _ in range(n):
-        p_old = [c.probs[-1] for c in chains]
-        prop = [c.get_last() for c in chains]
-        p_acc = list(p_old)
-        for i in range(P):
-            active = list(range(len(chains)))
-            while active:
-                for c in active:
-                    prop[c][i] = chains[c].params[i].proposal()
-                vals = batch_posterior(array([prop[c] for c in active]))
-                evals += len(active)
-                retry = []
-                for c, v in zip(active, vals):
-                    p_new = float(v) * chains[c].inv_temp
-                    if chains[c]._mh_test(chains[c].params[i], p_new, p_old[c]):
-                        p_old[c] = p_new
-                        p_acc[c] = p_new
-                    else:
-                        retry.append(c)
-                active = retry
-        for c, chain in enumerate(chains):
-            chain._commit(prop[c], p_acc[c])
+    step = [0] * len(chains)  # completed steps
+    par = [0] * len(chains)   # parameter being updated
+    p_old = [c.probs[-1] for c in chains]
+    p_acc = list(p_old)
+    prop = [c.get_last() for c in chains]
+    active = list(range(len(chains)))
+    while active:
+        for c in active:
+            prop[c][par[c]] = chains[c].params[par[c]].proposal()
+        vals = batch_posterior(array([prop[c] for c in active]))
+        evals += len(active)
+        still = []
+        for c, v in zip(active, vals):
+            chain = chains[c]
+            p_new = float(v) * chain.inv_temp
+            if chain._mh_test(chain.params[par[c]], p_new, p_old[c]):
+                p_old[c] = p_new
+                p_acc[c] = p_new
+                par[c] += 1
+                if par[c] == P:
+                    chain._commit(prop[c], p_acc[c])
+                    step[c] += 1
+                    par[c] = 0
+                    if step[c] < n:
+                        p_old[c] = chain.probs[-1]
+                        p_acc[c] = p_old[c]
+                        prop[c] = chain.get_last()
+            if step[c] < n:
+                still.append(c)
+        active = still
     return evals
