@@ -1090,6 +1090,44 @@ def test_four_lanes_at_full_size(gp_mod):
         check(gp.marginal_likelihood_batch(thetas), single, 1e-12, "four lanes vs one at a time")
 
 
+def test_schedule_variants_agree(tmp_path):
+    """The factorisation's stream choreography (look-ahead on the CU-masked pair, slices of the trailing update on the
+    panel stream, covariance build split over two streams, 32-row tiles, the split point of a launch) decides where,
+    when and by which tile shape a tile is computed, never from what: alpha, log-determinant and predictions of a fit at
+    N = 16384 agree to rounding (1e-11: the LDS-DMA kernel and the register-staged kernels group the k of an MFMA
+    differently, so the last bits move with the split points) under every setting, and the second of two consecutive
+    fits in one process is bit-identical to the first.  An ordering bug between the streams (a tile updated before
+    its operands are final, a slice racing the next update, a build overtaken by the first panel) is an O(1) error."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "fit_digest.py")
+    variants = [
+        {},
+        {"GPMI_SLICE_PCT": "0"},
+        {"GPMI_SLICE_PCT": "300"},
+        {"GPMI_LOOKAHEAD_MIN": "0"},
+        {"GPMI_LOOKAHEAD_MIN": "24", "GPMI_KBUILD_NO_SPLIT": "1"},
+        {"GPMI_M32_MAX": "0", "GPMI_SPLIT_PCT": "0", "GPMI_BIG_MIN": "64"},
+    ]
+    base = None
+    for k, extra in enumerate(variants):
+        out = str(tmp_path / f"v{k}.npz")
+        run = subprocess.run([sys.executable, tool, out], env=dict(os.environ, **extra), capture_output=True, text=True,
+                             timeout=300)
+        assert run.returncode == 0, (extra, run.stderr[-2000:])
+        r = dict(np.load(out))
+        for q in ("alpha", "logdet", "mu", "sig"):
+            assert np.array_equal(r[q + "0"], r[q + "1"]), (extra, q, "second fit differs from the first")
+        if base is None:
+            base = r
+            continue
+        for q in ("alpha", "logdet", "mu", "sig"):
+            check(r[q + "0"], base[q + "0"], 1e-11, f"{q} under {extra}")
+
+
 # ---------------------------------------------------------------------------------------
 # appending evaluations at fixed hyper-parameters (SURVEY.md section 8(f) rank 4): O(N^2) update of the factor
 # ---------------------------------------------------------------------------------------
