@@ -179,6 +179,7 @@ def launch_ranks(n_ranks):
     import subprocess
 
     env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
     env.update(WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=env.get("MASTER_PORT", "29511"),
                GPMI_RDV_KEY=f"bench_{os.getpid()}_{secrets.token_hex(6)}")
     procs = []
@@ -199,8 +200,8 @@ def launch_ranks(n_ranks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=60)  # 2 s of GPU time: a sustained-clock figure, not a burst
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--m", type=int, default=1024)
@@ -227,10 +228,17 @@ def main():
     finally:
         if rdv is not None:
             rdv.close()
+        if STUCK:  # a thread is still inside RCCL: tearing the library down under it could block for ever
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0 if sys.exc_info()[0] is None else 1)
         # destroy the device contexts here, while the interpreter is fully alive: under rocprofv3 a context that is
         # only torn down during interpreter shutdown ended in a SIGSEGV inside the runtime's static destructors
         # (after the profile had been written)
         _lib._close_all_handles()
+
+
+STUCK = []  # non-empty: a thread of this rank is still inside the RCCL bootstrap
 
 
 def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, local_rank, rdv):
@@ -245,13 +253,29 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
     eng = gp.engine
     gather = "none"
     if world > 1:
-        try:
-            sharding.init_device_comm_files(eng, rdv)
-            eng.comm_allgather(np.zeros(1))
-            ok = True
-        except Exception as err:  # keep the scaling run alive: the gather is 4 doubles per rank
-            ok = False
-            why = f"{type(err).__name__}: {err}"
+        # RCCL bootstrap + a first all-gather under a watchdog: a refusal (ranks sharing a device) or a bootstrap
+        # that never returns must not cost the scaling run - the gather is 4 doubles per rank and falls back to the
+        # rendezvous files; a rank left with a thread inside RCCL skips the library teardown at exit (STUCK)
+        import threading
+
+        box = {}
+
+        def bootstrap():
+            try:
+                sharding.init_device_comm_files(eng, rdv)
+                eng.comm_allgather(np.zeros(1))
+                box["ok"] = True
+            except Exception as err:
+                box["ok"], box["why"] = False, f"{type(err).__name__}: {err}"
+
+        th = threading.Thread(target=bootstrap, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("GPMI_BENCH_RCCL_TIMEOUT", "120")))
+        if th.is_alive():
+            STUCK.append(True)
+            ok, why = False, "RCCL bootstrap did not return within the time limit"
+        else:
+            ok, why = box.get("ok", False), box.get("why", "")
         # every rank must take the same path
         oks = rdv.allgather_obj(ok)
         gather = "rccl" if all(oks) else f"file-fallback ({'; '.join(str(o) for o in oks)}{'' if ok else ' ' + why})"
