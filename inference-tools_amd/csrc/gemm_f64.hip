@@ -488,6 +488,122 @@ __global__ __launch_bounds__(256, GPMI_DMA_WGS) void gemm_dma_kernel(GemmArgs g)
                                      ((__builtin_amdgcn_s_memrealtime() - r_start) & 0xffffffffull);
 }
 
+
+// ---- 64 x 64 tiles on the same ring ---------------------------------------------------------------------------------
+// The remainders of split launches, the narrow look-ahead updates (fewer than 384 tiles) and the tail's outer updates
+// run 64 x 64 tiles; with the register-staged kernel they reached 40-47 TFLOP/s at K = 512.  Same scheme as
+// gemm_dma_kernel at half the edge: one 16-byte piece per operand, stage and thread (64 rows x 4 pieces), 2 x 2 waves
+// of 32 x 32 (2 x 2 MFMA tiles), 8 KiB per stage.  The MFMAs take the k of a stage in the same groups as the 128 x 128
+// ring kernel ({0,2,4,6}, {1,3,5,7}).
+template <int TILES, int OP>
+__global__ __launch_bounds__(256, 4) void gemm_dma64_kernel(GemmArgs g) {
+  constexpr int OPD = 64 * DMA_BK;  // doubles of one operand of one stage
+  __shared__ double smem[DMA_STAGES * 2 * OPD];
+  int ti, tj;
+  const int wid = g.kskip ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+  if (g.split) {
+    int bi, bj;
+    tile_of<TILES>(g.tile_base + (wid >> 2), g.ntr >> 1, g.ntc >> 1, bi, bj);
+    ti = 2 * bi + ((wid >> 1) & 1);
+    tj = 2 * bj + (wid & 1);
+  } else {
+    tile_of<TILES>(g.tile_base + wid, g.ntr, g.ntc, ti, tj);
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool stamp_first = g.stamp && tid == 0 && blockIdx.x < 8;
+  if (stamp_first) g.stamp[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int kbeg = (g.kskip == 1) ? ti * 64 : 0;
+  const int kend = (g.kskip == 2 && (tj + 1) * 64 < g.k) ? (tj + 1) * 64 : g.k;
+  const double* __restrict__ Ag = g.A + (int64_t)ti * 64 * g.lda + kbeg;
+  const double* __restrict__ Bg = g.B + (int64_t)tj * 64 * g.ldb + kbeg;
+  // this thread's piece per operand and stage: row tid >> 2, slot tid & 3 (see gemm_dma_kernel for the slot swizzle)
+  const int row0 = tid >> 2, slot = tid & 3;
+  const int q0 = (slot - 2 * ((row0 >> 2) & 3)) & 3;
+  const double* a_src = Ag + (int64_t)row0 * g.lda + 2 * q0;
+  // LDS row 16 t + f of a wave's 32-column block holds column 2 f + t: the two MFMA tiles of a lane are adjacent columns
+  const int bcol = (row0 & 32) + 2 * (row0 & 15) + ((row0 >> 4) & 1);
+  const double* b_src = Bg + (int64_t)bcol * g.ldb + 2 * q0;
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const unsigned wave_off = (unsigned)__builtin_amdgcn_readfirstlane(wave * 64 * 16);
+  auto issue = [&](int st, int k0) {
+    const unsigned base = lds0 + (unsigned)st * (2 * OPD * 8) + wave_off;
+    const double* p0 = a_src + k0;
+    const double* p1 = b_src + k0;
+    asm volatile(
+        "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+        "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+        :
+        : "v"(p0), "v"(p1), "s"(base), "s"(base + OPD * 8)
+        : "memory");
+  };
+  const int nk = (kend - kbeg) / DMA_BK;
+  for (int st = 0; st < DMA_STAGES - 1 && st < nk; ++st) issue(st, st * DMA_BK);
+
+  double* Cg = g.C + ((int64_t)ti * 64 + wr * 32) * g.ldc + (int64_t)tj * 64 + wc * 32;
+  d4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      d2_t cv = d2_t{0.0, 0.0};
+      if (OP == OP_SUB)
+        cv = GPMI_C_LOAD(reinterpret_cast<const d2_t*>(&Cg[(int64_t)(i * 16 + fk + 4 * r) * g.ldc + 2 * fr]));
+      acc[i][0][r] = cv[0];
+      acc[i][1][r] = cv[1];
+    }
+  const int rslot = (fk + 2 * (fr >> 2)) & 3;
+  const int a_off = ((wr * 32 + fr) * 4 + rslot) * 2;  // doubles
+  const int b_off = OPD + ((wc * 32 + fr) * 4 + rslot) * 2;
+  auto wait2 = [](int newer) {  // at most `newer` younger vector-memory operations outstanding (2 per stage)
+    if (newer >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (newer >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (newer >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto stage = [&](int kt) {
+    const int ahead = nk - 1 - kt;
+    wait2(2 * (ahead < DMA_STAGES - 2 ? ahead : DMA_STAGES - 2));
+    __syncthreads();
+    const double* sa = smem + (kt % DMA_STAGES) * 2 * OPD;
+    d2_t a[2], b[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      a[t] = *reinterpret_cast<const d2_t*>(sa + a_off + t * 16 * 4 * 2);
+      b[t] = *reinterpret_cast<const d2_t*>(sa + b_off + t * 16 * 4 * 2);
+    }
+    if (kt + DMA_STAGES - 1 < nk) issue((kt + DMA_STAGES - 1) % DMA_STAGES, (kt + DMA_STAGES - 1) * DMA_BK);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][h], b[j][h], acc[i][j], 0, 0, OP == OP_SUB ? 1 : 0);
+  };
+  stage(0);
+  int kt = 1;
+  for (; kt + 3 < nk; kt += 4) {
+    stage(kt);
+    stage(kt + 1);
+    stage(kt + 2);
+    stage(kt + 3);
+  }
+  for (; kt < nk; ++kt) stage(kt);
+  const bool stamp_end = g.stamp && tid == 0 && blockIdx.x + 2048 >= gridDim.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      GPMI_C_STORE((d2_t{acc[i][0][r], acc[i][1][r]}),
+                   reinterpret_cast<d2_t*>(&Cg[(int64_t)(i * 16 + fk + 4 * r) * g.ldc + 2 * fr]));
+  if (stamp_end) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    g.stamp[8 + (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 7)] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -558,6 +674,23 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
     } else {
       if (op == OP_SUB) hipLaunchKernelGGL((gemm_dma_kernel<TILES_LOWER, OP_SUB>), grid, block, 0, s, g);
       else hipLaunchKernelGGL((gemm_dma_kernel<TILES_LOWER, OP_ASSIGN>), grid, block, 0, s, g);
+    }
+    return;
+  }
+  // 64 x 64 tiles with K-contiguous operands: the ring kernel at half the edge (GPMI_GEMM_NO_DMA64=1: register-staged)
+  static const bool no_dma64 = std::getenv("GPMI_GEMM_NO_DMA64") != nullptr;
+  static const int dma64_min_k = [] {
+    const char* e = std::getenv("GPMI_DMA64_MIN_K");
+    return e ? std::atoi(e) : 128;  // also the K = 128 inner updates of the panel chain: 34.9 -> 34.45 ms per step
+  }();
+  if (!no_dma && !no_dma64 && bm == 64 && bn == 64 && !b_kmajor && bt.count == 1 && bt.sC == 0 && k % 64 == 0 &&
+      k >= dma64_min_k) {
+    if (tiles == TILES_RECT) {
+      if (op == OP_SUB) hipLaunchKernelGGL((gemm_dma64_kernel<TILES_RECT, OP_SUB>), grid, block, 0, s, g);
+      else hipLaunchKernelGGL((gemm_dma64_kernel<TILES_RECT, OP_ASSIGN>), grid, block, 0, s, g);
+    } else {
+      if (op == OP_SUB) hipLaunchKernelGGL((gemm_dma64_kernel<TILES_LOWER, OP_SUB>), grid, block, 0, s, g);
+      else hipLaunchKernelGGL((gemm_dma64_kernel<TILES_LOWER, OP_ASSIGN>), grid, block, 0, s, g);
     }
     return;
   }
