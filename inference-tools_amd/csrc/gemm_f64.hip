@@ -735,8 +735,8 @@ void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, int k
 
 // A launch of T equal tiles on `ncu` CUs runs in ceil(T / ncu) rounds of one tile time (the two workgroups
 // of a CU share its MFMA pipes, so a CU with one tile left is as slow as a CU with two): a last round that
-// is nearly empty wastes up to 70 us x ncu CUs.  When that round would be less than ~55 % full its tiles run
-// as 64 x 64 tiles instead (four times as many workgroups, spread over all CUs), in a second launch.
+// is nearly empty wastes up to 70 us x ncu CUs.  When that round would be less than 70 % full (55 % before the
+// 64 x 64 tiles ran on the LDS-DMA ring) its tiles run as 64 x 64 tiles instead (four times as many workgroups, spread over all CUs), in a second launch.
 int64_t gemm_split_point(int64_t T, int ncu, int k) {
   static const int64_t BIG_MIN = [] {
     const char* e = std::getenv("GPMI_BIG_MIN");
@@ -744,7 +744,7 @@ int64_t gemm_split_point(int64_t T, int ncu, int k) {
   }();
   static const int64_t SPLIT_PCT = [] {
     const char* e = std::getenv("GPMI_SPLIT_PCT");
-    return (int64_t)(e ? std::atoi(e) : 55);
+    return (int64_t)(e ? std::atoi(e) : 70);
   }();
   if (k <= 128 || T < BIG_MIN || ncu <= 0) return T;  // these launches use the small tiles throughout
   const int64_t rem = T % ncu;
