@@ -754,6 +754,27 @@ def test_ragged_large_size_vs_oracle(gp_mod):
     check_each(grad, rg, what="gradient")
 
 
+def test_many_query_points_vs_oracle(gp_mod):
+    """Predict with more query points than training-matrix tile rows make convenient: M = 2500 (20 row tiles, ragged)
+    at N = 3000 - the many-right-hand-side solve then runs its products with the inverse blocks on 64 x 64 ring tiles
+    with the k-skip (few query points take the 32-row tiles), and its updates span several rounds."""
+    from oracle import gp_oracle as orc
+
+    n, d, m = 3000, 3, 2500
+    x, y, e = wl.synthetic_dataset(66, n, d)
+    th = wl.timing_theta(wl.SE, y, d)
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=th)
+    ref = orc.OracleGp(x, y, e, kernel=orc.SE, hyperpars=th)
+    pts = wl.query_points(66, m, d)
+    mu, sig = gp(pts)
+    rmu, rsig = ref(pts)
+    check(mu, rmu, what="mu")
+    check(sig, rsig, what="sig")
+    few = gp(pts[:40])
+    check(few[0], rmu[:40], what="mu (40 points)")
+    check(few[1], rsig[:40], what="sig (40 points)")
+
+
 def test_objects_pickle_without_device_state(gp_mod):
     """the reference pickles the GP object into worker processes (regression.py:600-601,
     parallel.py:130-136); here the device handle is dropped on pickling and re-created lazily."""
