@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, GPMI_DMA_WGS) void gemm_dma_kernel(GemmArgs g)
   // k-skipped launches have tiles of very different length: dealt round-robin over the XCDs (see gemm_nt_kernel)
   tile_of<TILES>(g.tile_base + (g.kskip ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x)), g.ntr, g.ntc, ti, tj);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool stamp_first = g.stamp && tid == 0 && blockIdx.x < 8;
+  const bool stamp_first = g.stamp && tid == 0 && blockIdx.x < 8 && blockIdx.z == 0;
   if (stamp_first) g.stamp[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
   const unsigned mid = gridDim.x >> 1;
   const bool stamp_clock = g.stamp && tid == 0 && blockIdx.x >= mid && blockIdx.x < mid + 8;
@@ -376,8 +376,9 @@ __global__ __launch_bounds__(256, GPMI_DMA_WGS) void gemm_dma_kernel(GemmArgs g)
   const int fr = lane & 15, fk = lane >> 4;
   const int kbeg = (g.kskip == 1) ? ti * 128 : 0;
   const int kend = (g.kskip == 2 && (tj + 1) * 128 < g.k) ? (tj + 1) * 128 : g.k;
-  const double* __restrict__ Ag = g.A + (int64_t)ti * 128 * g.lda + kbeg;
-  const double* __restrict__ Bg = g.B + (int64_t)tj * 128 * g.ldb + kbeg;
+  const int64_t bz = blockIdx.z;  // batch (lockstep factorisations): problem z works on C + z sC, A + z sA, B + z sB
+  const double* __restrict__ Ag = g.A + bz * g.sA + (int64_t)ti * 128 * g.lda + kbeg;
+  const double* __restrict__ Bg = g.B + bz * g.sB + (int64_t)tj * 128 * g.ldb + kbeg;
   // this thread's two pieces per operand and stage: p = i * 256 + tid -> row p >> 2, slot p & 3
   const int row0 = tid >> 2, slot = tid & 3;
   const int q0 = (slot - 2 * ((row0 >> 2) & 3)) & 3;          // rows row0 and row0 + 64 have the same (row >> 2) & 3
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(256, GPMI_DMA_WGS) void gemm_dma_kernel(GemmArgs g)
   const int nk = (kend - kbeg) / DMA_BK;
   for (int st = 0; st < DMA_STAGES - 1 && st < nk; ++st) issue(st, st * DMA_BK);
 
-  double* Cg = g.C + ((int64_t)ti * 128 + wr * 64) * g.ldc + (int64_t)tj * 128 + wc * 64;
+  double* Cg = g.C + bz * g.sC + ((int64_t)ti * 128 + wr * 64) * g.ldc + (int64_t)tj * 128 + wc * 64;
   d4_t acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -516,8 +517,9 @@ __global__ __launch_bounds__(256, 4) void gemm_dma64_kernel(GemmArgs g) {
   const int fr = lane & 15, fk = lane >> 4;
   const int kbeg = (g.kskip == 1) ? ti * 64 : 0;
   const int kend = (g.kskip == 2 && (tj + 1) * 64 < g.k) ? (tj + 1) * 64 : g.k;
-  const double* __restrict__ Ag = g.A + (int64_t)ti * 64 * g.lda + kbeg;
-  const double* __restrict__ Bg = g.B + (int64_t)tj * 64 * g.ldb + kbeg;
+  const int64_t bz = blockIdx.z;
+  const double* __restrict__ Ag = g.A + bz * g.sA + (int64_t)ti * 64 * g.lda + kbeg;
+  const double* __restrict__ Bg = g.B + bz * g.sB + (int64_t)tj * 64 * g.ldb + kbeg;
   // this thread's piece per operand and stage: row tid >> 2, slot tid & 3 (see gemm_dma_kernel for the slot swizzle)
   const int row0 = tid >> 2, slot = tid & 3;
   const int q0 = (slot - 2 * ((row0 >> 2) & 3)) & 3;
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(256, 4) void gemm_dma64_kernel(GemmArgs g) {
   const int nk = (kend - kbeg) / DMA_BK;
   for (int st = 0; st < DMA_STAGES - 1 && st < nk; ++st) issue(st, st * DMA_BK);
 
-  double* Cg = g.C + ((int64_t)ti * 64 + wr * 32) * g.ldc + (int64_t)tj * 64 + wc * 32;
+  double* Cg = g.C + bz * g.sC + ((int64_t)ti * 64 + wr * 32) * g.ldc + (int64_t)tj * 64 + wc * 32;
   d4_t acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -662,12 +664,13 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
   if (nwg <= 0) return;
   dim3 grid((unsigned)nwg, 1, (unsigned)bt.count), block(256);
   // full 128 x 128 tiles with K-contiguous operands take the LDS-DMA ring kernel (GPMI_GEMM_NO_DMA=1: the
-  // register-staged kernel everywhere, for A/B timing).  Never for the lockstep batches (any stride set): the ring
-  // kernel feeds k = {0,2,4,6} / {1,3,5,7} of a stage to its two MFMAs, the register-staged kernels k = {q, 4+q, 8+q,
-  // 12+q} - the sums differ in the last bit, and which kernel a launch gets depends on the batch size; a lockstep
-  // value must not (tests: test_config5_ladders_in_lockstep_at_stated_shape)
+  // register-staged kernel everywhere, for A/B timing).  The ring kernels feed k = {0,2,4,6} / {1,3,5,7} of a stage to
+  // their two MFMAs, the register-staged kernels k = {q, 4+q, 8+q, 12+q}: the sums differ in the last bit.  Lockstep
+  // batches (values must not depend on the batch size, which decides between 128 x 128 and 64 x 64 tiles) stay
+  // consistent because BOTH tile sizes of their C -= A B^T launches are ring kernels (this one and gemm_dma64_kernel)
+  // and their in-place TRSM is register-staged at either tile height.
   static const bool no_dma = std::getenv("GPMI_GEMM_NO_DMA") != nullptr;
-  if (!no_dma && bm == 128 && bn == 128 && !b_kmajor && bt.count == 1 && bt.sC == 0 && part != 2 && k % 128 == 0) {
+  if (!no_dma && bm == 128 && bn == 128 && !b_kmajor && part != 2 && k % 128 == 0) {
     if (tiles == TILES_RECT) {
       if (op == OP_SUB) hipLaunchKernelGGL((gemm_dma_kernel<TILES_RECT, OP_SUB>), grid, block, 0, s, g);
       else hipLaunchKernelGGL((gemm_dma_kernel<TILES_RECT, OP_ASSIGN>), grid, block, 0, s, g);
@@ -683,8 +686,7 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
     const char* e = std::getenv("GPMI_DMA64_MIN_K");
     return e ? std::atoi(e) : 128;  // also the K = 128 inner updates of the panel chain: 34.9 -> 34.45 ms per step
   }();
-  if (!no_dma && !no_dma64 && bm == 64 && bn == 64 && !b_kmajor && bt.count == 1 && bt.sC == 0 && k % 64 == 0 &&
-      k >= dma64_min_k) {
+  if (!no_dma && !no_dma64 && bm == 64 && bn == 64 && !b_kmajor && k % 64 == 0 && k >= dma64_min_k) {
     if (tiles == TILES_RECT) {
       if (op == OP_SUB) hipLaunchKernelGGL((gemm_dma64_kernel<TILES_RECT, OP_SUB>), grid, block, 0, s, g);
       else hipLaunchKernelGGL((gemm_dma64_kernel<TILES_RECT, OP_ASSIGN>), grid, block, 0, s, g);
