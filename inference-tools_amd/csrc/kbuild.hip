@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void kbuild_batched_kernel(const KParams* __re
                                                              const double* __restrict__ noise,
                                                              double* __restrict__ out, int64_t ld,
                                                              int64_t stride) {
-  kbuild_body<true>(pdev[blockIdx.z], x, n, x, n, noise, out + (int64_t)blockIdx.z * stride, ld, 1);
+  kbuild_body<true>(pdev[blockIdx.z], x, n, x, n, noise, out + (int64_t)blockIdx.z * stride, ld, 2);
 }
 
 template <bool SQUARE>
@@ -159,7 +159,8 @@ void launch_kbuild_square_part(hipStream_t s, const KParams& p, const double* x,
 void launch_kbuild_square_batched(hipStream_t s, const KParams* pdev, int batch, const double* x,
                                   int64_t n, int64_t np, const double* noise, double* A, int64_t ld,
                                   int64_t stride) {
-  dim3 grid((unsigned)(np / KT), (unsigned)(np / KT), (unsigned)batch);
+  const unsigned nt = (unsigned)(np / KT);
+  dim3 grid(nt * (nt + 1) / 2, 1, (unsigned)batch);  // lower tiles only, one-dimensional (kbuild_body, mode 2)
   hipLaunchKernelGGL(kbuild_batched_kernel, grid, dim3(256), 0, s, pdev, x, n, noise, A, ld, stride);
 }
 
