@@ -632,6 +632,9 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
     const char* e = std::getenv("GPMI_M32_MAX");
     return (int64_t)(e ? std::atoi(e) : 192);
   }();
+  // thresholds of the 32-row tiles, scaled to the CUs of a masked stream (the panel chain on its 32 CUs is throughput-
+  // bound from 24 workgroups on: halving the tiles there only doubles the operand traffic - 60 vs 45 us per panel TRSM)
+  const int64_t m32_max = bt.ncu_hint > 0 ? SMALL_M32_MAX * bt.ncu_hint / 256 : SMALL_M32_MAX;
   const bool small = part == 0 && ((k <= 128) || (big * bt.count < BIG_MIN));
   if (part == 2) {
     bm = 64;
@@ -640,14 +643,14 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
     if (ntc == 1 && tiles == TILES_RECT && op == OP_ASSIGN) {
       // the panel TRSM: one 128-column strip, bound by the MFMA time of ONE workgroup (6.8 us for 64 rows at
       // K = 128): 32-row tiles while that still leaves CUs idle
-      bm = (!b_kmajor && (int64_t)ntr * 2 * bt.count <= SMALL_M32_MAX) ? 32 : 64;
+      bm = (!b_kmajor && (int64_t)ntr * 2 * bt.count <= m32_max) ? 32 : 64;
     } else if (!b_kmajor || op == OP_SUB) {
       bm = 64;
       bn = 64;
       // fewer 64 x 64 tiles than three quarters of the CUs, and each of them long (K > 128: the products with the
       // 512 x 512 inverse blocks on the chain of the many-right-hand-side solves, 128 workgroups x up to 13 us of
       // MFMA time on one CU each): 32-row tiles put the same work on twice as many CUs
-      if (tiles == TILES_RECT && !b_kmajor && k > 128 && big * 4 * bt.count <= SMALL_M32_MAX) bm = 32;
+      if (tiles == TILES_RECT && !b_kmajor && k > 128 && big * 4 * bt.count <= m32_max) bm = 32;
     }
   }
   GemmArgs g{C, A, B, ldc, lda, ldb, ntr * (128 / bm), ntc * (128 / bn), k, kskip, stamp,

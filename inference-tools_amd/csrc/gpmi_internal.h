@@ -196,6 +196,8 @@ void launch_loo_vectors(hipStream_t s, const double* alpha, const double* ikdiag
 struct GemmBatch {
   int count = 1;
   int64_t sC = 0, sA = 0, sB = 0;
+  // CUs the launch's stream may use (0: the whole chip): the choice of 32-row tiles ("while CUs are idle") scales with it
+  int ncu_hint = 0;
 };
 struct BatchShape {
   int count = 1;

@@ -451,7 +451,9 @@ namespace {
 
 // factor outer panel [J, Je): inner right-looking steps on stream sp
 void factor_panel(gpmi_ctx* c, hipStream_t sp, double* A, int64_t ld, double* invD, int* info, int nt,
-                  int J, int Je) {
+                  int J, int Je, int ncu = 0) {
+  GemmBatch on;  // one problem; the CU count of a masked panel stream steers the tile height of the TRSM
+  on.ncu_hint = ncu;
   // GPMI_CHAIN_TRACE=1 (tools/chain_trace.py, with the profile enabled): in-kernel wall-clock stamps of every launch
   // of the chain, printed by the next profile read
   static const bool trace = std::getenv("GPMI_CHAIN_TRACE") != nullptr;
@@ -467,7 +469,7 @@ void factor_panel(gpmi_ctx* c, hipStream_t sp, double* A, int64_t ld, double* in
       if (below > 0) {
         // panel TRSM: A21 <- A21 * L11^-T  (in place: one tile column, see gemm_f64.hip)
         double* A21 = Ajj + (int64_t)NB * ld;
-        launch_gemm_nt(sp, TILES_RECT, OP_ASSIGN, A21, ld, A21, ld, invDj, NB, below, 1, NB, slot(1));
+        launch_gemm_nt(sp, TILES_RECT, OP_ASSIGN, A21, ld, A21, ld, invDj, NB, below, 1, NB, slot(1), on);
       }
     }
     const int pc = Je - j - 1;  // remaining block columns of the outer panel
@@ -643,7 +645,7 @@ void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, dou
     }
     sliced = false;
     main_stream = su;
-    factor_panel(c, sp, A, ld, invD, info, nt, k1, tile0(p + 2));
+    factor_panel(c, sp, A, ld, invD, info, nt, k1, tile0(p + 2), overlap ? c->pair_cus[0] : 0);
     if (overlap) (void)hipEventRecord(lane.ev_panel, sp);
     panel_stream = sp;
     if (slice > 0) {
