@@ -233,10 +233,13 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
       blk[j] = A[(int64_t)(i > fr ? i : fr) * ld + (i > fr ? fr : i)];
     }
   } else {
-    // the strictly-upper 16-blocks of the inverse are zero (fire-and-forget stores, acknowledged while the loads are in flight)
-    for (int idx = tid - 64; idx < NB * NB / 2; idx += DIAG_THREADS - 64) {
-      const int r = idx >> 6, c = (idx & 63) * 2;
-      if ((c >> 4) > (r >> 4)) *reinterpret_cast<d2_t*>(invD + r * NB + c) = d2_t{0.0, 0.0};
+    // the strictly-upper 16-blocks of the inverse are zero: in row r the contiguous columns from 16 ((r >> 4) + 1) on,
+    // one predicated 16-byte store per row and lane (fire-and-forget, acknowledged while the loads are in flight)
+#pragma unroll
+    for (int i = 0; i < (NB - BS + DIAG_BULK - 1) / DIAG_BULK; ++i) {
+      const int r = (wave - 1) + DIAG_BULK * i;
+      const int c = ((r >> 4) + 1) * BS + 2 * lane;
+      if (r < NB - BS && c < NB) *reinterpret_cast<d2_t*>(invD + r * NB + c) = d2_t{0.0, 0.0};
     }
     // rows 16 .. 127, one 1 KiB row per wave and load, dealt round-robin to the seven waves (16 rows each); only the
     // lower triangle is stored - the first readers of a diagonal 16-block (sub_chain, trailing_tile) take its upper
