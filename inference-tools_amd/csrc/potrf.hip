@@ -211,7 +211,10 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
   };
   if (dbg) t_prev = __builtin_amdgcn_s_memtime();
   __shared__ double S[S_DOUBLES];
-  __shared__ double Wl[2][BS * WP];
+  // the inverse as it grows: 16 x 16 block (k2, jb), jb <= k2, at Xl[k2 (k2 + 1) / 2 + jb] (row pitch 17).  Later row
+  // blocks are built from the earlier ones; keeping them here (78 KiB) instead of reading them back through L2 takes
+  // the store fence - the wait for the acknowledgement of every global store of a step - out of the waves' steps
+  __shared__ double Xl[NBLK * (NBLK + 1) / 2][BS * WP];
   __shared__ int sub_ready;   // wave 0: sub-diagonal tiles (k + 1, k) finished for k < sub_ready
   __shared__ int panel_done;  // waves 1-7: 7 (k + 1) once every one of them has finished its panel tiles of column k
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -224,7 +227,9 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
   // factor16 (both triangles from the lower one).  Waves 1-7 meanwhile bring the block-lower part of the 128 x 128
   // block into LDS (coalesced 16-byte loads, all of a thread's loads in flight before its first LDS store) -
   // everything except block (0, 0), which wave 0 writes itself; the barrier of step 0 is the first point where
-  // anybody reads what somebody else loaded.
+  // anybody reads what somebody else loaded.  (Wave 0 running its sub-diagonal step of step 0 ahead of that barrier, on
+  // operands of its own, was measured: 30.9 instead of 29.5 us - the other waves' step 0, the heaviest, then starts
+  // later and wave 0 waits for it at the next barrier.)
   d4_t blk = {0.0, 0.0, 0.0, 0.0};  // wave 0: diagonal block kb, in factor16's layout
   if (wave == 0) {
 #pragma unroll
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
 
   // A[ib][kb] <- A[ib][kb] * W_kb^T, to LDS and to the matrix in global memory
   auto panel_tile = [&](int kb, int ib) {
-    const double* W = Wl[kb & 1];
+    const double* W = Xl[kb * (kb + 1) / 2 + kb];
     d4_t acc = {0.0, 0.0, 0.0, 0.0};
     const int ra = prow(ib * BS + fr) + kb * BS + fk;
 #pragma unroll
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
   // the B operand of the trailing product (P[fr][fk + 4 q] = pt[q]); the result lands in factor16's layout and stays
   // in registers.  (Same products, same summation order as panel_tile / trailing_tile.)
   auto sub_chain_regs = [&](int kb, const d4_t& b, d4_t t) -> d4_t {
-    const double* W = Wl[kb & 1];
+    const double* W = Xl[kb * (kb + 1) / 2 + kb];
     const int ib = kb + 1;
     d4_t pt = {0.0, 0.0, 0.0, 0.0};
     const int rb = prow(ib * BS + fr) + kb * BS + fk;
@@ -342,19 +347,18 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
     const int wb = wave - 1;
     const int base = kb * BS;
     const int jb = wb;  // this wave's column of the inverse row block (tiles jb < kb)
-    // operands of the inverse row block first: their L2 latency overlaps the panel tile
-    double bx[NBLK - 1][4];
-#pragma unroll
-    for (int kk = 0; kk < NBLK - 1; ++kk) {
-      const int k2 = jb + kk;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        bx[kk][q] = (k2 < kb) ? invD[(k2 * BS + fk + 4 * q) * NB + jb * BS + fr] : 0.0;  // X[k2][jb]
-    }
     if (kb + 2 + wb < NBLK) panel_tile(kb, kb + 2 + wb);
     signal(&panel_done, 1);
     if (jb < kb) {
-      const double* W = Wl[kb & 1];
+      double bx[NBLK - 1][4];
+#pragma unroll
+      for (int kk = 0; kk < NBLK - 1; ++kk) {
+        const int k2 = jb + kk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          bx[kk][q] = (k2 < kb) ? Xl[k2 * (k2 + 1) / 2 + jb][(fk + 4 * q) * WP + fr] : 0.0;  // X[k2][jb]
+      }
+      const double* W = Xl[kb * (kb + 1) / 2 + kb];
       double wv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) wv[q] = -W[fr * WP + fk + 4 * q];  // A operand: -W[i = fr][k = fk + 4 q]
@@ -374,7 +378,10 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
 #pragma unroll
       for (int q = 0; q < 4; ++q) X = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q], T[q], X, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) invD[(base + fk + 4 * r) * NB + jb * BS + fr] = X[r];
+      for (int r = 0; r < 4; ++r) {
+        Xl[kb * (kb + 1) / 2 + jb][(fk + 4 * r) * WP + fr] = X[r];
+        invD[(base + fk + 4 * r) * NB + jb * BS + fr] = X[r];
+      }
     }
     if (kb + 1 < NBLK) {
       // trailing tiles (ib, jb), kb < jb <= ib, except (kb + 1, kb + 1) which wave 0 keeps on its chain; they
@@ -393,18 +400,13 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
   };
 
   for (int kb = 0; kb < NBLK; ++kb) {
-    // The barrier of a step orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).  Global memory needs ordering
-    // for one thing: rows of the inverse are read back by bulk() in later steps.  The bulk waves fence their stores
-    // before the barrier; wave 0, whose diagonal block of step kb is first read in step kb + 2, fences at the TOP of
-    // its next step instead - by then the stores have long been acknowledged, and the 0.4 us of store latency a fence
-    // behind factor16 exposed in every step are off the chain.
+    // The barrier of a step orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): nothing a wave writes to global
+    // memory is read again inside this kernel (L and the inverse go out tile by tile; the inverse is also kept in Xl).
     if (wave == 0) {
-      __threadfence_block();
-      factor16(S, Wl[kb & 1], invD, A, ld, kb, info, col0, lane, blk);
+      factor16(S, Xl[kb * (kb + 1) / 2 + kb], invD, A, ld, kb, info, col0, lane, blk);
       lap(4);
-    } else {
-      if (kb > 0) bulk(kb - 1);
-      __threadfence_block();
+    } else if (kb > 0) {
+      bulk(kb - 1);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     lap(1);
