@@ -40,9 +40,9 @@ __device__ inline double rcp_newton(double p) {
 
 // LDS image of the 128 x 128 block: only the block-lower part is kept (block row ib holds
 // (ib + 1) * 16 columns), each row padded by one double so that row and column walks are
-// conflict-free.  74,752 bytes: together with the 2 KiB inverse block this leaves room for a
-// 72 KiB GEMM workgroup on the same CU, which is what lets the panel stream overlap the trailing
-// update (a 150 KiB image had to wait for a completely idle CU).
+// conflict-free: 74,752 bytes.  (Round 1 kept the kernel's LDS below 80 KiB so that it could share a CU with a GEMM
+// workgroup; since the panel chain has CUs of its own - CU-masked streams - the kernel also keeps the inverse in LDS,
+// 153 KiB in all: one workgroup per CU.)
 constexpr int S_DOUBLES = 16 * (16 * 36 + 8);
 __device__ inline int prow(int r) {
   const int ib = r >> 4;
