@@ -144,22 +144,23 @@ def _pt_worker(rank, world, port, n_ladders, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_ladders", [3, 1])
-def test_tempering_run_two_ranks_gloo(tmp_path, n_ladders):
-    """Ladders block-partitioned over 2 ranks give the state a single process gets (n_ladders=1: rank 1 idle)."""
+@pytest.mark.parametrize("n_ladders,world", [(3, 2), (1, 2), (4, 3)])
+def test_tempering_run_two_ranks_gloo(tmp_path, n_ladders, world):
+    """Ladders block-partitioned over the ranks give the state a single process gets (n_ladders = 1: rank 1 idle;
+    4 ladders over 3 ranks: blocks of 2, 1, 1)."""
     import random
 
     from inference_amd import sharding
     from oracle import gp_oracle as orc
 
     port = _free_port()
-    mp.spawn(_pt_worker, args=(2, port, n_ladders, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_pt_worker, args=(world, port, n_ladders, str(tmp_path)), nprocs=world, join=True)
     x, y, e = _pt_problem()
     gp = orc.OracleGp(x, y, e, kernel=orc.SE)
     serial, evals = sharding.tempering_run(_make_ladder_factory(gp), n_ladders, 6, swap_interval=3,
                                            batch_posterior=_batch_of(gp))
     assert serial.shape == (n_ladders, 3, 4)
-    for r in range(2):
+    for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"pt{r}.npy"), serial)
         assert int(np.load(tmp_path / f"ev{r}.npy")[0]) == evals
     assert evals >= n_ladders * 3 * 6 * 3
