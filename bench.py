@@ -153,7 +153,7 @@ def kernel_rows(eng, step, _lib, N, M):
             rows.append({"kernel": name, "bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": a / PEAK_HBM_GBS, "launches": p["launches"], "avg_ms": p["ms"] / p["launches"], "bytes": what})
 
-    hbm("kbuild_kernel<true> (K-build, lower tiles) + kbuild_kernel<false> (cross-covariance of the query points)", kb,
+    hbm("kbuild_kernel<true, SE> (K-build, lower tiles) + kbuild_kernel<false, SE> (cross-covariance of the query points)", kb,
         "4 N^2 B per fit (lower tiles written once) + 8 M N B per predict")
     hbm("trsv_fwd_flow_kernel + trsv_bwd_flow_kernel (alpha = L^-T L^-1 (y - mu))", sv, "4 N^2 B per sweep (L read once)")
     if ts["ms"] > 0:

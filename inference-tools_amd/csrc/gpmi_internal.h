@@ -250,7 +250,7 @@ void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, in
 // batched, in-order factorisation of bs.count matrices (small problems: no look-ahead)
 void potrf_lower_batched(gpmi_ctx* c, hipStream_t s, double* A, int64_t np, int64_t ld, double* invD,
                          int* info, const BatchShape& bs);
-void launch_kbuild_square_batched(hipStream_t s, const KParams* pdev, int batch, const double* x,
+void launch_kbuild_square_batched(hipStream_t s, int kernel, const KParams* pdev, int batch, const double* x,
                                   int64_t n, int64_t np, const double* noise, double* A, int64_t ld,
                                   int64_t stride);
 // blocked right-looking Cholesky, in place, lower; invD receives the inverses of the diagonal blocks

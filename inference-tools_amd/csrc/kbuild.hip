@@ -10,38 +10,43 @@ namespace {
 
 constexpr int KT = 64;  // output tile edge
 
+// KERNEL is a template parameter of the builders: with the choice made at run time every one of the 16 unrolled
+// elements of a thread carried both exp and pow (6 000 instructions per kernel, well beyond the instruction cache
+// two CUs share); one function per build keeps the SquaredExponential kernel at a quarter of that.
+template <int KERNEL>
 __device__ inline double kfun(const KParams& p, double s) {
   // s = sum_k 0.5 * dx_k^2 / l_k^2  (>= 0)
-  if (p.kernel == GPMI_KERNEL_SE) return exp(-s);              // covariance.py:254
+  if (KERNEL == GPMI_KERNEL_SE) return exp(-s);                // covariance.py:254
   return pow(1.0 + s / p.kappa, -p.kappa);                      // covariance.py:348
 }
 
 // SQUARE: U == V, jitter + noise on the diagonal, identity in the padding (rows/cols >= n).
-template <bool SQUARE>
+template <bool SQUARE, int KERNEL>
 __device__ inline void kbuild_body(const KParams& p, const double* __restrict__ U, int64_t nu,
                                    const double* __restrict__ V, int64_t nv,
                                    const double* __restrict__ noise, double* __restrict__ out,
                                    int64_t ld, int lower_only);
 
-template <bool SQUARE>
+template <bool SQUARE, int KERNEL>
 __global__ __launch_bounds__(256) void kbuild_kernel(KParams p, const double* __restrict__ U,
                                                      int64_t nu, const double* __restrict__ V,
                                                      int64_t nv, const double* __restrict__ noise,
                                                      double* __restrict__ out, int64_t ld,
                                                      int lower_only) {
-  kbuild_body<SQUARE>(p, U, nu, V, nv, noise, out, ld, lower_only);
+  kbuild_body<SQUARE, KERNEL>(p, U, nu, V, nv, noise, out, ld, lower_only);
 }
 
 // batched square build: problem z uses hyper-parameters pdev[z] and writes matrix out + z * stride
+template <int KERNEL>
 __global__ __launch_bounds__(256) void kbuild_batched_kernel(const KParams* __restrict__ pdev,
                                                              const double* __restrict__ x, int64_t n,
                                                              const double* __restrict__ noise,
                                                              double* __restrict__ out, int64_t ld,
                                                              int64_t stride) {
-  kbuild_body<true>(pdev[blockIdx.z], x, n, x, n, noise, out + (int64_t)blockIdx.z * stride, ld, 2);
+  kbuild_body<true, KERNEL>(pdev[blockIdx.z], x, n, x, n, noise, out + (int64_t)blockIdx.z * stride, ld, 2);
 }
 
-template <bool SQUARE>
+template <bool SQUARE, int KERNEL>
 __device__ inline void kbuild_body(const KParams& p, const double* __restrict__ U, int64_t nu,
                                    const double* __restrict__ V, int64_t nv,
                                    const double* __restrict__ noise, double* __restrict__ out,
@@ -104,7 +109,7 @@ __device__ inline void kbuild_body(const KParams& p, const double* __restrict__ 
       const int64_t gj = j0 + tx * 4 + c;
       double val;
       if (gi < nu && gj < nv) {
-        double cfun = kfun(p, s[r][c]);
+        double cfun = kfun<KERNEL>(p, s[r][c]);
         if (SQUARE && gi == gj) {
           // a^2 (C + 1e-12) + WhiteNoise + sig   (covariance.py:254-255, 163-169; regression.py:239)
           val = p.a2 * (cfun + 1e-12);
@@ -133,12 +138,23 @@ __global__ void add_full_kernel(double* __restrict__ A, int64_t ld, const double
 
 }  // namespace
 
+// dispatch on the covariance function (a template parameter of the kernels)
+template <bool SQUARE>
+static void launch_kb(dim3 grid, hipStream_t s, const KParams& p, const double* U, int64_t nu, const double* V,
+                      int64_t nv, const double* noise, double* out, int64_t ld, int lower_only) {
+  if (p.kernel == GPMI_KERNEL_SE)
+    hipLaunchKernelGGL((kbuild_kernel<SQUARE, GPMI_KERNEL_SE>), grid, dim3(256), 0, s, p, U, nu, V, nv, noise, out, ld,
+                       lower_only);
+  else
+    hipLaunchKernelGGL((kbuild_kernel<SQUARE, GPMI_KERNEL_RQ>), grid, dim3(256), 0, s, p, U, nu, V, nv, noise, out, ld,
+                       lower_only);
+}
+
 void launch_kbuild_square(hipStream_t s, const KParams& p, const double* x, int64_t n, int64_t np,
                           const double* noise, double* A, int64_t ld, bool lower_only) {
   const unsigned nt = (unsigned)(np / KT);
   dim3 grid = lower_only ? dim3(nt * (nt + 1) / 2) : dim3(nt, nt);
-  hipLaunchKernelGGL(kbuild_kernel<true>, grid, dim3(256), 0, s, p, x, n, x, n, noise, A, ld,
-                     lower_only ? 2 : 0);
+  launch_kb<true>(grid, s, p, x, n, x, n, noise, A, ld, lower_only ? 2 : 0);
 }
 
 // The lower tiles in two launches: part 1 = the first `split_cols` columns (all rows), part 2 = everything to the right
@@ -148,27 +164,28 @@ void launch_kbuild_square_part(hipStream_t s, const KParams& p, const double* x,
                                const double* noise, double* A, int64_t ld, int part, int split_cols) {
   const unsigned nt = (unsigned)(np / KT), sp = (unsigned)(split_cols / KT);
   if (part == 1) {
-    hipLaunchKernelGGL(kbuild_kernel<true>, dim3(sp, nt), dim3(256), 0, s, p, x, n, x, n, noise, A, ld, 1);
+    launch_kb<true>(dim3(sp, nt), s, p, x, n, x, n, noise, A, ld, 1);
   } else if (nt > sp) {
     const unsigned m = nt - sp;
-    hipLaunchKernelGGL(kbuild_kernel<true>, dim3(m * (m + 1) / 2), dim3(256), 0, s, p, x, n, x, n, noise, A, ld,
-                       2 | (int)(sp << 8));
+    launch_kb<true>(dim3(m * (m + 1) / 2), s, p, x, n, x, n, noise, A, ld, 2 | (int)(sp << 8));
   }
 }
 
-void launch_kbuild_square_batched(hipStream_t s, const KParams* pdev, int batch, const double* x,
+void launch_kbuild_square_batched(hipStream_t s, int kernel, const KParams* pdev, int batch, const double* x,
                                   int64_t n, int64_t np, const double* noise, double* A, int64_t ld,
                                   int64_t stride) {
   const unsigned nt = (unsigned)(np / KT);
   dim3 grid(nt * (nt + 1) / 2, 1, (unsigned)batch);  // lower tiles only, one-dimensional (kbuild_body, mode 2)
-  hipLaunchKernelGGL(kbuild_batched_kernel, grid, dim3(256), 0, s, pdev, x, n, noise, A, ld, stride);
+  if (kernel == GPMI_KERNEL_SE)
+    hipLaunchKernelGGL(kbuild_batched_kernel<GPMI_KERNEL_SE>, grid, dim3(256), 0, s, pdev, x, n, noise, A, ld, stride);
+  else
+    hipLaunchKernelGGL(kbuild_batched_kernel<GPMI_KERNEL_RQ>, grid, dim3(256), 0, s, pdev, x, n, noise, A, ld, stride);
 }
 
 void launch_kbuild_cross(hipStream_t s, const KParams& p, const double* U, int64_t mu, int64_t mp,
                          const double* V, int64_t n, int64_t np, double* out, int64_t ld) {
   dim3 grid((unsigned)(np / KT), (unsigned)(mp / KT));
-  hipLaunchKernelGGL(kbuild_kernel<false>, grid, dim3(256), 0, s, p, U, mu, V, n, nullptr, out, ld,
-                     0);
+  launch_kb<false>(grid, s, p, U, mu, V, n, nullptr, out, ld, 0);
 }
 
 void launch_add_full(hipStream_t s, double* A, int64_t ld, const double* Y, int64_t n) {

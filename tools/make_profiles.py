@@ -48,7 +48,7 @@ out = {
                     "achieved_tflops_with_rocprof_avg": bench["roofline"]["flop_per_launch_avg"] / (upd_us * 1e-6) / 1e12},
 }
 for key, name in (("update128", "gemm_dma_kernel<1, 0> (trailing update, 128x128 tiles)"),
-                  ("kbuild", "kbuild_kernel<true> (covariance build, lower tiles)"),
+                  ("kbuild", "kbuild_kernel<true, SE> (covariance build, lower tiles)"),
                   ("trsv_fwd", "trsv_fwd_flow_kernel (forward sweep)")):
     if key not in pmc:
         continue

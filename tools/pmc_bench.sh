@@ -13,7 +13,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + '/*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
-        key = 'update128' if ('gemm_dma_kernel<1, 0>' in n or 'gemm_nt_kernel<1, 0, 0, 128, 128>' in n) else 'kbuild' if 'kbuild_kernel<true>' in n else \
+        key = 'update128' if ('gemm_dma_kernel<1, 0>' in n or 'gemm_nt_kernel<1, 0, 0, 128, 128>' in n) else 'kbuild' if 'kbuild_kernel<true' in n else \
               'trsv_fwd' if 'trsv_fwd_flow' in n else None
         if key:
             agg[key][r['Counter_Name']].append(float(r['Counter_Value']))

@@ -6,7 +6,7 @@ f = glob.glob(d + '/*/*kernel_trace.csv')[0]
 rows = list(csv.DictReader(open(f)))
 ks = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'][27:60], r['Grid_Size_X'], r['Stream_Id']) for r in rows]
 ks.sort()
-idx = [i for i, k in enumerate(ks) if 'kbuild_kernel<true>' in k[2]]
+idx = [i for i, k in enumerate(ks) if 'kbuild_kernel<true' in k[2]]
 s = idx[-1]
 seg = ks[s:s + n]
 t0 = seg[0][0]

@@ -14,8 +14,8 @@ if mode == "stats":
     for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print('"%s",%d,%.3f,%.2f,%.2f' % (n, c, t / 1e6, t / c / 1e3, 100.0 * t / tot))
     sys.exit()
-sq = [i for i, k in enumerate(ks) if 'kbuild_kernel<true>' in k[2]]
-cr = [i for i, k in enumerate(ks) if 'kbuild_kernel<false>' in k[2]]
+sq = [i for i, k in enumerate(ks) if 'kbuild_kernel<true' in k[2]]
+cr = [i for i, k in enumerate(ks) if 'kbuild_kernel<false' in k[2]]
 s = sq[-1]; e = [i for i in cr if i > s][0]
 seg = ks[s:e] if mode == "fit" else ks[e:]
 t0 = seg[0][0]

@@ -6,7 +6,7 @@ f = glob.glob(d + '/*/*kernel_trace.csv')[0]
 rows = list(csv.DictReader(open(f)))
 ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r['Grid_Size_X'], r['Workgroup_Size_X'],
              r.get('Stream_Id', r.get('Queue_Id', '?'))) for r in rows)
-idx = [i for i, k in enumerate(ks) if 'kbuild_kernel<true>' in k[2]]
+idx = [i for i, k in enumerate(ks) if 'kbuild_kernel<true' in k[2]]
 s = idx[-1]
 full = ks[s:]
 t0 = full[0][0]
