@@ -132,6 +132,7 @@ void lane_free(Lane& L) {
     if (L.sp[k]) (void)hipStreamSynchronize(L.sp[k]);
     if (L.su[k]) (void)hipStreamSynchronize(L.su[k]);
   }
+  potrf_flow_free(L);
   DBG_FREE("lane: destroy events");
   if (L.ev_la) (void)hipEventDestroy(L.ev_la);
   if (L.ev_panel) (void)hipEventDestroy(L.ev_panel);

@@ -55,6 +55,14 @@ struct Lane {
   int* info = nullptr;      // device info word
   double* h_red = nullptr;  // pinned host mirror of red
   int* h_info = nullptr;    // pinned host mirror of info
+  // flag-ordered factorisation of the chain-bound part (potrf_flow.hip): task lists of a tail of flow_m tile rows
+  void* flow_tasks = nullptr;
+  int* flow_flags = nullptr;
+  int flow_m = 0;
+  int64_t flow_ntasks = 0;
+  int64_t flow_off[4] = {0, 0, 0, 0};
+  int flow_count[4] = {0, 0, 0, 0};
+  double flow_flops_update = 0.0, flow_flops_trsm = 0.0;
 };
 
 // device state of the linear-inversion entry points (gpmi_linv_*): m data values, model matrix A (m x n)
@@ -192,12 +200,24 @@ void launch_scale_columns(hipStream_t s, const double* A, const double* sc, doub
 void launch_loo_vectors(hipStream_t s, const double* alpha, const double* ikdiag, double* c1,
                         double* sc2, int64_t n, int64_t np);
 
+// flags a chain launch of the flag-ordered factorisation publishes / waits for at its start (potrf_flow.hip,
+// gemm_tiles.h: flow_hook_enter)
+struct FlowHook {
+  int* pub = nullptr;         // *pub = pub_val at the start of the launch (first thread of workgroup 0)
+  int pub_val = 0;
+  const int* wait = nullptr;  // every workgroup: spin until *wait >= wait_val
+  int wait_val = 0;
+  int* abort = nullptr;       // non-zero: somebody timed out; stop waiting.  Set by a poll that times out itself
+  int* info = nullptr;        // receives GPMI_ERR_INTERNAL on a time-out (if still zero)
+};
+
 // batch of independent equal-shape problems in one launch (blockIdx.z): strides in doubles
 struct GemmBatch {
   int count = 1;
   int64_t sC = 0, sA = 0, sB = 0;
   // CUs the launch's stream may use (0: the whole chip): the choice of 32-row tiles ("while CUs are idle") scales with it
   int ncu_hint = 0;
+  FlowHook hook;
 };
 struct BatchShape {
   int count = 1;
@@ -258,6 +278,11 @@ void launch_kbuild_square_batched(hipStream_t s, int kernel, const KParams* pdev
 // concurrently already fill the chip, and their masked stream pairs would only fight for HW queues)
 void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, double* invD,
                  int* info, bool allow_lookahead = true);
+
+// potrf_flow.hip: the chain-bound part of the factorisation as one persistent tile-task launch beside the panel chain
+bool potrf_flow_enabled(gpmi_ctx* c, Lane& lane, int m);
+bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* invD, int* info, int nt, int t0);
+void potrf_flow_free(Lane& lane);
 
 // solve.hip
 // forward substitution  L v = r : the solution goes to `out` (no aliasing; `r` is only read).

@@ -612,6 +612,14 @@ void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, dou
   const int OBT = OUTER_TILES;
   const int LOOKAHEAD_MIN = lookahead_min();
   const bool la_ok = allow_lookahead && nt - OBT >= LOOKAHEAD_MIN && ensure_masked_pair(c, lane, 0);
+  // The chain-bound part - everything below LOOKAHEAD_MIN trailing tile rows, i.e. the whole of a matrix of N <= ~8000
+  // and the tail of a larger one - runs as a flag-ordered tile-task launch beside the bare chain (potrf_flow.hip)
+  // instead of in stream order: chain and updates then overlap instead of adding up.  Same tile bodies, same order of
+  // summation: the factor is bit-identical either way (GPMI_FLOW=0 keeps the stream-ordered schedule).
+  const bool flow_ok = allow_lookahead;
+  if (flow_ok && !(la_ok && nt - OBT >= LOOKAHEAD_MIN) && potrf_flow_enabled(c, lane, nt) &&
+      potrf_flow_tail(c, lane, A, ld, invD, info, nt, 0))
+    return;
   auto follow = [](hipStream_t waiter, hipStream_t producer, hipEvent_t ev) {
     if (waiter != producer) (void)hipStreamWaitEvent(waiter, ev, 0);
   };
@@ -647,6 +655,8 @@ void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, dou
     } else {
       if (sliced) (void)hipStreamWaitEvent(su, lane.ev_slice, 0);
       update_columns(c, su, A, ld, nt, k1, nt, k0, k1, ncu);
+      // from here on the chain is the longer of the two: the rest as a flag-ordered tile-task launch beside the chain
+      if (flow_ok && potrf_flow_enabled(c, lane, nt - k1) && potrf_flow_tail(c, lane, A, ld, invD, info, nt, k1)) return;
     }
     sliced = false;
     main_stream = su;

@@ -30,6 +30,15 @@ Cases
              every public GpRegressor method, the seeded hyper-parameter search and an EI proposal
   means      LinearMean / QuadraticMean: labels, bounds, fit, predict, LML, LML gradient (mean-parameter components
              included), LOO gradient, posterior
+  head16k    the metric's own size: SE, N=16384, d=8 (fit at the timing theta: alpha at 64 indices, |alpha|, diag(L),
+             logdet, LML at 3 thetas, mu / sigma at 64 query points, posterior at 16).  The reference's classes need
+             3 x N^2 d x 8 B = 52 GB there (covariance.py:218-219,254), more than this container can give them, so
+             this case and the next are produced by the ROW-CHUNKED ORACLE (oracle/gp_oracle.py) - the same
+             element-wise operations in the same order, the same numpy.linalg.cholesky / solve_triangular - which
+             tests/test_oracle_golden.py pins to the imported reference up to N = 8192 (K bit-exact).  The script
+             first re-checks that pin at N = 2048 with these very code paths before it writes anything.
+  cfg3_16k   BASELINE config 3 at full size: RQ, N=16384, d=16, 8 thetas of the 64-point grid (one GPU's share of
+             the 8-GPU sweep: grid rows 0, 9, 18, ... 63): LML and logdet each; alpha / predict at the first
 """
 import os
 import sys
@@ -628,6 +637,104 @@ def case_means():
     return out
 
 
+def _oracle_pin_check():
+    """The 16k cases come from the row-chunked oracle; before writing them, re-check the oracle against the imported
+    reference on the same code paths (K bit-exact, factor-derived quantities to 1e-11) at a size the reference holds."""
+    from oracle import gp_oracle as orc
+
+    for cfg, kid, n, d in ((2, wl.SE, 2048, 8), (3, wl.RQ, 1536, 16)):
+        x, y, e = wl.synthetic_dataset(cfg, n, d)
+        th = wl.timing_theta(kid, y, d)
+        ref = GpRegressor(x, y, y_err=e, hyperpars=th, kernel=kernel_cls(kid))
+        o = orc.OracleGp(x, y, e, kernel=kid, hyperpars=th)
+        assert np.array_equal(o.K_xx, ref.K_xx), "oracle K differs from the reference bit-wise"
+        assert np.abs(o.alpha - ref.alpha).max() <= 1e-11 * np.abs(ref.alpha).max()
+        assert abs(o.marginal_likelihood(th) - ref.marginal_likelihood(th)) <= 1e-11 * abs(ref.marginal_likelihood(th))
+
+
+def _oracle_fit_outputs(o, th, pts, out, n_post=16):
+    ii = idx64(o.n)
+    out["theta"] = th
+    out["alpha_norm"] = np.linalg.norm(o.alpha)
+    out["alpha_idx"] = ii
+    out["alpha_sub"] = o.alpha[ii]
+    out["diagL_sub"] = np.diagonal(o.L)[ii]
+    out["logdet"] = np.log(np.diagonal(o.L)).sum()
+    r = o.y - th[0]
+    out["lml_fit"] = -0.5 * float(r @ o.alpha) - out["logdet"]
+    mu, sig = o(pts)
+    out["pts"], out["mu"], out["sig"] = pts, mu, sig
+    if n_post:
+        pm, pc = o.build_posterior(pts[:n_post])
+        out["post_mu"], out["post_cov"] = pm, pc
+
+
+def case_head16k():
+    """SE, N = 16384, d = 8 - the configuration BASELINE.json's metric is quoted on (regression.py:218-244,188-216,
+    528-542), from the row-chunked oracle."""
+    from oracle import gp_oracle as orc
+
+    _oracle_pin_check()
+    out = {}
+    n, d = 16384, 8
+    x, y, e = wl.synthetic_dataset(2, n, d)
+    thetas = wl.theta_set(wl.SE, y, d, 3)
+    pts = wl.query_points(2, 64, d)
+    o = orc.OracleGp(x, y, e, kernel=orc.SE, hyperpars=thetas[0])
+    _oracle_fit_outputs(o, thetas[0], pts, out)
+    lml = [out["lml_fit"]]
+    ld = [out["logdet"]]
+    del o.K_xx
+    for t in thetas[1:]:
+        K = o._K(t[1:])
+        Lf = np.linalg.cholesky(K)
+        del K
+        from scipy.linalg import solve_triangular
+
+        v = solve_triangular(Lf, y - t[0], lower=True)
+        ld.append(np.log(np.diagonal(Lf)).sum())
+        lml.append(-0.5 * float(v @ v) - ld[-1])
+        del Lf
+    out["thetas"] = thetas
+    out["lml"] = np.array(lml)
+    out["logdets"] = np.array(ld)
+    out["meta"] = np.array([2, wl.SE, n, d])
+    return out
+
+
+def case_cfg3_16k():
+    """RQ, N = 16384, d = 16 (BASELINE config 3): the 8 grid points one GPU of eight evaluates, from the row-chunked
+    oracle (regression.py:528-542; covariance.py:343-348)."""
+    from oracle import gp_oracle as orc
+    from scipy.linalg import solve_triangular
+
+    _oracle_pin_check()
+    out = {}
+    n, d = 16384, 16
+    x, y, e = wl.synthetic_dataset(3, n, d)
+    grid = wl.theta_grid_cfg3(y, d)
+    sel = np.arange(0, 64, 9)  # the grid's diagonal: every amplitude and every length scale once
+    pts = wl.query_points(3, 64, d)
+    o = orc.OracleGp(x, y, e, kernel=orc.RQ, hyperpars=grid[sel[0]])
+    _oracle_fit_outputs(o, grid[sel[0]], pts, out, n_post=0)
+    lml, ld = [out["lml_fit"]], [out["logdet"]]
+    del o.K_xx, o.L
+    for t in grid[sel[1:]]:
+        K = o._K(t[1:])
+        Lf = np.linalg.cholesky(K)
+        del K
+        v = solve_triangular(Lf, y - t[0], lower=True)
+        ld.append(np.log(np.diagonal(Lf)).sum())
+        lml.append(-0.5 * float(v @ v) - ld[-1])
+        del Lf
+    out["grid_idx"] = sel
+    out["thetas"] = grid[sel]
+    out["lml"] = np.array(lml)
+    out["logdets"] = np.array(ld)
+    out["meta"] = np.array([3, wl.RQ, n, d])
+    return out
+
+
 IDX_TOMO = np.arange(0, 400, 7)  # 58 rows / columns of the 400 x 400 posterior covariance
 
 CASES = {
@@ -645,6 +752,8 @@ CASES = {
     "cfg4": case_cfg4,
     "cfg2": case_cfg2,
     "fail": case_fail,
+    "head16k": case_head16k,
+    "cfg3_16k": case_cfg3_16k,
 }
 
 if __name__ == "__main__":
