@@ -37,11 +37,11 @@ thread_local std::string g_create_err;
     }                          \
   } while (0)
 
-// a negative `info` is written by the single-launch triangular sweeps when their polling timed out
+// a negative `info` is written by the flag-ordered kernels (triangular sweeps, potrf_flow.hip) when a poll timed out
 #define INFOCHK(ctx, inf)                                                              \
   do {                                                                                 \
     if ((inf) < 0) {                                                                   \
-      (ctx)->err = "internal error: a triangular sweep timed out waiting for a block"; \
+      (ctx)->err = "internal error: a flag-ordered kernel timed out (triangular sweep / tile-task factorisation)"; \
       return GPMI_ERR_INTERNAL;                                                        \
     }                                                                                  \
   } while (0)

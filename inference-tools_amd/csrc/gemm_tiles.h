@@ -515,11 +515,15 @@ __device__ __forceinline__ int flow_ld(const int* p) {
 }
 // called by every thread of the workgroup at the top of a chain kernel
 __device__ __forceinline__ void flow_hook_enter(const FlowHook& h) {
-  if (h.pub && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+  if (h.trace && blockIdx.x == 0 && threadIdx.x == 0) h.trace[0] = __builtin_amdgcn_s_memrealtime();
+  if (h.pub && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
     __hip_atomic_store(h.pub, h.pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (h.wait) {
     if (threadIdx.x == 0) {
       int spins = 0;
+      unsigned long long t0 = 0;
+      if (h.wait_ticks) t0 = __builtin_amdgcn_s_memrealtime();
       while (flow_ld(h.wait) < h.wait_val) {
         __builtin_amdgcn_s_sleep(4);
         if ((++spins & 63) == 0 && flow_ld(h.abort)) break;
@@ -529,6 +533,8 @@ __device__ __forceinline__ void flow_hook_enter(const FlowHook& h) {
           break;
         }
       }
+      if (h.wait_ticks) atomicAdd(h.wait_ticks, __builtin_amdgcn_s_memrealtime() - t0);
+      if (h.trace && blockIdx.x == 0) h.trace[1] = __builtin_amdgcn_s_memrealtime();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }

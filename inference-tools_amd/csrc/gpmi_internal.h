@@ -57,11 +57,10 @@ struct Lane {
   int* h_info = nullptr;    // pinned host mirror of info
   // flag-ordered factorisation of the chain-bound part (potrf_flow.hip): task lists of a tail of flow_m tile rows
   void* flow_tasks = nullptr;
+  int* flow_off = nullptr;
   int* flow_flags = nullptr;
-  int flow_m = 0;
+  int flow_m = 0, flow_nwg = 0;
   int64_t flow_ntasks = 0;
-  int64_t flow_off[4] = {0, 0, 0, 0};
-  int flow_count[4] = {0, 0, 0, 0};
   double flow_flops_update = 0.0, flow_flops_trsm = 0.0;
 };
 
@@ -209,6 +208,8 @@ struct FlowHook {
   int wait_val = 0;
   int* abort = nullptr;       // non-zero: somebody timed out; stop waiting.  Set by a poll that times out itself
   int* info = nullptr;        // receives GPMI_ERR_INTERNAL on a time-out (if still zero)
+  unsigned long long* wait_ticks = nullptr;  // diagnostics: 10 ns ticks spent waiting, summed over the workgroups
+  unsigned long long* trace = nullptr;       // diagnostics: {launch start, wait over} (s_memrealtime), workgroup 0
 };
 
 // batch of independent equal-shape problems in one launch (blockIdx.z): strides in doubles

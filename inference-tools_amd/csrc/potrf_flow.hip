@@ -9,8 +9,8 @@
 //       D(k)  = potrf_diag of tile (k, k)
 //       Tc(k) = tile (k+1, k) <- tile (k+1, k) invD(k)^T              (4 workgroups of 32 rows)
 //       Uc(k) = tile (k+1, k+1) -= L(k+1, k) L(k+1, k)^T               (3 workgroups of 64 x 64)
-//   update stream (the other CUs): ONE persistent launch whose workgroups pull tile tasks from in-order queues, a task
-//   being claimed only when the flags of its inputs are set:
+//   update stream (the other CUs): ONE persistent launch; every workgroup owns a fixed list of tile tasks and runs it in
+//   order, starting a task when the flags of its inputs are set:
 //       T(i, k), i >= k + 2    panel TRSM of tile (i, k), four 32-row slabs
 //       U(i, j, k)             tile (i, j) -= L(i, k) L(j, k)^T for ONE column k (K = 128), four 64 x 64 sub-tiles;
 //                              columns of the tile's own outer panel (and, near the diagonal, of the panel before it)
@@ -25,16 +25,27 @@
 // visible) and waits - normally not at all - for the flags of the tile it is about to touch.  A task kernel workgroup
 // releases its stores (agent-scope release fence) before it bumps a flag and acquires after it has claimed a task.
 //
-// Progress: every queue is sorted by a virtual time under which each task comes after all its inputs, a task is
-// claimed only when its inputs are complete, and claimed tasks run to completion - so the earliest unclaimed task of
-// the earliest queue head always becomes ready, whatever the dispatch order and however few workgroups are resident.
+// Scheduling is static: the tasks, sorted by a virtual time under which each task comes after all its inputs (T(i, k)
+// at k, U(., ., k) at k + 1/2, Z(., ., q) right behind T(., 4q + 3)), are dealt round-robin to the workgroups - the
+// tasks of the rows next to the chain (i - k <= 3) to the first FLOW_NEAR_WGS workgroups, which do nothing else, so
+// that what the chain waits for never queues behind a K = 512 tile.  A workgroup polls only the two or three flags
+// of ITS next task: no shared queue heads, no claims, nothing every workgroup re-reads.  (First version: dynamic
+// in-order queues with a claim word per task, every idle workgroup re-reading ~300 flags at every publication:
+// 60 ms for a 7 ms factorisation - the polling saturated the fabric; tools/sim/flow_sim.py prices the static deal
+// at 3.7 ms against 3.6 for ideal queues.)
+// Progress: every list is in virtual-time order, so the earliest unfinished task overall is the next one of its
+// owner and all its inputs are complete - PROVIDED every workgroup of the launch is resident (one that never starts
+// would hold its tasks back): the launch has two workgroups per CU of the update stream's CU mask, which is what
+// the kernel's 64 KiB of LDS and 256 VGPRs admit.
 // The only cross-launch dependency is between the chain stream and the task kernel, which run on disjoint CU masks.
 // Every poll is bounded: a time-out (a bug or a serialising profiler, never a wait) sets the abort word, every
 // poller gives up, and the host reports GPMI_ERR_INTERNAL through `info` instead of hanging the GPU.
 // tools/sim/flow_sim.py holds the same task list as an executable model (NumPy replay in random admissible order
 // + a discrete-event timing model that chose the queue layout).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <tuple>
 #include <vector>
 
@@ -46,7 +57,14 @@ namespace {
 
 constexpr int NB = GPMI_NB;
 constexpr int OBT = 4;        // tile columns per outer panel (K = 512 chunks)
-constexpr int FLOW_NQ = 4;    // queues: rows within 3 / within 8 tile rows of the column being applied / the rest / Z
+// tasks of the rows within FLOW_NEAR_D (3) tile rows of the column being applied go to the first FLOW_NEAR_WGS (32)
+// workgroups (GPMI_FLOW_NEAR_D, GPMI_FLOW_NEAR_WGS: tuning aids)
+int env_int(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return e ? std::atoi(e) : dflt;
+}
+const int FLOW_NEAR_D = env_int("GPMI_FLOW_NEAR_D", 3);
+const int FLOW_NEAR_WGS = (env_int("GPMI_FLOW_NEAR_WGS", 32) + 7) / 8 * 8;
 constexpr int FT_T = 0, FT_U = 1, FT_Z = 2;
 
 struct FlowTask {
@@ -56,22 +74,23 @@ struct FlowTask {
 static_assert(sizeof(FlowTask) == 12, "FlowTask layout");
 
 // hot words on lines of their own
-constexpr int FL_DDONE = 0, FL_ABORT = 32, FL_HEAD = 64, FL_LCNT = 64 + 32 * FLOW_NQ;
+constexpr int FL_DDONE = 0, FL_ABORT = 32, FL_STATS = 64, FL_LCNT = 128;
 __host__ __device__ inline int flow_f_off(int m) { return FL_LCNT + ((m + 31) / 32) * 32; }
-inline int flow_claim_off(int m) { return flow_f_off(m) + ((m * m + 31) / 32) * 32; }  // one claim word per task
-inline int flow_flag_ints(int m, int64_t ntasks) { return flow_claim_off(m) + (int)ntasks; }
+inline int flow_flag_ints(int m) { return flow_f_off(m) + m * m; }
 
 struct FlowArgs {
   double* A;           // tile (0, 0) of the tail
   const double* invD;  // inverse of diagonal block 0 of the tail
   int64_t ld;
   int m;
-  const FlowTask* tasks[FLOW_NQ];
-  int* claim[FLOW_NQ];  // claim words of queue q
-  int count[FLOW_NQ];
+  const FlowTask* tasks;  // the lists, workgroup after workgroup
+  const int* off;         // list of workgroup b: tasks[off[b] .. off[b + 1])
   int* flags;
   int* info;
   unsigned long long* stamp;
+  unsigned long long* stats;  // GPMI_FLOW_STATS: {waiting ticks, body ticks, polls, tasks} summed over the workgroups
+  unsigned long long* trace;  // GPMI_FLOW_TRACE: per task {poll start, inputs seen, body done, published} (10 ns ticks)
+  int fault;                  // test hook (GPMI_FLOW_FAULT=<n>): task n never sets its flag; -1: none
 };
 
 __device__ __forceinline__ bool flow_ready(const FlowTask& t, const int* __restrict__ fl, int m) {
@@ -116,80 +135,42 @@ __global__ __launch_bounds__(256, 2) void flow_task_kernel(FlowArgs a) {
   int* Lcnt = fl + FL_LCNT;
   int* F = fl + flow_f_off(a.m);
   if (a.stamp && tid == 0 && blockIdx.x < 8) a.stamp[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-  for (;;) {
+  unsigned long long scan_ticks = 0, body_ticks = 0;  // GPMI_FLOW_STATS (wave 0)
+  int nscan = 0, ntask = 0;
+  const int n_end = a.off[blockIdx.x + 1];
+  for (int n = a.off[blockIdx.x];; ++n) {
     if (wave == 0) {
-      // Queues in priority order; of each, the wave examines the 64 tasks from the queue's head on at once (lane l:
-      // claim word and input flags of task head + l) and takes a ready one with a CAS on ITS claim word - claims of
-      // different tasks do not serialise on one word.  Which of the ready ones: the (workgroup id mod 4)-th, so
-      // that workgroups arriving together spread over the first few instead of all racing for the first.  The head
-      // (every task before it is claimed) is advanced by whoever sees claimed tasks at it.
-      int got = 0;
-      int spins = 0;
-      for (;;) {
-        bool any_live = false;
-        for (int q = 0; q < FLOW_NQ && got == 0; ++q) {
-          const FlowTask* tq = q == 0 ? a.tasks[0] : q == 1 ? a.tasks[1] : q == 2 ? a.tasks[2] : a.tasks[3];
-          int* cq = q == 0 ? a.claim[0] : q == 1 ? a.claim[1] : q == 2 ? a.claim[2] : a.claim[3];
-          const int nq = q == 0 ? a.count[0] : q == 1 ? a.count[1] : q == 2 ? a.count[2] : a.count[3];
-          const int h = __builtin_amdgcn_readfirstlane(flow_ld(fl + FL_HEAD + 32 * q));
-          if (h >= nq) continue;
-          any_live = true;
-          const int x = h + lane;
-          bool taken = true, rdy = false;
-          FlowTask mine{};
-          if (x < nq) {
-            taken = flow_ld(cq + x) != 0;
-            if (!taken) {
-              mine = tq[x];
-              rdy = flow_ready(mine, fl, a.m);
+      int got = -1;
+      if (n < n_end) {
+        const FlowTask mine = a.tasks[n];
+        unsigned long long t_scan = 0;
+        if (a.stats || a.trace) t_scan = __builtin_amdgcn_s_memrealtime();
+        if (a.trace && lane == 0) a.trace[4 * (int64_t)n] = t_scan;
+        int spins = 0;
+        got = 1;
+        while (!flow_ready(mine, fl, a.m)) {
+          __builtin_amdgcn_s_sleep(8);
+          ++spins;
+          if ((spins & 63) == 0 && flow_ld(fl + FL_ABORT)) {
+            got = -1;
+            break;
+          }
+          if (spins > FLOW_SPIN_LIMIT) {
+            if (lane == 0) {
+              __hip_atomic_store(fl + FL_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (a.info) atomicCAS(a.info, 0, GPMI_ERR_INTERNAL);
             }
-          }
-          const unsigned long long tb = __ballot(taken);
-          const int lead = tb == ~0ull ? 64 : __ffsll((long long)~tb) - 1;  // claimed tasks at the head
-          if (lead > 0 && lane == 0) atomicMax(fl + FL_HEAD + 32 * q, h + lead);
-          unsigned long long rb = __ballot(rdy);
-          int skip = (int)(blockIdx.x & 3);
-          while (rb != 0ull) {
-            unsigned long long pick = rb;
-            for (int s = 0; s < skip && (pick & (pick - 1)) != 0ull; ++s) pick &= pick - 1;
-            const int sel = __ffsll((long long)pick) - 1;
-            int ok = 0;
-            if (lane == sel) ok = atomicCAS(cq + x, 0, 1) == 0;
-            ok = __shfl(ok, sel, 64);
-            if (ok) {
-              const int w0 = __shfl(*reinterpret_cast<const int*>(&mine), sel, 64);
-              const int w1 = __shfl(*(reinterpret_cast<const int*>(&mine) + 1), sel, 64);
-              const int w2 = __shfl(*(reinterpret_cast<const int*>(&mine) + 2), sel, 64);
-              if (lane == 0) {
-                sh[1] = w0;
-                sh[2] = w1;
-                sh[3] = w2;
-              }
-              got = 1;
-              break;
-            }
-            rb &= ~(1ull << sel);
-            skip = 0;
+            got = -1;
+            break;
           }
         }
-        if (got != 0) break;
-        if (!any_live) {  // every queue is exhausted
-          got = -1;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(16);
-        ++spins;
-        if ((spins & 63) == 0 && flow_ld(fl + FL_ABORT)) {
-          got = -1;
-          break;
-        }
-        if (spins > FLOW_SPIN_LIMIT) {
-          if (lane == 0) {
-            __hip_atomic_store(fl + FL_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.info) atomicCAS(a.info, 0, GPMI_ERR_INTERNAL);
-          }
-          got = -1;
-          break;
+        nscan += spins + 1;
+        if (a.stats) scan_ticks += __builtin_amdgcn_s_memrealtime() - t_scan;
+        if (a.trace && lane == 0) a.trace[4 * (int64_t)n + 1] = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+          sh[1] = *reinterpret_cast<const int*>(&mine);
+          sh[2] = *(reinterpret_cast<const int*>(&mine) + 1);
+          sh[3] = *(reinterpret_cast<const int*>(&mine) + 2);
         }
       }
       if (lane == 0) sh[0] = got;
@@ -210,6 +191,8 @@ __global__ __launch_bounds__(256, 2) void flow_task_kernel(FlowArgs a) {
     }
     int* flag;
     const int64_t ld = a.ld;
+    unsigned long long t_body = 0;
+    if (a.stats) t_body = __builtin_amdgcn_s_memrealtime();
     if (t.type == FT_T) {
       // rows [32 s, 32 s + 32) of tile (i, k) <- the same rows times invD(k)^T, in place
       double* C = a.A + ((int64_t)t.i * NB + 32 * t.s) * ld + (int64_t)t.k * NB;
@@ -232,13 +215,25 @@ __global__ __launch_bounds__(256, 2) void flow_task_kernel(FlowArgs a) {
     // publish: the tile was stored write-through (sc1); every wave's stores acknowledged, workgroup barrier, flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (a.trace && tid == 0) a.trace[4 * (int64_t)n + 2] = __builtin_amdgcn_s_memrealtime();
     if (tid == 0) {
       if (PROTO == 1 || PROTO == 3) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      __hip_atomic_fetch_add(flag, (int)t.fadd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (n != a.fault) __hip_atomic_fetch_add(flag, (int)t.fadd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.trace) a.trace[4 * (int64_t)n + 3] = __builtin_amdgcn_s_memrealtime();
     }
+    if (a.stats) {
+      body_ticks += __builtin_amdgcn_s_memrealtime() - t_body;
+      ++ntask;
+    }
+  }
+  if (a.stats && tid == 0) {
+    atomicAdd(a.stats + 0, scan_ticks);
+    atomicAdd(a.stats + 1, body_ticks);
+    atomicAdd(a.stats + 2, (unsigned long long)nscan);
+    atomicAdd(a.stats + 3, (unsigned long long)ntask);
   }
   if (a.stamp && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -250,30 +245,29 @@ __global__ __launch_bounds__(256, 2) void flow_task_kernel(FlowArgs a) {
 // outer panels before `lazy` are applied as K = 512 chunks, the columns [4 lazy, j) one at a time; lazy = P - 1 for
 // the tiles within NEAR rows below their own panel's diagonal block (the K = 512 chunk of the panel just finished
 // would sit on the chain: potrf_diag(4P) waits for it), lazy = P elsewhere.
-constexpr int FLOW_NEAR = 4;
+const int FLOW_NEAR = env_int("GPMI_FLOW_NEAR", 4);
 inline int flow_lazy_panels(int i, int j) {
   const int P = j / OBT;
   const int e = (i < OBT * P + OBT + FLOW_NEAR) ? P - 1 : P;
   return e > 0 ? e : 0;
 }
 
-struct FlowQueues {
-  std::vector<FlowTask> q[FLOW_NQ];
+struct FlowLists {
+  std::vector<FlowTask> tasks;
+  std::vector<int> off;
   double flops_update = 0.0, flops_trsm = 0.0;
 };
 
-FlowQueues flow_build(int m) {
-  FlowQueues out;
-  // virtual time: T(i, k) at k, U(i, j, k) at k + 1/2, Z(i, j, q) at 4 q + 3 + 1/4; queues sorted by it, then by row
-  typedef std::tuple<int, int, int, int, int> Key;  // (4 x virtual time, i, j, s, index)
-  std::vector<std::pair<Key, FlowTask>> h[FLOW_NQ];
+FlowLists flow_build(int m, int nwg) {
+  FlowLists out;
+  typedef std::tuple<int, int, int, int> Key;  // (4 x virtual time, i, j, s)
+  std::vector<std::pair<Key, FlowTask>> near, rest;
   for (int k = 0; k < m; ++k)
     for (int i = k + 2; i < m; ++i) {
-      const int d = i - k;
-      const int cls = d <= 3 ? 0 : (d <= 8 ? 1 : 2);
+      auto& dst = (i - k <= FLOW_NEAR_D) ? near : rest;
       for (int s = 0; s < 4; ++s) {
         FlowTask t{(uint8_t)FT_T, (uint8_t)s, 1, 0, (uint16_t)i, 0, (uint16_t)k, 0};
-        h[cls].push_back({Key(4 * k, i, 0, s, 0), t});
+        dst.push_back({Key(4 * k, i, 0, s), t});
       }
       out.flops_trsm += (double)NB * NB * NB;
       for (int j = k + 1; j <= i; ++j) {
@@ -284,24 +278,44 @@ FlowQueues flow_build(int m) {
           if (i == j && s == 1) continue;
           FlowTask t{(uint8_t)FT_U, (uint8_t)s, (uint8_t)((i == j && s == 0) ? 2 : 1), 0, (uint16_t)i, (uint16_t)j,
                      (uint16_t)k, 0};
-          h[cls].push_back({Key(4 * k + 2, i, j, s, 0), t});
+          dst.push_back({Key(4 * k + 2, i, j, s), t});
         }
         out.flops_update += (i == j ? 0.75 : 1.0) * 2.0 * NB * NB * NB;
       }
     }
-  for (int i = 0; i < m; ++i)
-    for (int j = 0; j <= i; ++j)
-      for (int q = 0; q < flow_lazy_panels(i, j); ++q) {
-        FlowTask t{(uint8_t)FT_Z, 0, (uint8_t)(4 * OBT), 0, (uint16_t)i, (uint16_t)j, (uint16_t)q, 0};
-        h[FLOW_NQ - 1].push_back({Key(4 * (OBT * q + OBT - 1) + 1, i, j, 0, 0), t});
-        out.flops_update += 2.0 * NB * NB * NB * OBT;
-      }
-  for (int c = 0; c < FLOW_NQ; ++c) {
-    std::sort(h[c].begin(), h[c].end(), [](const std::pair<Key, FlowTask>& x, const std::pair<Key, FlowTask>& y) {
-      return x.first < y.first;
-    });
-    out.q[c].reserve(h[c].size());
-    for (auto& e : h[c]) out.q[c].push_back(e.second);
+  auto by_key = [](const std::pair<Key, FlowTask>& x, const std::pair<Key, FlowTask>& y) { return x.first < y.first; };
+  std::sort(near.begin(), near.end(), by_key);
+  std::sort(rest.begin(), rest.end(), by_key);
+  const int nn = (nwg > 2 * FLOW_NEAR_WGS) ? FLOW_NEAR_WGS : 0;  // a small launch: one deal for everything
+  std::vector<std::vector<std::pair<Key, FlowTask>>> lists((size_t)nwg);
+  if (nn == 0) {
+    rest.insert(rest.end(), near.begin(), near.end());
+    std::sort(rest.begin(), rest.end(), by_key);
+    near.clear();
+  }
+  for (size_t n = 0; n < near.size(); ++n) lists[n % (size_t)nn].push_back(near[n]);
+  for (size_t n = 0; n < rest.size(); ++n) lists[(size_t)nn + n % (size_t)(nwg - nn)].push_back(rest[n]);
+  // The K = 512 tiles: chunk after chunk, rows from the top (the rows the chain reaches first), dealt round-robin like
+  // the rest.  (Dealt for L2 locality instead - column strips of 8, blocks of 64 consecutive tiles to the workgroups
+  // of one XCD, as the launch-per-product kernels order their tiles - the tiles were no faster, 117 us with two on a CU
+  // either way, and the chain waited 0.8 ms longer for the rows near the diagonal: 7.0 against 6.1 ms at N = 8192.)
+  {
+    std::vector<std::pair<Key, FlowTask>> zt;
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j <= i; ++j)
+        for (int q = 0; q < flow_lazy_panels(i, j); ++q) {
+          FlowTask t{(uint8_t)FT_Z, 0, (uint8_t)(4 * OBT), 0, (uint16_t)i, (uint16_t)j, (uint16_t)q, 0};
+          zt.push_back({Key(4 * (OBT * q + OBT - 1) + 1, i, j, 0), t});
+          out.flops_update += 2.0 * NB * NB * NB * OBT;
+        }
+    std::sort(zt.begin(), zt.end(), by_key);
+    for (size_t n = 0; n < zt.size(); ++n) lists[(size_t)nn + (n + rest.size()) % (size_t)(nwg - nn)].push_back(zt[n]);
+  }
+  for (auto& l : lists) std::stable_sort(l.begin(), l.end(), by_key);
+  out.off.push_back(0);
+  for (auto& l : lists) {
+    for (auto& e : l) out.tasks.push_back(e.second);
+    out.off.push_back((int)out.tasks.size());
   }
   return out;
 }
@@ -309,6 +323,40 @@ FlowQueues flow_build(int m) {
 }  // namespace
 
 bool ensure_masked_pair(gpmi_ctx* c, Lane& L, int k);  // api.hip
+
+// One flag-ordered factorisation per device at a time, process-wide: a workgroup of the task kernel may wait for a task
+// that belongs to a workgroup of the same launch which is not resident yet; with the CUs to itself every workgroup
+// becomes resident, but two such launches on the same CUs (two contexts, two threads) could each hold the slots the
+// other one's missing workgroups need.  A second factorisation that arrives while the event of the previous one has not
+// completed takes the stream-ordered schedule instead.
+namespace {
+std::mutex g_flow_mu;
+hipEvent_t g_flow_ev[64] = {nullptr};
+bool g_flow_busy[64] = {false};
+
+bool flow_gate_try(int device) {
+  if (device < 0 || device >= 64) return false;
+  std::lock_guard<std::mutex> lk(g_flow_mu);
+  if (g_flow_busy[device]) {
+    if (hipEventQuery(g_flow_ev[device]) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    g_flow_busy[device] = false;
+  }
+  if (!g_flow_ev[device] && hipEventCreateWithFlags(&g_flow_ev[device], hipEventDisableTiming) != hipSuccess) {
+    g_flow_ev[device] = nullptr;
+    (void)hipGetLastError();
+    return false;
+  }
+  g_flow_busy[device] = true;  // until flow_gate_leave's event has completed
+  return true;
+}
+void flow_gate_leave(int device, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_flow_mu);
+  (void)hipEventRecord(g_flow_ev[device], s);
+}
+}  // namespace
 
 // GPMI_FLOW=0 keeps the stream-ordered schedule everywhere; GPMI_FLOW_MIN=<tile rows> (default 8) is the smallest
 // tail worth a task kernel
@@ -326,10 +374,13 @@ bool potrf_flow_enabled(gpmi_ctx* c, Lane& lane, int m) {
 
 void potrf_flow_free(Lane& lane) {
   if (lane.flow_tasks) (void)hipFree(lane.flow_tasks);
+  if (lane.flow_off) (void)hipFree(lane.flow_off);
   if (lane.flow_flags) (void)hipFree(lane.flow_flags);
   lane.flow_tasks = nullptr;
+  lane.flow_off = nullptr;
   lane.flow_flags = nullptr;
   lane.flow_m = 0;
+  lane.flow_nwg = 0;
 }
 
 // Factor the trailing tile rows [t0, nt) of A (every update by the columns before t0 applied) in place.  The caller
@@ -338,36 +389,37 @@ void potrf_flow_free(Lane& lane) {
 bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* invD, int* info, int nt, int t0) {
   const int m = nt - t0;
   hipStream_t sf = lane.stream, sp = lane.sp[0], su = lane.su[0];
-  if (lane.flow_m != m) {
+  const int ncu_u = c->ncu - c->pair_cus[0];
+  static const int wgs_per_cu = [] {
+    const char* e = std::getenv("GPMI_FLOW_WGS");
+    const int v = e ? std::atoi(e) : 2;
+    return (v == 1 || v == 2) ? v : 2;
+  }();
+  const int nwg = wgs_per_cu * ncu_u;
+  if (!flow_gate_try(c->device)) return false;
+  if (lane.flow_m != m || lane.flow_nwg != nwg) {
     potrf_flow_free(lane);
-    const FlowQueues fq = flow_build(m);
-    size_t total = 0;
-    for (int q = 0; q < FLOW_NQ; ++q) total += fq.q[q].size();
+    const FlowLists fl = flow_build(m, nwg);
+    const size_t total = fl.tasks.size();
     if (hipMalloc(&lane.flow_tasks, sizeof(FlowTask) * (total ? total : 1)) != hipSuccess ||
-        hipMalloc(&lane.flow_flags, sizeof(int) * flow_flag_ints(m, (int64_t)total)) != hipSuccess) {
+        hipMalloc(&lane.flow_off, sizeof(int) * fl.off.size()) != hipSuccess ||
+        hipMalloc(&lane.flow_flags, sizeof(int) * flow_flag_ints(m)) != hipSuccess ||
+        (total && hipMemcpy(lane.flow_tasks, fl.tasks.data(), sizeof(FlowTask) * total, hipMemcpyHostToDevice) !=
+                      hipSuccess) ||
+        hipMemcpy(lane.flow_off, fl.off.data(), sizeof(int) * fl.off.size(), hipMemcpyHostToDevice) != hipSuccess) {
       (void)hipGetLastError();
       potrf_flow_free(lane);
+      flow_gate_leave(c->device, sf);
       return false;
     }
-    size_t off = 0;
-    for (int q = 0; q < FLOW_NQ; ++q) {
-      lane.flow_off[q] = (int64_t)off;
-      lane.flow_count[q] = (int)fq.q[q].size();
-      if (!fq.q[q].empty() &&
-          hipMemcpy(static_cast<FlowTask*>(lane.flow_tasks) + off, fq.q[q].data(), sizeof(FlowTask) * fq.q[q].size(),
-                    hipMemcpyHostToDevice) != hipSuccess) {
-        potrf_flow_free(lane);
-        return false;
-      }
-      off += fq.q[q].size();
-    }
-    lane.flow_flops_update = fq.flops_update;
-    lane.flow_flops_trsm = fq.flops_trsm;
+    lane.flow_flops_update = fl.flops_update;
+    lane.flow_flops_trsm = fl.flops_trsm;
     lane.flow_ntasks = (int64_t)total;
     lane.flow_m = m;
+    lane.flow_nwg = nwg;
   }
   int* fl = lane.flow_flags;
-  (void)hipMemsetAsync(fl, 0, sizeof(int) * flow_flag_ints(m, lane.flow_ntasks), sf);
+  (void)hipMemsetAsync(fl, 0, sizeof(int) * flow_flag_ints(m), sf);
   (void)hipEventRecord(lane.ev_join, sf);
   (void)hipStreamWaitEvent(sp, lane.ev_join, 0);
   (void)hipStreamWaitEvent(su, lane.ev_join, 0);
@@ -379,27 +431,39 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
   fa.invD = invD0;
   fa.ld = ld;
   fa.m = m;
-  for (int q = 0; q < FLOW_NQ; ++q) {
-    fa.tasks[q] = static_cast<const FlowTask*>(lane.flow_tasks) + lane.flow_off[q];
-    fa.claim[q] = fl + flow_claim_off(m) + lane.flow_off[q];
-    fa.count[q] = lane.flow_count[q];
-  }
+  fa.tasks = static_cast<const FlowTask*>(lane.flow_tasks);
+  fa.off = lane.flow_off;
   fa.flags = fl;
   fa.info = info;
   // one stamped "launch" for the bench's accounting of the trailing updates (class SYRK_REST: not the dominant kernel's
   // name in rocprof's tables): FLOPs of every U and Z task
   fa.stamp = prof_stamp_slot(c, lane.flow_flops_update, 0.0, GPMI_PROF_SYRK_REST);
-  const int ncu_u = c->ncu - c->pair_cus[0];
-  static const int wgs_per_cu = [] {
-    const char* e = std::getenv("GPMI_FLOW_WGS");
-    const int v = e ? std::atoi(e) : 2;
-    return v > 0 ? v : 2;
-  }();
+  // GPMI_FLOW_TRACE=<file>: time stamps of every task and chain launch, written after a (synchronous) factorisation:
+  // tools/flow_trace.py reads them
+  static const char* trace_path = std::getenv("GPMI_FLOW_TRACE");
+  const int64_t ntasks = lane.flow_ntasks;
+  const int64_t trace_words = 4 * ntasks + (int64_t)m * (GPMI_STAMP_WORDS + 4);
+  unsigned long long* trace = nullptr;
+  if (trace_path && hipMalloc(&trace, sizeof(unsigned long long) * trace_words) == hipSuccess)
+    (void)hipMemsetAsync(trace, 0, sizeof(unsigned long long) * trace_words, sf);
+  fa.trace = trace;
+  unsigned long long* ctrace = trace ? trace + 4 * ntasks : nullptr;  // per column: potrf_diag's 24 words, Tc 2, Uc 2
+  static const bool want_stats = std::getenv("GPMI_FLOW_STATS") != nullptr;
+  unsigned long long* stats = want_stats ? reinterpret_cast<unsigned long long*>(fl + FL_STATS) : nullptr;
+  fa.stats = stats;
+  // GPMI_FLOW_FAULT=<n>: the suite's own check that a lost flag ends in GPMI_ERR_INTERNAL, not in a hung GPU
+  static const int fault = env_int("GPMI_FLOW_FAULT", -1);
+  fa.fault = fault;
+  if (trace) {  // the chain and the task kernel start behind the trace buffer's memset too
+    (void)hipEventRecord(lane.ev_join, sf);
+    (void)hipStreamWaitEvent(sp, lane.ev_join, 0);
+    (void)hipStreamWaitEvent(su, lane.ev_join, 0);
+  }
   static const int proto = [] {
     const char* e = std::getenv("GPMI_FLOW_PROTO");
     return e ? std::atoi(e) : 0;
   }();
-  const dim3 grid((unsigned)(wgs_per_cu * ncu_u));
+  const dim3 grid((unsigned)nwg);
   if (proto == 1) hipLaunchKernelGGL(flow_task_kernel<1>, grid, dim3(256), 0, su, fa);
   else if (proto == 2) hipLaunchKernelGGL(flow_task_kernel<2>, grid, dim3(256), 0, su, fa);
   else if (proto == 3) hipLaunchKernelGGL(flow_task_kernel<3>, grid, dim3(256), 0, su, fa);
@@ -413,7 +477,8 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
     for (int k = 0; k < m; ++k) {
       double* Akk = A0 + (int64_t)k * NB * ld + (int64_t)k * NB;
       double* invDk = invD0 + (int64_t)k * NB * NB;
-      launch_potrf_diag(sp, Akk, ld, invDk, info, (t0 + k) * NB);
+      unsigned long long* ck = ctrace ? ctrace + (int64_t)k * (GPMI_STAMP_WORDS + 4) : nullptr;
+      launch_potrf_diag(sp, Akk, ld, invDk, info, (t0 + k) * NB, ck);
       if (k + 1 < m) {
         double* A21 = Akk + (int64_t)NB * ld;
         GemmBatch tc;
@@ -424,6 +489,8 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
         tc.hook.wait_val = 4 * k;
         tc.hook.abort = fl + FL_ABORT;
         tc.hook.info = info;
+        tc.hook.wait_ticks = stats ? stats + 4 : nullptr;
+        tc.hook.trace = ck ? ck + GPMI_STAMP_WORDS : nullptr;
         launch_gemm_nt(sp, TILES_RECT, OP_ASSIGN, A21, ld, A21, ld, invDk, NB, 1, 1, NB, nullptr, tc);
         GemmBatch uc;
         uc.hook.pub = Lcnt + k + 1;
@@ -432,6 +499,8 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
         uc.hook.wait_val = 4 * k;
         uc.hook.abort = fl + FL_ABORT;
         uc.hook.info = info;
+        uc.hook.wait_ticks = stats ? stats + 5 : nullptr;
+        uc.hook.trace = ck ? ck + GPMI_STAMP_WORDS + 2 : nullptr;
         launch_gemm_nt(sp, TILES_LOWER, OP_SUB, A21 + NB, ld, A21, ld, A21, ld, 1, 1, NB, nullptr, uc);
       }
     }
@@ -440,5 +509,33 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
   (void)hipEventRecord(lane.ev_main, su);
   (void)hipStreamWaitEvent(sf, lane.ev_panel, 0);
   (void)hipStreamWaitEvent(sf, lane.ev_main, 0);
+  flow_gate_leave(c->device, sf);
+  if (trace) {  // diagnostics only: synchronous
+    (void)hipStreamSynchronize(sf);
+    std::vector<unsigned long long> h((size_t)trace_words);
+    std::vector<FlowTask> ht((size_t)ntasks);
+    std::vector<int> ho((size_t)nwg + 1);
+    (void)hipMemcpy(h.data(), trace, sizeof(unsigned long long) * trace_words, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(ht.data(), lane.flow_tasks, sizeof(FlowTask) * ntasks, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(ho.data(), lane.flow_off, sizeof(int) * (nwg + 1), hipMemcpyDeviceToHost);
+    (void)hipFree(trace);
+    if (FILE* fp = std::fopen(trace_path, "wb")) {
+      const int64_t hdr[4] = {m, nwg, ntasks, GPMI_STAMP_WORDS + 4};
+      std::fwrite(hdr, sizeof(hdr), 1, fp);
+      std::fwrite(ho.data(), sizeof(int), ho.size(), fp);
+      std::fwrite(ht.data(), sizeof(FlowTask), ht.size(), fp);
+      std::fwrite(h.data(), sizeof(unsigned long long), h.size(), fp);
+      std::fclose(fp);
+    }
+  }
+  if (stats) {  // diagnostics only: synchronous
+    unsigned long long h[8] = {0};
+    (void)hipStreamSynchronize(sf);
+    (void)hipMemcpy(h, stats, sizeof(h), hipMemcpyDeviceToHost);
+    std::fprintf(stderr,
+                 "[flow] m=%d tasks=%llu polls=%llu | per workgroup: waiting %.1f us, in tasks %.1f us | chain waited: "
+                 "Tc %.1f us, Uc %.1f us\n",
+                 m, h[3], h[2], h[0] * 0.01 / grid.x, h[1] * 0.01 / grid.x, h[4] * 0.01 / 4.0, h[5] * 0.01 / 3.0);
+  }
   return true;
 }

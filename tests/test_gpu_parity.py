@@ -1132,6 +1132,8 @@ def test_schedule_variants_agree(tmp_path):
         {"GPMI_LOOKAHEAD_MIN": "0"},
         {"GPMI_LOOKAHEAD_MIN": "24", "GPMI_KBUILD_NO_SPLIT": "1"},
         {"GPMI_M32_MAX": "0", "GPMI_SPLIT_PCT": "0", "GPMI_BIG_MIN": "64"},
+        {"GPMI_FLOW": "0"},  # the last 60 tile rows in stream order instead of as flag-ordered tile tasks
+        {"GPMI_LOOKAHEAD_MIN": "84", "GPMI_FLOW_NEAR_WGS": "64", "GPMI_FLOW_NEAR": "0", "GPMI_FLOW_NEAR_D": "5"},
     ]
     base = None
     for k, extra in enumerate(variants):
@@ -1147,6 +1149,52 @@ def test_schedule_variants_agree(tmp_path):
             continue
         for q in ("alpha", "logdet", "mu", "sig"):
             check(r[q + "0"], base[q + "0"], 1e-11, f"{q} under {extra}")
+            if "GPMI_FLOW" in extra or "GPMI_FLOW_NEAR" in extra:  # same bodies, same summation order: same bits
+                assert np.array_equal(r[q + "0"], base[q + "0"]), (extra, q)
+
+
+@pytest.mark.parametrize("n", [5200, 6500, 8192])
+def test_flow_tail_is_bit_identical_to_stream_order(tmp_path, n):
+    """The flag-ordered tile-task factorisation of the chain-bound part (csrc/potrf_flow.hip: persistent task kernel
+    beside the bare panel chain; the whole matrix at these sizes) against the stream-ordered schedule (GPMI_FLOW=0):
+    same tile bodies, same order of summation for every element, hence the SAME BITS in alpha, log det, mean and sigma -
+    also with another deal of the tasks and with every matrix byte loaded at agent scope (GPMI_FLOW_PROTO=2).  A tile
+    used before its inputs were final, or a stale cache line, is an O(1) difference here."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "fit_digest.py")
+    res = []
+    for k, extra in enumerate(({"GPMI_FLOW": "0"}, {}, {"GPMI_FLOW_NEAR_WGS": "16", "GPMI_FLOW_PROTO": "2", "GPMI_FLOW_WGS": "1"})):
+        out = str(tmp_path / f"f{k}.npz")
+        run = subprocess.run([sys.executable, tool, out, str(n)], env=dict(os.environ, **extra), capture_output=True,
+                             text=True, timeout=300)
+        assert run.returncode == 0, (extra, run.stderr[-2000:])
+        res.append(dict(np.load(out)))
+    for r in res[1:]:
+        for q in res[0]:
+            assert np.array_equal(r[q], res[0][q]), (n, q)
+
+
+def test_flow_lost_flag_is_an_error_not_a_hang(tmp_path):
+    """A task that never sets its flag (test hook GPMI_FLOW_FAULT) must end in GpmiError (GPMI_ERR_INTERNAL) within
+    seconds - every poll of the task kernel and of the chain launches is bounded - and leave the GPU usable."""
+    import os
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "fit_digest.py")
+    t0 = time.time()
+    run = subprocess.run([sys.executable, tool, str(tmp_path / "x.npz"), "8192"], env=dict(os.environ, GPMI_FLOW_FAULT="7000"),
+                         capture_output=True, text=True, timeout=120)
+    assert run.returncode != 0 and "timed out" in run.stderr, run.stderr[-2000:]
+    assert time.time() - t0 < 90
+    run = subprocess.run([sys.executable, tool, str(tmp_path / "y.npz"), "8192"], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr[-2000:]
 
 
 # ---------------------------------------------------------------------------------------

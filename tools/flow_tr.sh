@@ -1,0 +1,5 @@
+#!/bin/bash
+out=${1:-gpurun_out/flowt}; mkdir -p $out
+cd "$(dirname "$0")/.."
+GPMI_FLOW_TRACE=$out/trace.bin GPMI_FLOW_STATS=1 timeout 300 python tools/fit_digest.py $out/t.npz ${N:-8192} 2>&1 | tail -3
+python tools/flow_trace.py $out/trace.bin 20 3
