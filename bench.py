@@ -123,7 +123,7 @@ def pmc_traffic():
     command (profiles/rNN_pmc.json, written by tools/pmc_bench.sh + tools/make_profiles.py: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
     coalesced reads on gfx950); (None, None) if absent."""
-    for name in ("r02_pmc.json", "r01_pmc.json"):
+    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)["kernels"]["update128"]["hbm_bytes_per_launch"], "profiles/" + name
@@ -168,6 +168,69 @@ def kernel_rows(eng, step, _lib, N, M):
     return rows
 
 
+def sharded_configs(args, wl, sharding, rank, world, local_rank, rdv, gather, eng_comm, _lib):
+    """BASELINE configs 3 and 5 through the sharded drivers, AFTER the timed headline region (not part of `value`):
+    config 3 = the 64-point RationalQuadratic hyper-parameter grid at N = 16384, d = 16 through
+    `marginal_likelihood_sweep` (8 per GPU on 8 GPUs; reference: a Python loop over regression.py:528-542);
+    config 5 = 64 ParallelTempering ladders x 8 temperatures over the GP log-marginal likelihood (N = 2048, d = 4)
+    through `tempering_run`, whole ladders per rank (mcmc/parallel.py:127-136,190-231).  Both gather over the same
+    path as the headline's result gather (`gather`).  Wall time = max over ranks (barrier before and after)."""
+    from inference_amd.gp import GpRegressor, RationalQuadratic
+
+    sharding.use_rendezvous(rdv)
+    dev = local_rank % max(_lib.device_count(), 1)
+
+    def timed(fn):
+        if rdv is not None:
+            rdv.barrier()
+        t0 = time.perf_counter()
+        out = fn()
+        dt = time.perf_counter() - t0
+        if rdv is not None:
+            dt = max(float(v) for v in rdv.allgather_obj(dt))
+        return dt, out
+
+    res = {"gather": gather, "note": "measured after the timed headline region; one process per GPU, contiguous blocks of "
+           "units per rank, ONE all-gather of the results at the end"}
+    grid_n = int(os.environ.get("BENCH_CFG3_POINTS", "64"))
+    if grid_n > 0:
+        n3, d3 = 16384, 16
+        x, y, e = wl.synthetic_dataset(3, n3, d3)
+        grid = wl.theta_grid_cfg3(y, d3)[:grid_n]
+        gp3 = GpRegressor(x, y, y_err=e, hyperpars=grid[0], kernel=RationalQuadratic, device=dev)
+        gp3.engine.set_streams(2)
+        sharding.marginal_likelihood_sweep(gp3, grid[: 2 * world], engine=eng_comm)  # warm-up: lanes, workspaces
+        dt, vals = timed(lambda: sharding.marginal_likelihood_sweep(gp3, grid, engine=eng_comm))
+        fl = len(grid) * n3**3 / 3.0
+        res["config3"] = {
+            "workload": f"RationalQuadratic N={n3} d={d3}: {len(grid)}-point hyper-parameter grid, marginal_likelihood_sweep",
+            "seconds": dt, "lml_evals_per_s": len(grid) / dt, "tflops_aggregate": fl / dt / 1e12,
+            "frac_of_aggregate_fp64_mfma_peak": fl / dt / 1e12 / (world * PEAK_FP64_MFMA_TFLOPS),
+            "checksum": float(np.sum(vals)),
+        }
+        gp3.engine.close()
+    n_lad = int(os.environ.get("BENCH_CFG5_LADDERS", "64"))
+    if n_lad > 0:
+        n5, d5, steps5 = 2048, 4, int(os.environ.get("BENCH_CFG5_STEPS", "10"))
+        x, y, e = wl.synthetic_dataset(5, n5, d5)
+        gp5 = GpRegressor(x, y, y_err=e, hyperpars=wl.timing_theta(wl.SE, y, d5), device=dev)
+        gp5.batch_independent_values(True)
+        sharding.tempering_run(lambda k: wl.cfg5_ladder(gp5, k), world, 2, swap_interval=2, engine=eng_comm)  # warm-up
+        dt, (state, evals) = timed(lambda: sharding.tempering_run(lambda k: wl.cfg5_ladder(gp5, k), n_lad, steps5,
+                                                                  swap_interval=10, engine=eng_comm))
+        chains = state.shape[0] * state.shape[1]
+        res["config5"] = {
+            "workload": f"{n_lad} ParallelTempering ladders x {state.shape[1]} temperatures, GibbsChain over the GP log-marginal "
+                        f"likelihood (SE N={n5} d={d5}), {steps5} steps, swap interval 10, tempering_run",
+            "seconds": dt, "chain_steps_per_s": chains * steps5 / dt, "lml_evals_per_s": evals / dt,
+            "tflops_aggregate": evals / dt * (n5**3 / 3.0) / 1e12,
+            "frac_of_aggregate_fp64_mfma_peak": evals / dt * (n5**3 / 3.0) / 1e12 / (world * PEAK_FP64_MFMA_TFLOPS),
+            "checksum": float(np.sum(state[:, :, -1])),
+        }
+        gp5.engine.close()
+    return res
+
+
 def launch_ranks(n_ranks):
     """`python bench.py --gpus N` without a launcher: start N rank processes of this same script and relay rank
     0's JSON line.  The parent never touches the GPU (nothing GPU-related is imported before this point), the
@@ -206,6 +269,7 @@ def main():
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--m", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sharded", action="store_true", help="skip the config 3 / config 5 runs behind the timed region")
     args = ap.parse_args()
 
     if "RANK" not in os.environ and args.gpus > 1:
@@ -222,7 +286,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    rdv = sharding.FileRendezvous(rank, world) if world > 1 else None
+    # the rendezvous must outlive the RCCL bootstrap watchdog below: a rank whose bootstrap returned at once waits in
+    # allgather_obj for the ranks still inside th.join
+    rccl_timeout = float(os.environ.get("GPMI_BENCH_RCCL_TIMEOUT", "120"))
+    rdv = sharding.FileRendezvous(rank, world, timeout=rccl_timeout + 90.0) if world > 1 else None
     try:
         run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, local_rank, rdv)
     finally:
@@ -270,7 +337,7 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
 
         th = threading.Thread(target=bootstrap, daemon=True)
         th.start()
-        th.join(float(os.environ.get("GPMI_BENCH_RCCL_TIMEOUT", "120")))
+        th.join(float(os.environ.get("GPMI_BENCH_RCCL_TIMEOUT", "120")))  # < the rendezvous' own time limit (main)
         if th.is_alive():
             STUCK.append(True)
             ok, why = False, "RCCL bootstrap did not return within the time limit"
@@ -320,6 +387,7 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
     prof = eng.profile_read(_lib.PROF_SYRK)
     prof_rest = eng.profile_read(_lib.PROF_SYRK_REST)
     prof_slice = eng.profile_read(_lib.PROF_SYRK_SLICE)
+    prof_flow = eng.profile_read(_lib.PROF_FLOW)
     clock = eng.profile_clock()
     eng.profile_enable(0)
 
@@ -328,6 +396,14 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
 
     flops_step = N**3 / 3.0 + M * float(N) ** 2
     value = flops_step * args.steps * world / dt / 1e9
+
+    sharded = None
+    if not args.no_sharded:
+        try:
+            sharded = sharded_configs(args, wl, sharding, rank, world, local_rank, rdv, gather,
+                                      eng if gather == "rccl" else None, _lib)
+        except Exception as err:  # the headline line must not be lost to a failure behind the timed region
+            sharded = {"error": f"{type(err).__name__}: {err}"}
 
     if rank == 0:
         ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
@@ -391,6 +467,13 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                     "ms_per_step": all_ms / max(args.steps, 1),
                     "flop_per_step": all_fl / max(args.steps, 1),
                 },
+                "flow_tail": {
+                    "what": "the chain-bound last tile rows of the factorisation (below 60 trailing tile rows) as ONE persistent tile-task launch on the update stream's 224 CUs beside the bare panel chain (csrc/potrf_flow.hip): FLOPs of its K = 128 / K = 512 update tasks over the launch's whole duration - the launch waits for the chain most of the time, so this is the overlap achieved, not a kernel rate; not part of all_trailing",
+                    "achieved": (prof_flow["flops"] / (prof_flow["ms"] * 1e-3) / 1e12) if prof_flow["ms"] > 0 else 0.0,
+                    "launches": prof_flow["launches"],
+                    "ms_per_step": prof_flow["ms"] / max(args.steps, 1),
+                    "flop_per_step": prof_flow["flops"] / max(args.steps, 1),
+                },
                 "slices": {
                     "what": "the last tiles of a trailing update, run by the same 128x128-tile kernel on the 32 CUs reserved for the panel chain once the chain is through (peak share 32 / 256)",
                     "achieved": ach_slice,
@@ -401,6 +484,8 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                 },
             },
         }
+        if sharded is not None:
+            line["sharded"] = sharded
         if world == 1:
             line["roofline"]["kernels"] = kernel_rows(eng, step, _lib, N, M)
         if world == 1 and not args.no_cpu_baseline:

@@ -311,7 +311,10 @@ int gpmi_timer_stop(gpmi_ctx* ctx, float* ms);
 #define GPMI_PROF_TRSM 5    /* many right-hand side solves: predict, posterior, L^-T (fp64 MFMA bound) */
 #define GPMI_PROF_SYRK_SLICE 6 /* the tiles of a trailing update that run, concurrently with the rest, on the 32 CUs
                                   reserved for the panel chain (same 128 x 128-tile kernel as SYRK) */
-#define GPMI_PROF_NCLASS 7
+#define GPMI_PROF_FLOW 7    /* the flag-ordered tile-task launch of the chain-bound part of a factorisation (potrf_flow.hip):
+                               FLOPs of its update tasks over the launch's whole duration - it waits for the panel
+                               chain most of the time, so this is the overlap achieved, not a kernel rate */
+#define GPMI_PROF_NCLASS 8
 /* on = 0: off; 1: every class; otherwise a class bitmask shifted left by one (2 << klass) */
 int gpmi_profile_enable(gpmi_ctx* ctx, int on);
 /* accumulated since the last reset: launches, total ms, algorithmic flops and bytes */

@@ -442,7 +442,7 @@ unsigned long long* prof_stamp_slot(gpmi_ctx* c, double flops, double bytes, int
 ProfScope::ProfScope(gpmi_ctx* ctx, hipStream_t st, int klass, double flops, double bytes)
     : c(ctx), s(st), slot(nullptr) {
   if (!((c->prof_mask >> klass) & 1) || klass == GPMI_PROF_SYRK || klass == GPMI_PROF_SYRK_REST ||
-      klass == GPMI_PROF_SYRK_SLICE)
+      klass == GPMI_PROF_SYRK_SLICE || klass == GPMI_PROF_FLOW)
     return;
   if (c->prof_used == c->prof_slots.size()) {
     ProfSlot ns{};

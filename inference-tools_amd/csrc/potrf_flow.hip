@@ -33,10 +33,10 @@
 // in-order queues with a claim word per task, every idle workgroup re-reading ~300 flags at every publication:
 // 60 ms for a 7 ms factorisation - the polling saturated the fabric; tools/sim/flow_sim.py prices the static deal
 // at 3.7 ms against 3.6 for ideal queues.)
-// Progress: every list is in virtual-time order, so the earliest unfinished task overall is the next one of its
-// owner and all its inputs are complete - PROVIDED every workgroup of the launch is resident (one that never starts
-// would hold its tasks back): the launch has two workgroups per CU of the update stream's CU mask, which is what
-// the kernel's 64 KiB of LDS and 256 VGPRs admit.
+// Progress: every list is in virtual-time order, so the earliest unfinished task overall is the head of its list and
+// all its inputs are complete: whoever holds that list finds it ready.  Every list has a holder that is resident: a
+// list whose own workgroup has not started (two workgroups per CU of the update stream's mask is what 64 KiB of LDS
+// and 256 VGPRs admit, but another process may hold those slots) is adopted after 50 us by a workgroup that is.
 // The only cross-launch dependency is between the chain stream and the task kernel, which run on disjoint CU masks.
 // Every poll is bounded: a time-out (a bug or a serialising profiler, never a wait) sets the abort word, every
 // poller gives up, and the host reports GPMI_ERR_INTERNAL through `info` instead of hanging the GPU.
@@ -74,9 +74,12 @@ struct FlowTask {
 static_assert(sizeof(FlowTask) == 12, "FlowTask layout");
 
 // hot words on lines of their own
-constexpr int FL_DDONE = 0, FL_ABORT = 32, FL_STATS = 64, FL_LCNT = 128;
+constexpr int FL_DDONE = 0, FL_ABORT = 32, FL_T0 = 48, FL_STATS = 64, FL_LCNT = 128;
 __host__ __device__ inline int flow_f_off(int m) { return FL_LCNT + ((m + 31) / 32) * 32; }
-inline int flow_flag_ints(int m) { return flow_f_off(m) + m * m; }
+__host__ __device__ inline int flow_owner_off(int m) { return flow_f_off(m) + ((m * m + 31) / 32) * 32; }  // one word per list
+inline int flow_flag_ints(int m, int nwg) { return flow_owner_off(m) + nwg; }
+constexpr int FLOW_MAX_LISTS = 512;                  // lists a workgroup can hold (its own + adopted ones)
+constexpr unsigned long long FLOW_GRACE_TICKS = 5000;  // 50 us: a list nobody has claimed by then is an orphan
 
 struct FlowArgs {
   double* A;           // tile (0, 0) of the tail
@@ -128,7 +131,7 @@ __device__ __attribute__((noinline)) void flow_do_U(const glb_double_t* Ai, cons
 template <int PROTO>
 __global__ __launch_bounds__(256, 2) void flow_task_kernel(FlowArgs a) {
   __shared__ double smem[DMA128_LDS_DOUBLES];
-  __shared__ int sh[4];
+  __shared__ int sh[8];
   static_assert(staged_lds_doubles<0, 32, 128>() <= DMA128_LDS_DOUBLES, "LDS of the TRSM slab body");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int* fl = a.flags;
@@ -137,43 +140,136 @@ __global__ __launch_bounds__(256, 2) void flow_task_kernel(FlowArgs a) {
   if (a.stamp && tid == 0 && blockIdx.x < 8) a.stamp[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
   unsigned long long scan_ticks = 0, body_ticks = 0;  // GPMI_FLOW_STATS (wave 0)
   int nscan = 0, ntask = 0;
-  const int n_end = a.off[blockIdx.x + 1];
-  for (int n = a.off[blockIdx.x];; ++n) {
-    if (wave == 0) {
-      int got = -1;
-      if (n < n_end) {
-        const FlowTask mine = a.tasks[n];
-        unsigned long long t_scan = 0;
-        if (a.stats || a.trace) t_scan = __builtin_amdgcn_s_memrealtime();
-        if (a.trace && lane == 0) a.trace[4 * (int64_t)n] = t_scan;
-        int spins = 0;
-        got = 1;
-        while (!flow_ready(mine, fl, a.m)) {
-          __builtin_amdgcn_s_sleep(8);
-          ++spins;
-          if ((spins & 63) == 0 && flow_ld(fl + FL_ABORT)) {
-            got = -1;
-            break;
-          }
-          if (spins > FLOW_SPIN_LIMIT) {
-            if (lane == 0) {
-              __hip_atomic_store(fl + FL_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (a.info) atomicCAS(a.info, 0, GPMI_ERR_INTERNAL);
-            }
-            got = -1;
-            break;
-          }
-        }
-        nscan += spins + 1;
-        if (a.stats) scan_ticks += __builtin_amdgcn_s_memrealtime() - t_scan;
-        if (a.trace && lane == 0) a.trace[4 * (int64_t)n + 1] = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) {
-          sh[1] = *reinterpret_cast<const int*>(&mine);
-          sh[2] = *(reinterpret_cast<const int*>(&mine) + 1);
-          sh[3] = *(reinterpret_cast<const int*>(&mine) + 2);
+  // Lists.  Workgroup b claims list b (CAS on the list's owner word) and normally runs just that.  A list nobody has
+  // claimed 50 us after the launch began is an orphan - its workgroup is not resident: another launch (a second process
+  // on this device) holds the slots - and is adopted by whichever workgroup finds it while it has nothing to do; a
+  // workgroup holding several lists runs whichever head task is ready.  So the launch needs ONE resident workgroup to
+  // finish, not all of them, and a workgroup that arrives after its list was adopted just leaves.
+  __shared__ int s_own[FLOW_MAX_LISTS], s_cur[FLOW_MAX_LISTS];
+  int* owner = fl + flow_owner_off(a.m);
+  const int nlists = (int)gridDim.x;
+  int nown = 0, last_slot = -1, n = 0;
+  if (wave == 0) {
+    if (lane == 0) {
+      unsigned long long* t0p = reinterpret_cast<unsigned long long*>(fl + FL_T0);
+      atomicCAS(t0p, 0ull, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+      if (atomicCAS(owner + blockIdx.x, 0, (int)blockIdx.x + 1) == 0) {
+        s_own[0] = (int)blockIdx.x;
+        s_cur[0] = a.off[blockIdx.x];
+        nown = 1;
+      }
+    }
+    nown = __shfl(nown, 0, 64);
+  }
+  auto try_adopt = [&]() {  // wave 0
+    const unsigned long long t0 = __hip_atomic_load(reinterpret_cast<unsigned long long*>(fl + FL_T0), __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+    if (__builtin_amdgcn_s_memrealtime() - t0 < FLOW_GRACE_TICKS || nown >= FLOW_MAX_LISTS) return false;
+    for (int r = 0; r < nlists; r += 64) {
+      const int idx = ((int)blockIdx.x + 1 + r + lane) % nlists;
+      const bool un = (r + lane < nlists) && flow_ld(owner + idx) == 0;
+      const unsigned long long ub = __ballot(un);
+      if (ub == 0ull) continue;
+      const int sel = __ffsll((long long)ub) - 1;
+      int ok = 0;
+      if (lane == sel) {
+        ok = atomicCAS(owner + idx, 0, (int)blockIdx.x + 1) == 0;
+        if (ok) {
+          s_own[nown] = idx;
+          s_cur[nown] = a.off[idx];
         }
       }
-      if (lane == 0) sh[0] = got;
+      ok = __shfl(ok, sel, 64);
+      if (ok) {
+        ++nown;
+        return true;
+      }
+    }
+    return false;
+  };
+  auto any_unowned = [&]() {  // wave 0
+    for (int r = 0; r < nlists; r += 64) {
+      const bool un = (r + lane < nlists) && flow_ld(owner + r + lane) == 0;
+      if (__ballot(un) != 0ull) return true;
+    }
+    return false;
+  };
+  for (;;) {
+    if (wave == 0) {
+      int got = 0;
+      if (last_slot >= 0 && lane == 0) s_cur[last_slot] += 1;
+      unsigned long long t_scan = 0;
+      if (a.stats || a.trace) t_scan = __builtin_amdgcn_s_memrealtime();
+      int spins = 0;
+      for (;;) {
+        // a ready head among the lists this workgroup holds (lane l looks at list slot l, 64 at a time)
+        bool all_done = true;
+        for (int base = 0; base < nown && got == 0; base += 64) {
+          const int slot = base + lane;
+          bool rdy = false;
+          FlowTask mine{};
+          int c = 0;
+          if (slot < nown) {
+            c = s_cur[slot];
+            if (c < a.off[s_own[slot] + 1]) {
+              all_done = false;
+              mine = a.tasks[c];
+              rdy = flow_ready(mine, fl, a.m);
+            }
+          }
+          const unsigned long long rb = __ballot(rdy);
+          if (rb != 0ull) {
+            const int sel = __ffsll((long long)rb) - 1;
+            const int w0 = __shfl(*reinterpret_cast<const int*>(&mine), sel, 64);
+            const int w1 = __shfl(*(reinterpret_cast<const int*>(&mine) + 1), sel, 64);
+            const int w2 = __shfl(*(reinterpret_cast<const int*>(&mine) + 2), sel, 64);
+            n = __shfl(c, sel, 64);
+            last_slot = base + sel;
+            if (lane == 0) {
+              sh[1] = w0;
+              sh[2] = w1;
+              sh[3] = w2;
+            }
+            got = 1;
+          }
+        }
+        if (got != 0) break;
+        if (__ballot(!all_done) == 0ull) {
+          // every list held is finished: adopt an orphan, or leave once every list has an owner
+          last_slot = -1;
+          if (try_adopt()) continue;
+          if (!any_unowned()) {
+            got = -1;
+            break;
+          }
+        } else if ((spins & 15) == 15) {
+          try_adopt();  // the task waited for may belong to an orphan list
+        }
+        __builtin_amdgcn_s_sleep(8);
+        ++spins;
+        if ((spins & 63) == 0 && flow_ld(fl + FL_ABORT)) {
+          got = -1;
+          break;
+        }
+        if (spins > FLOW_SPIN_LIMIT) {
+          if (lane == 0) {
+            __hip_atomic_store(fl + FL_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.info) atomicCAS(a.info, 0, GPMI_ERR_INTERNAL);
+          }
+          got = -1;
+          break;
+        }
+      }
+      nscan += spins + 1;
+      if (a.stats) scan_ticks += __builtin_amdgcn_s_memrealtime() - t_scan;
+      if (got > 0 && a.trace && lane == 0) {
+        a.trace[4 * (int64_t)n] = t_scan;
+        a.trace[4 * (int64_t)n + 1] = __builtin_amdgcn_s_memrealtime();
+      }
+      if (lane == 0) {
+        sh[0] = got;
+        sh[4] = n;
+      }
       if (got > 0) {
         // the inputs were written by other CUs: drop what this CU's L1 holds of them
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -182,6 +278,7 @@ __global__ __launch_bounds__(256, 2) void flow_task_kernel(FlowArgs a) {
     }
     __syncthreads();
     if (sh[0] < 0) break;
+    n = sh[4];
     FlowTask t;
     {
       int* w = reinterpret_cast<int*>(&t);
@@ -403,7 +500,7 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
     const size_t total = fl.tasks.size();
     if (hipMalloc(&lane.flow_tasks, sizeof(FlowTask) * (total ? total : 1)) != hipSuccess ||
         hipMalloc(&lane.flow_off, sizeof(int) * fl.off.size()) != hipSuccess ||
-        hipMalloc(&lane.flow_flags, sizeof(int) * flow_flag_ints(m)) != hipSuccess ||
+        hipMalloc(&lane.flow_flags, sizeof(int) * flow_flag_ints(m, nwg)) != hipSuccess ||
         (total && hipMemcpy(lane.flow_tasks, fl.tasks.data(), sizeof(FlowTask) * total, hipMemcpyHostToDevice) !=
                       hipSuccess) ||
         hipMemcpy(lane.flow_off, fl.off.data(), sizeof(int) * fl.off.size(), hipMemcpyHostToDevice) != hipSuccess) {
@@ -419,7 +516,7 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
     lane.flow_nwg = nwg;
   }
   int* fl = lane.flow_flags;
-  (void)hipMemsetAsync(fl, 0, sizeof(int) * flow_flag_ints(m), sf);
+  (void)hipMemsetAsync(fl, 0, sizeof(int) * flow_flag_ints(m, nwg), sf);
   (void)hipEventRecord(lane.ev_join, sf);
   (void)hipStreamWaitEvent(sp, lane.ev_join, 0);
   (void)hipStreamWaitEvent(su, lane.ev_join, 0);
@@ -435,9 +532,8 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
   fa.off = lane.flow_off;
   fa.flags = fl;
   fa.info = info;
-  // one stamped "launch" for the bench's accounting of the trailing updates (class SYRK_REST: not the dominant kernel's
-  // name in rocprof's tables): FLOPs of every U and Z task
-  fa.stamp = prof_stamp_slot(c, lane.flow_flops_update, 0.0, GPMI_PROF_SYRK_REST);
+  // one stamped "launch" of its own class for the bench: FLOPs of every U and Z task over the launch's whole duration
+  fa.stamp = prof_stamp_slot(c, lane.flow_flops_update, 0.0, GPMI_PROF_FLOW);
   // GPMI_FLOW_TRACE=<file>: time stamps of every task and chain launch, written after a (synchronous) factorisation:
   // tools/flow_trace.py reads them
   static const char* trace_path = std::getenv("GPMI_FLOW_TRACE");

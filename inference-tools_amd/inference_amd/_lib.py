@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("GPMI_LIB") or os.path.join(_HERE, "lib", "libgpmi.so"
 
 KERNEL_SE = 0
 KERNEL_RQ = 1
-PROF_KBUILD, PROF_SYRK, PROF_PANEL, PROF_SOLVE, PROF_SYRK_REST, PROF_TRSM, PROF_SYRK_SLICE = 0, 1, 2, 3, 4, 5, 6
+PROF_KBUILD, PROF_SYRK, PROF_PANEL, PROF_SOLVE, PROF_SYRK_REST, PROF_TRSM, PROF_SYRK_SLICE, PROF_FLOW = 0, 1, 2, 3, 4, 5, 6, 7
 OPT_LOCKSTEP_ALWAYS, OPT_RESERVE_POINTS = 1, 2
 
 

@@ -138,11 +138,12 @@ def _comm_engine(gp):
     return eng if eng is not None and getattr(eng, "comm_world", 0) > 1 else None
 
 
-def marginal_likelihood_sweep(gp, thetas):
+def marginal_likelihood_sweep(gp, thetas, engine=None):
     """Config 3: log-marginal likelihood of `gp` at every row of `thetas`, rows sharded over the
-    ranks (each rank drives its own GPU), results all-gathered."""
+    ranks (each rank drives its own GPU), results all-gathered - over the device communicator of
+    `engine` (default: the regressor's own engine) when it has one, else over the bootstrap channel."""
     return sharded_map(lambda th: gp.marginal_likelihood_batch(th), np.atleast_2d(np.asarray(thetas, dtype=float)),
-                       engine=_comm_engine(gp))[:, 0]
+                       engine=engine if engine is not None else _comm_engine(gp))[:, 0]
 
 
 def multistart_sweep(gp, starting_positions):
@@ -282,7 +283,10 @@ class FileRendezvous:
             t0 = time.time()
             while True:
                 if not os.path.exists(os.path.join(self.dir, f"hello.{self.rank}")):
-                    self._write(f"hello.{self.rank}", mine)
+                    try:
+                        self._write(f"hello.{self.rank}", mine)
+                    except OSError:  # rank 0's purge took the half-written file from under the rename: write it again
+                        continue
                 try:
                     with open(os.path.join(self.dir, "gen")) as f:
                         g = json.load(f)
@@ -295,8 +299,10 @@ class FileRendezvous:
                     raise TimeoutError("rank 0 did not open the rendezvous")
                 time.sleep(0.005)
 
-    def _purge(self):
+    def _purge(self, everything=False):
         for name in os.listdir(self.dir):
+            if name.endswith(".tmp") and not everything:  # being written right now (truncated on re-use, never read)
+                continue
             try:
                 os.remove(os.path.join(self.dir, name))
             except OSError:
@@ -360,7 +366,7 @@ class FileRendezvous:
         except (TimeoutError, OSError):
             pass  # a peer died: clean up what we can
         if self.rank == 0:
-            self._purge()
+            self._purge(everything=True)
             try:
                 os.rmdir(self.dir)
             except OSError:

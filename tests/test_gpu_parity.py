@@ -521,6 +521,37 @@ def test_rccl_gather_single_rank(gp_mod):
     assert vals.shape == (5, 1)
 
 
+def test_two_ranks_on_one_device(tmp_path):
+    """What the first multi-GPU run does first, on the hardware there is: two fresh processes on ONE device run
+    `marginal_likelihood_sweep`, `multistart_sweep` and `tempering_run` on device engines through a FileRendezvous
+    (tests/sharded_rank.py; RCCL refuses two ranks on one device, so the gather is the rendezvous-file path) and must
+    reproduce the single-process results bit for bit - blocks of uneven size included."""
+    import os
+    import secrets
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tests", "sharded_rank.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    single = str(tmp_path / "single.npz")
+    run = subprocess.run([sys.executable, tool, single], env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    key = f"test_{os.getpid()}_{secrets.token_hex(4)}"
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), WORLD_SIZE="2", GPMI_RDV_KEY=key, GPMI_RDV_DIR=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, tool, str(tmp_path / f"rank{r}.npz")], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    ref = dict(np.load(single))
+    for r in range(2):
+        got = dict(np.load(str(tmp_path / f"rank{r}.npz")))
+        for k in ref:
+            assert np.array_equal(got[k], ref[k]), (r, k)
+
+
 # ---------------------------------------------------------------------------------------
 # BASELINE.json's full sizes: the oracle needs minutes there, so the checks are identities
 # that hold at any size, with every right-hand side formed on the host from the oracle's kernels
@@ -573,6 +604,57 @@ def test_full_size_identities(gp_mod, cfg, n, d, kid):
     var_expected = D[idx] - D[idx] ** 2 * ik
     # var* is a difference of O(a^2) numbers: 1e-10 relative to a^2, the scale the kernels work at
     assert np.abs(sig**2 - var_expected).max() <= 1e-10 * a2
+
+
+def test_headline_size_against_the_oracle(golden, gp_mod):
+    """The configuration BASELINE.json's metric is quoted on (SE, N = 16384, d = 8) against values of the row-chunked
+    oracle (tests/golden/head16k.npz; the oracle itself is pinned to the imported reference up to N = 8192, K bit for
+    bit): alpha at 64 indices and its norm, diag(L), log det, LML at three hyper-parameter vectors, mean / sigma at 64
+    query points, the posterior at 16 (regression.py:218-244, 188-216, 421-449, 528-542)."""
+    g = golden("head16k")
+    n, d = 16384, 8
+    x, y, e = wl.synthetic_dataset(2, n, d)
+    th = g["thetas"]
+    assert np.array_equal(th[0], wl.timing_theta(wl.SE, y, d)) and np.array_equal(th, wl.theta_set(wl.SE, y, d, 3))
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=th[0])
+    ii = g["alpha_idx"]
+    check_each(gp.alpha[ii], g["alpha_sub"], what="alpha at 64 indices")
+    check(np.linalg.norm(gp.alpha), g["alpha_norm"], what="|alpha|")
+    check(gp._logdet, g["logdet"], what="log det")
+    mu, sig = gp(g["pts"])
+    check(mu, g["mu"], what="mean")
+    check(sig, g["sig"], what="sigma")
+    pm, pc = gp.build_posterior(g["pts"][:16])
+    check(pm, g["post_mu"], what="posterior mean")
+    check(pc, g["post_cov"], what="posterior covariance")
+    check(np.diagonal(gp.L)[ii], g["diagL_sub"], what="diag(L) at 64 indices")
+    check([gp.marginal_likelihood(t) for t in th], g["lml"], what="LML at 3 thetas")
+    check(gp.marginal_likelihood_batch(th), g["lml"], what="LML batch")
+
+
+def test_config3_share_of_the_grid_against_the_oracle(golden, gp_mod):
+    """BASELINE config 3 at full size (RQ, N = 16384, d = 16): the 8 grid points of one GPU's share of the 64-point
+    sweep through `marginal_likelihood_sweep` with 4 lanes, against the row-chunked oracle (tests/golden/cfg3_16k.npz);
+    fit + predict at the first of them (regression.py:528-542; covariance.py:343-348)."""
+    from inference_amd import sharding
+
+    g = golden("cfg3_16k")
+    n, d = 16384, 16
+    x, y, e = wl.synthetic_dataset(3, n, d)
+    grid = wl.theta_grid_cfg3(y, d)
+    sel = g["grid_idx"]
+    assert np.array_equal(grid[sel], g["thetas"])
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=grid[sel[0]], kernel=gp_mod.RationalQuadratic)
+    check_each(gp.alpha[g["alpha_idx"]], g["alpha_sub"], what="alpha at 64 indices")
+    check(np.linalg.norm(gp.alpha), g["alpha_norm"], what="|alpha|")
+    check(gp._logdet, g["logdet"], what="log det")
+    mu, sig = gp(g["pts"])
+    check(mu, g["mu"], what="mean")
+    check(sig, g["sig"], what="sigma")
+    gp.engine.set_streams(4)
+    vals = sharding.marginal_likelihood_sweep(gp, grid[sel])
+    check(vals, g["lml"], what="8-point share of the RQ grid")
+    assert np.array_equal(vals, sharding.marginal_likelihood_sweep(gp, grid[sel]))
 
 
 # ---------------------------------------------------------------------------------------
