@@ -243,6 +243,17 @@ int gpmi_linv_lml_grad(gpmi_ctx* ctx, int kernel, const double* theta_host, int 
 int gpmi_linv_posterior(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_theta,
                         double extra_diag, const double* mu_host, double* mean_host, double* cov_host,
                         int* info);
+/* The same three with a prior covariance the CALLER evaluated (K_host: n x n, row-major, symmetric) - any
+ * CovarianceFunction object the reference accepts as `prior_covariance_function` (inversion.py:117-127, plugin ABC
+ * covariance.py:8-44): the host calls the object's own build_covariance / covariance_and_gradients, the device does
+ * A K A^T + Sigma, the factorisation, the solves and the inverse.  gpmi_linv_lml_grad_dense returns
+ * G = A^T J^-1 A (n x n) and w = A^T alpha (at_alpha_host, n): grad_j = 1/2 sum (w w^T - G) o dK_j on the host
+ * (inversion.py:202-216 with Q = alpha alpha^T - J^-1 folded through A). */
+int gpmi_linv_lml_dense(gpmi_ctx* ctx, const double* K_host, const double* mu_host, double* lml, int* info);
+int gpmi_linv_lml_grad_dense(gpmi_ctx* ctx, const double* K_host, const double* mu_host, double* lml,
+                             double* G_host, double* at_alpha_host, int* info);
+int gpmi_linv_posterior_dense(gpmi_ctx* ctx, const double* K_host, const double* mu_host, double* mean_host,
+                              double* cov_host, int* info);
 
 /* ---- multi-GPU result gather (RCCL over xGMI) ----------------------------------------
  * Replaces the result return of multiprocessing.Pool.map (regression.py:600-601) and the

@@ -515,7 +515,6 @@ int gpmi_destroy(gpmi_ctx* c) {
   }
   if (c->stamp_pool) (void)hipFree(c->stamp_pool);
   if (c->dev_masked) (void)hipStreamDestroy(c->dev_masked);
-  if (c->flow_gate) (void)hipEventDestroy(c->flow_gate);
   if (c->trsm_panel) (void)hipFree(c->trsm_panel);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->t0) (void)hipEventDestroy(c->t0);
@@ -778,6 +777,8 @@ int gpmi_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
 int gpmi_predict(gpmi_ctx* c, const double* pts, int64_t m, double* mu_out, double* var_out) {
   if (!c) return GPMI_ERR_ARG;
   ARGCHK(c, c->fitted, "gpmi_predict needs a successful gpmi_fit");
+  ARGCHK(c, c->fit_params.kernel >= 0 || c->mix_nk > 0,
+         "gpmi_predict: the model was fitted with a caller-built covariance (gpmi_fit_dense) - use gpmi_predict_dense / gpmi_solve_rows");
   ARGCHK(c, pts && m > 0, "pts is NULL or m <= 0");
   if (int rc = set_device(c)) return rc;
   Lane& L = c->lanes[0];
@@ -815,6 +816,8 @@ int gpmi_predict(gpmi_ctx* c, const double* pts, int64_t m, double* mu_out, doub
 int gpmi_posterior(gpmi_ctx* c, const double* pts, int64_t m, double* mu_out, double* cov_out) {
   if (!c) return GPMI_ERR_ARG;
   ARGCHK(c, c->fitted, "gpmi_posterior needs a successful gpmi_fit");
+  ARGCHK(c, c->fit_params.kernel >= 0 || c->mix_nk > 0,
+         "gpmi_posterior: the model was fitted with a caller-built covariance (gpmi_fit_dense) - use gpmi_predict_dense / gpmi_solve_rows");
   ARGCHK(c, pts && m > 0, "pts is NULL or m <= 0");
   if (int rc = set_device(c)) return rc;
   Lane& L = c->lanes[0];
@@ -854,6 +857,8 @@ int gpmi_spatial_derivatives(gpmi_ctx* c, const double* pts, int64_t m, double* 
                              double* dvar_out) {
   if (!c) return GPMI_ERR_ARG;
   ARGCHK(c, c->fitted, "gpmi_spatial_derivatives needs a successful gpmi_fit");
+  ARGCHK(c, c->fit_params.kernel >= 0 || c->mix_nk > 0,
+         "gpmi_spatial_derivatives: the model was fitted with a caller-built covariance (gpmi_fit_dense) - use gpmi_predict_dense / gpmi_solve_rows");
   ARGCHK(c, c->fit_params.kernel == GPMI_KERNEL_SE, "spatial derivatives: SquaredExponential only");
   ARGCHK(c, pts && m > 0 && dmu_out && dvar_out, "NULL argument or m <= 0");
   if (int rc = set_device(c)) return rc;
@@ -888,6 +893,8 @@ int gpmi_spatial_derivatives(gpmi_ctx* c, const double* pts, int64_t m, double* 
 int gpmi_gradient(gpmi_ctx* c, const double* pts, int64_t m, double* gmu_out, double* gcov_out) {
   if (!c) return GPMI_ERR_ARG;
   ARGCHK(c, c->fitted, "gpmi_gradient needs a successful gpmi_fit");
+  ARGCHK(c, c->fit_params.kernel >= 0 || c->mix_nk > 0,
+         "gpmi_gradient: the model was fitted with a caller-built covariance (gpmi_fit_dense) - use gpmi_predict_dense / gpmi_solve_rows");
   ARGCHK(c, c->fit_params.kernel == GPMI_KERNEL_SE, "gradient: SquaredExponential only");
   ARGCHK(c, pts && m > 0 && gmu_out && gcov_out, "NULL argument or m <= 0");
   if (int rc = set_device(c)) return rc;
@@ -1084,6 +1091,7 @@ int gpmi_cross_covariance(gpmi_ctx* c, int kernel, const double* theta, int n_th
 int gpmi_get_K(gpmi_ctx* c, double* K_host) {
   if (!c) return GPMI_ERR_ARG;
   ARGCHK(c, c->fitted && K_host, "gpmi_get_K needs a successful gpmi_fit");
+  ARGCHK(c, c->fit_params.kernel >= 0, "gpmi_get_K: the covariance of this fit was built by the caller (gpmi_fit_dense / gpmi_fit_mix)");
   if (int rc = set_device(c)) return rc;
   if (int rc = ensure_lanes(c, 2)) return rc;
   Lane& L = c->lanes[1];
@@ -1716,7 +1724,9 @@ int linv_alloc(gpmi_ctx* c, double** p, int64_t doubles) {
 }
 
 // J = A K(theta) A^T + Sigma -> L, v = L^-1 (y - A mu) in vec[0:mp], red = {v.v, sum ln L_ii} in lanes[0].red
-int linv_factor(gpmi_ctx* c, const KParams& p, const double* mu_host) {
+// prior covariance: built on the device from kernel parameters (K_host == nullptr), or a dense n x n matrix the host
+// evaluated with the covariance object's own build_covariance (user-defined kernels, plugin ABC covariance.py:8-44)
+int linv_factor(gpmi_ctx* c, const KParams& p, const double* mu_host, const double* K_host = nullptr) {
   LinvState& S = c->linv;
   Lane& L = c->lanes[0];
   hipStream_t s = L.stream;
@@ -1730,7 +1740,13 @@ int linv_factor(gpmi_ctx* c, const KParams& p, const double* mu_host) {
   HIPCHK(c, hipMemsetAsync(mu_dev, 0, sizeof(double) * c->np, s));
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu_host, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
   // prior covariance, both triangles (it is a GEMM operand), identity in the padding (A's padding is zero)
-  launch_kbuild_square(s, p, c->x, c->n, c->np, S.zero, S.K, c->ld, false);
+  if (K_host) {
+    launch_set_identity(s, S.K, c->ld, c->np);
+    HIPCHK(c, hipMemcpy2DAsync(S.K, sizeof(double) * c->ld, K_host, sizeof(double) * c->n, sizeof(double) * c->n, c->n,
+                               hipMemcpyHostToDevice, s));
+  } else {
+    launch_kbuild_square(s, p, c->x, c->n, c->np, S.zero, S.K, c->ld, false);
+  }
   launch_gemm_nt(s, TILES_RECT, OP_ASSIGN, S.T, c->ld, S.A, c->ld, S.K, c->ld, mt, nt, (int)c->np);   // T = A K
   launch_gemm_nt(s, TILES_LOWER, OP_ASSIGN, S.J, S.ldm, S.T, c->ld, S.A, c->ld, mt, mt, (int)c->np);  // J = T A^T
   hipLaunchKernelGGL(linv_add_diag_kernel, dim3((unsigned)((S.mp + 255) / 256)), dim3(256), 0, s, S.J, S.ldm,
@@ -1794,16 +1810,12 @@ int gpmi_linv_set(gpmi_ctx* c, const double* A, int64_t m, const double* y, cons
   return GPMI_OK;
 }
 
-int gpmi_linv_lml(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,
-                  const double* mu, double* lml, int* info) {
-  if (!c) return GPMI_ERR_ARG;
-  if (int rc = linv_ready(c)) return rc;
-  KParams p;
-  if (int rc = make_params(c, kernel, theta, n_theta, extra_diag, p)) return rc;
+static int linv_lml_impl(gpmi_ctx* c, const KParams& p, const double* K_host, const double* mu, double* lml,
+                         int* info) {
   ARGCHK(c, mu && lml, "mu / lml is NULL");
   if (int rc = set_device(c)) return rc;
   Lane& L = c->lanes[0];
-  if (int rc = linv_factor(c, p, mu)) return rc;
+  if (int rc = linv_factor(c, p, mu, K_host)) return rc;
   HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, L.stream));
   HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, L.stream));
   HIPCHK(c, hipStreamSynchronize(L.stream));
@@ -1814,14 +1826,29 @@ int gpmi_linv_lml(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
   return GPMI_OK;
 }
 
-int gpmi_linv_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,
-                       const double* mu, double* lml, double* grad_theta, double* trace_q,
-                       double* at_alpha, int* info) {
+int gpmi_linv_lml(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,
+                  const double* mu, double* lml, int* info) {
   if (!c) return GPMI_ERR_ARG;
   if (int rc = linv_ready(c)) return rc;
   KParams p;
   if (int rc = make_params(c, kernel, theta, n_theta, extra_diag, p)) return rc;
-  ARGCHK(c, mu && lml && grad_theta, "mu / lml / grad_theta is NULL");
+  return linv_lml_impl(c, p, nullptr, mu, lml, info);
+}
+
+int gpmi_linv_lml_dense(gpmi_ctx* c, const double* K_host, const double* mu, double* lml, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  if (int rc = linv_ready(c)) return rc;
+  ARGCHK(c, K_host, "K is NULL");
+  return linv_lml_impl(c, KParams{}, K_host, mu, lml, info);
+}
+
+// n_theta >= 0: fused contraction with the kernel's own derivatives (grad_theta, trace_q);
+// n_theta < 0 (dense prior): G = A^T J^-1 A goes back to the host (G_host, n x n), which contracts it with the
+// covariance object's dK_j
+static int linv_lml_grad_impl(gpmi_ctx* c, const KParams& p, int n_theta, const double* K_host, const double* mu,
+                              double* lml, double* grad_theta, double* trace_q, double* G_host, double* at_alpha,
+                              int* info) {
+  ARGCHK(c, mu && lml && (grad_theta || G_host), "mu / lml / output is NULL");
   if (int rc = set_device(c)) return rc;
   LinvState& S = c->linv;
   Lane& L = c->lanes[0];
@@ -1832,7 +1859,7 @@ int gpmi_linv_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta
   if (int rc = linv_alloc(c, &S.inv2, (int64_t)((mt + 3) / 4) * GPMI_OB * GPMI_OB)) return rc;
   if (int rc = linv_alloc(c, &S.inv2_t, (int64_t)((mt + 3) / 4) * 256 * 256)) return rc;
   if (int rc = linv_alloc(c, &S.panel, S.mp * (GPMI_OB + 32))) return rc;
-  const int64_t need = grad_ws_doubles(c->np, n_theta);
+  const int64_t need = n_theta >= 0 ? grad_ws_doubles(c->np, n_theta) : 0;
   if (S.gws_doubles < need) {
     if (S.gws) (void)hipFree(S.gws);
     S.gws = nullptr;
@@ -1840,7 +1867,7 @@ int gpmi_linv_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta
     HIPCHK(c, hipMalloc(&S.gws, sizeof(double) * need));
     S.gws_doubles = need;
   }
-  if (int rc = linv_factor(c, p, mu)) return rc;
+  if (int rc = linv_factor(c, p, mu, K_host)) return rc;
   double* v = S.vec;
   double* alpha = S.vec + 4 * vmax;  // mp
   double* w = S.vec + 5 * vmax;      // np
@@ -1856,10 +1883,14 @@ int gpmi_linv_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta
   // A^T J^-1 A: U = J^-1 A (into T), then A^T U (into K; B = U is k-major)
   launch_gemm_nt(s, TILES_RECT, OP_ASSIGN, S.T, c->ld, S.J, S.ldm, S.At, S.ldm, mt, nt, (int)S.mp);
   launch_gemm(s, TILES_RECT, OP_ASSIGN, true, 0, S.K, c->ld, S.At, S.ldm, S.T, c->ld, nt, nt, (int)S.mp);
-  launch_lml_grad(s, p, n_theta, c->x, c->n, c->np, S.K, c->ld, w, w, S.gws, gout);
+  if (n_theta >= 0) launch_lml_grad(s, p, n_theta, c->x, c->n, c->np, S.K, c->ld, w, w, S.gws, gout);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(L.h_red + 16, gout, sizeof(double) * (n_theta + 1), hipMemcpyDeviceToHost, s));
+  if (n_theta >= 0)
+    HIPCHK(c, hipMemcpyAsync(L.h_red + 16, gout, sizeof(double) * (n_theta + 1), hipMemcpyDeviceToHost, s));
+  if (G_host)
+    HIPCHK(c, hipMemcpy2DAsync(G_host, sizeof(double) * c->n, S.K, sizeof(double) * c->ld, sizeof(double) * c->n, c->n,
+                               hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
   if (at_alpha) HIPCHK(c, hipMemcpyAsync(at_alpha, w, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
@@ -1872,12 +1903,27 @@ int gpmi_linv_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta
   return GPMI_OK;
 }
 
-int gpmi_linv_posterior(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,
-                        const double* mu, double* mean, double* cov, int* info) {
+int gpmi_linv_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,
+                       const double* mu, double* lml, double* grad_theta, double* trace_q,
+                       double* at_alpha, int* info) {
   if (!c) return GPMI_ERR_ARG;
   if (int rc = linv_ready(c)) return rc;
   KParams p;
   if (int rc = make_params(c, kernel, theta, n_theta, extra_diag, p)) return rc;
+  ARGCHK(c, grad_theta, "grad_theta is NULL");
+  return linv_lml_grad_impl(c, p, n_theta, nullptr, mu, lml, grad_theta, trace_q, nullptr, at_alpha, info);
+}
+
+int gpmi_linv_lml_grad_dense(gpmi_ctx* c, const double* K_host, const double* mu, double* lml, double* G_host,
+                             double* at_alpha, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  if (int rc = linv_ready(c)) return rc;
+  ARGCHK(c, K_host && G_host, "K / G is NULL");
+  return linv_lml_grad_impl(c, KParams{}, -1, K_host, mu, lml, nullptr, nullptr, G_host, at_alpha, info);
+}
+
+static int linv_posterior_impl(gpmi_ctx* c, const KParams& p, const double* K_host, const double* mu, double* mean,
+                               double* cov, int* info) {
   ARGCHK(c, mu && mean, "mu / mean is NULL");
   if (int rc = set_device(c)) return rc;
   LinvState& S = c->linv;
@@ -1889,7 +1935,7 @@ int gpmi_linv_posterior(gpmi_ctx* c, int kernel, const double* theta, int n_thet
   if (int rc = linv_alloc(c, &S.X, c->np * S.ldm)) return rc;
   if (int rc = linv_alloc(c, &S.inv2, (int64_t)((mt + 3) / 4) * GPMI_OB * GPMI_OB)) return rc;
   if (int rc = linv_alloc(c, &S.inv2_t, (int64_t)((mt + 3) / 4) * 256 * 256)) return rc;
-  if (int rc = linv_factor(c, p, mu)) return rc;
+  if (int rc = linv_factor(c, p, mu, K_host)) return rc;
   double* v = S.vec;
   double* dm = S.vec + 5 * vmax;  // np
   build_inv2(s, S.J, S.mp, S.ldm, S.invD, S.inv2, S.inv2_t);
@@ -1910,6 +1956,23 @@ int gpmi_linv_posterior(gpmi_ctx* c, int kernel, const double* theta, int n_thet
   INFOCHK(c, L.h_info[0]);
   if (info) *info = L.h_info[0];
   return GPMI_OK;
+}
+
+int gpmi_linv_posterior(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,
+                        const double* mu, double* mean, double* cov, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  if (int rc = linv_ready(c)) return rc;
+  KParams p;
+  if (int rc = make_params(c, kernel, theta, n_theta, extra_diag, p)) return rc;
+  return linv_posterior_impl(c, p, nullptr, mu, mean, cov, info);
+}
+
+int gpmi_linv_posterior_dense(gpmi_ctx* c, const double* K_host, const double* mu, double* mean, double* cov,
+                              int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  if (int rc = linv_ready(c)) return rc;
+  ARGCHK(c, K_host, "K is NULL");
+  return linv_posterior_impl(c, KParams{}, K_host, mu, mean, cov, info);
 }
 
 }  // extern "C"

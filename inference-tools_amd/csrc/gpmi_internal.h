@@ -142,8 +142,6 @@ struct gpmi_ctx {
   hipStream_t comm_stream = nullptr;
   double* comm_buf = nullptr;
   int64_t comm_buf_doubles = 0;
-  hipEvent_t flow_gate = nullptr;        // last large single-launch sweep (solve.hip: flow_gate_enter)
-  hipStream_t flow_gate_stream = nullptr;
   hipStream_t dev_masked = nullptr;  // tools: CU-masked stream of the device-pointer entry points (GPMI_DEV_CUS)
   // instrumentation
   hipEvent_t t0 = nullptr, t1 = nullptr;

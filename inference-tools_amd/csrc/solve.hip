@@ -6,6 +6,7 @@
 //   single right-hand side  -> HBM-bound GEMV sweeps (L is read exactly once per solve)
 //   many right-hand sides    -> the fp64 MFMA GEMM (right-hand sides stored as rows, "NT" form)
 #include <cstdlib>
+#include <mutex>
 
 #include "gpmi_internal.h"
 
@@ -363,25 +364,36 @@ __global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restric
 // Serialise sweeps of different streams so that their workgroups are always all resident together (see the
 // progress argument above): the chip holds 2 x ncu flow workgroups; a sweep of nt >= FLOW_GATE_MIN workgroups
 // (N > 4096: the sizes that run one lane per evaluation, gpmi_lml_batch) queues behind the previous such sweep of
-// the context through one event, whichever lane issues it, so at most one of them (<= 2 x ncu workgroups for
+// the context through one event, whichever lane or context issues it, so at most one of them (<= 2 x ncu workgroups for
 // N <= 65536) is in flight beside any number of small ones.  They are HBM-bound and sub-millisecond: nothing is
 // lost by not overlapping them.
+// The gate is per DEVICE, process-wide (one event per device id under a mutex), not per context: a regressor, the
+// engine its covariance object keeps for cross-covariances, a second regressor or another thread each have a context
+// of their own, and their sweeps share the same CUs.
 constexpr int64_t FLOW_GATE_MIN = 32;
+namespace {
+std::mutex g_sweep_mu;
+hipEvent_t g_sweep_ev[64] = {nullptr};
+bool g_sweep_used[64] = {false};
+}  // namespace
 static void flow_gate_enter(gpmi_ctx* c, hipStream_t s, int64_t workgroups) {
-  if (workgroups <= FLOW_GATE_MIN) return;
-  if (!c->flow_gate) {
-    if (hipEventCreateWithFlags(&c->flow_gate, hipEventDisableTiming) != hipSuccess) {
-      c->flow_gate = nullptr;
-      return;
-    }
-  } else if (c->flow_gate_stream != s) {
-    (void)hipStreamWaitEvent(s, c->flow_gate, 0);
+  if (workgroups <= FLOW_GATE_MIN || c->device < 0 || c->device >= 64) return;
+  std::lock_guard<std::mutex> lk(g_sweep_mu);
+  const int d = c->device;
+  if (!g_sweep_ev[d] && hipEventCreateWithFlags(&g_sweep_ev[d], hipEventDisableTiming) != hipSuccess) {
+    g_sweep_ev[d] = nullptr;
+    (void)hipGetLastError();
+    return;
   }
+  if (g_sweep_used[d]) (void)hipStreamWaitEvent(s, g_sweep_ev[d], 0);  // (a no-op behind the same stream's own record)
 }
 static void flow_gate_leave(gpmi_ctx* c, hipStream_t s, int64_t workgroups) {
-  if (workgroups <= FLOW_GATE_MIN || !c->flow_gate) return;
-  (void)hipEventRecord(c->flow_gate, s);
-  c->flow_gate_stream = s;
+  if (workgroups <= FLOW_GATE_MIN || c->device < 0 || c->device >= 64) return;
+  std::lock_guard<std::mutex> lk(g_sweep_mu);
+  const int d = c->device;
+  if (!g_sweep_ev[d]) return;
+  (void)hipEventRecord(g_sweep_ev[d], s);
+  g_sweep_used[d] = true;
 }
 
 void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,

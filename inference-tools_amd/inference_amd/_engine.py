@@ -399,3 +399,32 @@ class LinvEngine:
         self.h.call("gpmi_linv_posterior", kernel, dptr(theta), theta.size, float(extra_diag), dptr(mu),
                     dptr(mean), dptr(cov), C.byref(info))
         return mean, cov, info.value
+
+    # -- prior covariance evaluated by the caller (any CovarianceFunction object) ------------
+    def _dense(self, K):
+        K = as_f64(K)
+        if K.shape != (self.n, self.n):
+            raise ValueError(f"prior covariance must be ({self.n}, {self.n}), got {K.shape}")
+        return K
+
+    def lml_dense(self, K, mu):
+        K, mu = self._dense(K), as_f64(mu)
+        out, info = C.c_double(0.0), C.c_int(0)
+        self.h.call("gpmi_linv_lml_dense", dptr(K), dptr(mu), C.byref(out), C.byref(info))
+        return out.value, info.value
+
+    def lml_grad_dense(self, K, mu):
+        """(LML, G = A^T J^-1 A, w = A^T alpha, info): grad_j = 1/2 sum (w w^T - G) o dK_j."""
+        K, mu = self._dense(K), as_f64(mu)
+        lml, info = C.c_double(0.0), C.c_int(0)
+        G, w = np.empty((self.n, self.n)), np.empty(self.n)
+        self.h.call("gpmi_linv_lml_grad_dense", dptr(K), dptr(mu), C.byref(lml), dptr(G), dptr(w), C.byref(info))
+        return lml.value, G, w, info.value
+
+    def posterior_dense(self, K, mu, with_cov=True):
+        K, mu = self._dense(K), as_f64(mu)
+        info = C.c_int(0)
+        mean = np.empty(self.n)
+        cov = np.empty((self.n, self.n)) if with_cov else None
+        self.h.call("gpmi_linv_posterior_dense", dptr(K), dptr(mu), dptr(mean), dptr(cov), C.byref(info))
+        return mean, cov, info.value

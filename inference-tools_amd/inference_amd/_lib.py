@@ -75,6 +75,9 @@ SIGNATURES = {
     "gpmi_linv_lml": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _ip]),
     "gpmi_linv_lml_grad": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_linv_posterior": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _ip]),
+    "gpmi_linv_lml_dense": (C.c_int, [_vp, _dp, _dp, _dp, _ip]),
+    "gpmi_linv_lml_grad_dense": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_linv_posterior_dense": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_append_point": (C.c_int, [_vp, _dp, C.c_double, C.c_double, _dp, _dp, _dp, _ip]),
     "gpmi_capacity": (C.c_int, [_vp, C.POINTER(_i64)]),
     "gpmi_fit_dense": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _ip]),

@@ -10,8 +10,12 @@ runs that are waiting for an objective value are served by one batched call `fun
 The iterates of a run are those of `fmin_l_bfgs_b` up to the last bits in which a batched and a single
 device evaluation of the same point may differ.
 
-The driver uses SciPy's private `_lbfgsb.setulb`; if that entry point is missing or its signature differs
-(other SciPy versions) the runs fall back to `fmin_l_bfgs_b` one after another on the same batched objective.
+The driver uses SciPy's private `_lbfgsb.setulb` (written against SciPy 1.15's `_minimize_lbfgsb`).  A SciPy whose
+`setulb` differs can differ silently - same arity, other work-array sizes or task codes - so the driver is trusted
+only after a self-check in this process: before its first use it minimises a small bounded test function through
+the driver and through the public `fmin_l_bfgs_b` and requires identical iterates (x, f, function calls, iterations
+bit for bit).  If the entry point is missing, raises, or fails that check, the runs fall back to `fmin_l_bfgs_b`
+one after another on the same batched objective (same results, no lockstep) and `DRIVER_STATE` says why.
 """
 import numpy as np
 from scipy.optimize import fmin_l_bfgs_b
@@ -56,23 +60,65 @@ def _encode_bounds(bounds, n):
     return low, upp, nbd
 
 
+DRIVER_STATE = {"checked": False, "ok": False, "why": "not checked yet"}
+
+
+def _self_check(setulb):
+    """The reverse-communication driver against the public entry point on a bounded 4-D test problem (a tilted
+    Rosenbrock chain with two active bounds): identical x, f, funcalls and nit, or the driver is not used."""
+
+    def fg(x):
+        f = np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1.0 - x[:-1]) ** 2) + 0.1 * x[-1]
+        g = np.zeros_like(x)
+        g[:-1] = -400.0 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2.0 * (1.0 - x[:-1])
+        g[1:] += 200.0 * (x[1:] - x[:-1] ** 2)
+        g[-1] += 0.1
+        return float(f), g
+
+    def batch(X):
+        r = [fg(x) for x in X]
+        return np.array([a for a, _ in r]), np.array([b for _, b in r])
+
+    bounds = [(-1.5, 0.8), (None, 2.0), (-0.5, None), (None, None)]
+    starts = np.array([[-1.2, 1.0, 0.3, -0.7], [0.5, 0.5, 0.5, 0.5], [0.8, -1.0, 2.0, 1.5]])
+    kw = dict(pgtol=1e-9, factr=1e7, m=10, maxfun=15000, maxiter=15000, maxls=20)
+    try:
+        got = _drive(setulb, batch, starts, bounds, 4, **kw)
+    except Exception as err:  # signature / dtype / shape mismatch of a different SciPy
+        return False, f"driver raised {type(err).__name__}: {err}"
+    for (x, f, d), x0 in zip(got, starts):
+        xr, fr, dr = fmin_l_bfgs_b(fg, x0, approx_grad=False, bounds=bounds, **kw)
+        if not (np.array_equal(x, xr) and f == float(fr) and d["funcalls"] == dr["funcalls"] and d["nit"] == dr["nit"]
+                and d["warnflag"] == dr["warnflag"]):
+            return False, "driver and fmin_l_bfgs_b disagree on the self-check problem"
+    return True, "setulb driver verified against fmin_l_bfgs_b"
+
+
+def _driver():
+    """SciPy's setulb if this process has verified the driver against the public entry point, else None."""
+    if not DRIVER_STATE["checked"]:
+        DRIVER_STATE["checked"] = True
+        try:
+            from scipy.optimize import _lbfgsb
+
+            setulb = _lbfgsb.setulb
+        except (ImportError, AttributeError):
+            DRIVER_STATE.update(ok=False, why="scipy.optimize._lbfgsb.setulb not found")
+            return None
+        ok, why = _self_check(setulb)
+        DRIVER_STATE.update(ok=ok, why=why, setulb=setulb if ok else None)
+    return DRIVER_STATE.get("setulb") if DRIVER_STATE["ok"] else None
+
+
 def lockstep_lbfgsb(fun_batch, starts, bounds, pgtol=1e-5, factr=1e7, m=10, maxfun=15000, maxiter=15000, maxls=20):
     """Minimise from every row of `starts`; `fun_batch(X (B, n)) -> (f (B,), G (B, n))`.
     Returns a list of `(x, f, info)` in the order of `starts`, `info` with the keys of fmin_l_bfgs_b's dict
     ('warnflag', 'funcalls', 'nit', 'grad')."""
     starts = np.atleast_2d(np.asarray(starts, dtype=float))
     n = starts.shape[1]
-    try:
-        from scipy.optimize import _lbfgsb
-
-        setulb = _lbfgsb.setulb
-    except (ImportError, AttributeError):
-        setulb = None
+    setulb = _driver()
     if setulb is not None:
-        try:
-            return _drive(setulb, fun_batch, starts, bounds, n, pgtol, factr, m, maxfun, maxiter, maxls)
-        except TypeError:
-            pass  # another SciPy: different setulb signature
+        return _drive(setulb, fun_batch, starts, bounds, n, pgtol, factr, m, maxfun, maxiter, maxls)
 
     def single(x):
         f, g = fun_batch(np.asarray(x, dtype=float)[None, :])

@@ -71,10 +71,13 @@ class GpLinearInverter:
         self.cov_slice = slice(self.mean.n_params, self.n_hyperpars)
         self.hyperpar_labels = [*self.mean.hyperpar_labels, *self.cov.hyperpar_labels]
 
+        # SquaredExponential / RationalQuadratic (+ WhiteNoise) priors are built on the device; for any other
+        # CovarianceFunction object (the reference takes any, inversion.py:117-127) the host evaluates the object's
+        # own build_covariance / covariance_and_gradients and the device does every O(n^3) step (gpmi_linv_*_dense)
         plan = device_plan(self.cov)
-        if plan is None or heteroscedastic_slice(self.cov) is not None:
-            raise NotImplementedError(msg.no_device_kernel(type(self.cov)).replace("GpRegressor", "GpLinearInverter"))
-        self._kernel_id, self._stat, self._stat_slice, self._wn_index = plan
+        self._dense = plan is None or plan[0] < 0 or heteroscedastic_slice(self.cov) is not None  # -1: ChangePoint mixture
+        if not self._dense:
+            self._kernel_id, self._stat, self._stat_slice, self._wn_index = plan
         self._device = device
         self._engine = None
 
@@ -104,33 +107,56 @@ class GpLinearInverter:
     # ---------------------------------------------------------------------------------
     def calculate_posterior(self, theta: ndarray):
         """Posterior mean and covariance of the model parameters (inversion.py:138-156)."""
-        theta_stat, extra = self._device_args(theta)
-        prior_mean = self.mean.build_mean(np.asarray(theta, dtype=float)[self.mean_slice])
-        mean, cov, info = self.engine.posterior(self._kernel_id, theta_stat, extra, prior_mean, with_cov=True)
+        theta = np.asarray(theta, dtype=float)
+        prior_mean = self.mean.build_mean(theta[self.mean_slice])
+        if self._dense:
+            mean, cov, info = self.engine.posterior_dense(self.cov.build_covariance(theta[self.cov_slice]), prior_mean)
+        else:
+            theta_stat, extra = self._device_args(theta)
+            mean, cov, info = self.engine.posterior(self._kernel_id, theta_stat, extra, prior_mean, with_cov=True)
         self._check(info)
         return mean, cov
 
     def calculate_posterior_mean(self, theta: ndarray) -> ndarray:
         """Posterior mean only (inversion.py:158-175)."""
-        theta_stat, extra = self._device_args(theta)
-        prior_mean = self.mean.build_mean(np.asarray(theta, dtype=float)[self.mean_slice])
-        mean, _, info = self.engine.posterior(self._kernel_id, theta_stat, extra, prior_mean, with_cov=False)
+        theta = np.asarray(theta, dtype=float)
+        prior_mean = self.mean.build_mean(theta[self.mean_slice])
+        if self._dense:
+            mean, _, info = self.engine.posterior_dense(self.cov.build_covariance(theta[self.cov_slice]), prior_mean,
+                                                        with_cov=False)
+        else:
+            theta_stat, extra = self._device_args(theta)
+            mean, _, info = self.engine.posterior(self._kernel_id, theta_stat, extra, prior_mean, with_cov=False)
         self._check(info)
         return mean
 
     def marginal_likelihood(self, theta: ndarray) -> float:
         """Log-marginal likelihood without the 2 pi constant (inversion.py:177-191)."""
-        theta_stat, extra = self._device_args(theta)
-        prior_mean = self.mean.build_mean(np.asarray(theta, dtype=float)[self.mean_slice])
-        lml, info = self.engine.lml(self._kernel_id, theta_stat, extra, prior_mean)
+        theta = np.asarray(theta, dtype=float)
+        prior_mean = self.mean.build_mean(theta[self.mean_slice])
+        if self._dense:
+            lml, info = self.engine.lml_dense(self.cov.build_covariance(theta[self.cov_slice]), prior_mean)
+        else:
+            theta_stat, extra = self._device_args(theta)
+            lml, info = self.engine.lml(self._kernel_id, theta_stat, extra, prior_mean)
         self._check(info)
         return float(lml)
 
     def marginal_likelihood_gradient(self, theta: ndarray):
         """Log-marginal likelihood and its gradient (inversion.py:193-217)."""
         theta = np.asarray(theta, dtype=float)
-        theta_stat, extra = self._device_args(theta)
         mu, grad_mu = self.mean.mean_and_gradients(theta[self.mean_slice])
+        if self._dense:
+            K, grad_K = self.cov.covariance_and_gradients(theta[self.cov_slice])
+            lml, G, w, info = self.engine.lml_grad_dense(K, mu)
+            self._check(info)
+            grad = np.zeros(self.n_hyperpars)
+            grad[self.mean_slice] = np.array([(w * dmu).sum() for dmu in grad_mu])
+            # 1/2 sum (alpha alpha^T - J^-1) o (A dK A^T)^T = 1/2 sum (w w^T - A^T J^-1 A) o dK^T, w = A^T alpha
+            Q = w[:, None] * w[None, :] - G
+            grad[self.cov_slice] = np.array([0.5 * (Q * dK.T).sum() for dK in grad_K])
+            return float(lml), grad
+        theta_stat, extra = self._device_args(theta)
         lml, g_stat, trace_q, at_alpha, info = self.engine.lml_grad(self._kernel_id, theta_stat, extra, mu)
         self._check(info)
         grad = np.zeros(self.n_hyperpars)

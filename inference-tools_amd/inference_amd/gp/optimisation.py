@@ -109,15 +109,18 @@ class GpOptimiser:
         self.convergence_metric_history.append(self.acquisition.convergence_metric(point))
         self.iteration_history.append(self.y.size + 1)
 
+        if self.y_err is not None and error is None:
+            raise ValueError(msg.NEW_Y_ERR_REQUIRED)
+        if self.reuse_hyperpars:
+            # the model first: a point that makes the factor update fail (a duplicate proposal at fixed
+            # hyper-parameters: pivot <= 0, LinAlgError) must leave the optimiser's own record unchanged too
+            self.gp.add_point(point, value, error)
         self.x = np.append(self.x, point, axis=0)
         self.y = np.append(self.y, value)
         if self.y_err is not None:
-            if error is None:
-                raise ValueError(msg.NEW_Y_ERR_REQUIRED)
             self.y_err = np.append(self.y_err, error)
 
         if self.reuse_hyperpars:
-            self.gp.add_point(point, value, error)
             self.acquisition.update_gp(self.gp)
         else:
             self._fit_gp()

@@ -292,10 +292,26 @@ class GpRegressor:
         if (self._noise_var is None) != (y_err_new is None):
             raise ValueError("y_err_new must be given exactly when the model was built with y_err")
         var_new = 0.0 if y_err_new is None else float(np.asarray(y_err_new).squeeze()) ** 2
-        fast = (not self._generic and self._mix is None and self._het_slice is None and self._y_cov is None
+        if self._het_slice is not None:
+            # one noise hyper-parameter per training point: the hyper-parameter vector itself would have to grow
+            raise NotImplementedError("add_point with HeteroscedasticNoise: rebuild the regressor with the enlarged data")
+        fast = (not self._generic and self._mix is None and self._y_cov is None
                 and self._engine is not None and self.engine.n < self.engine.capacity())
-        self.x = np.vstack([self.x, x_new])
-        self.y = np.append(self.y, y_new)
+        x_all = np.vstack([self.x, x_new])
+        y_all = np.append(self.y, y_new)
+        if fast:
+            # the device first: a pivot <= 0 (a duplicate point at fixed hyper-parameters) must leave host and device
+            # state as they were.  The means are centred on the data, so the prior mean comes from a copy that already
+            # knows the new point.
+            import copy
+
+            mean_new = copy.deepcopy(self.mean)
+            mean_new.pass_spatial_data(x_all)
+            mu_new = mean_new.build_mean(self.mean_hyperpars)
+            alpha, logdet, info = self.engine.append_point(x_new[0], y_new, var_new, mu_new)
+            if info != 0:
+                raise LinAlgError("Matrix is not positive definite")
+        self.x, self.y = x_all, y_all
         if self._noise_var is not None:
             self._noise_var = np.append(self._noise_var, var_new)
         self.n_points = self.y.size
@@ -309,10 +325,7 @@ class GpRegressor:
             self._reserve = max(getattr(self, "_reserve", 0), 128)
             self.set_hyperparameters(self.hyperpars)
             return
-        self.mu = self.mean.build_mean(self.mean_hyperpars)
-        alpha, logdet, info = self.engine.append_point(x_new[0], y_new, var_new, self.mu)
-        if info != 0:
-            raise LinAlgError("Matrix is not positive definite")
+        self.mu = mu_new
         self.alpha, self._logdet = alpha, logdet
 
     def check_error_data(self, y_err, y_cov):
@@ -395,10 +408,6 @@ class GpRegressor:
             dmu, dvar = self._generic_spatial_derivatives(p)
             return dmu.reshape(len(p), -1), dvar.reshape(len(p), -1)
         return self.engine.spatial_derivatives(p)
-
-    def _no_mixture(self, what):
-        if self._mix is not None:
-            raise NotImplementedError(f"{what} is not available on the device for ChangePoint kernels yet")
 
     def build_posterior(self, points: ndarray, mean_only=False):
         """Posterior mean vector and covariance matrix (regression.py:421-449)."""

@@ -28,6 +28,8 @@ Cases
              SE + HeteroscedasticNoise
   plugin     a user-defined covariance function written against the plugin ABC only (Matern-3/2, workloads.Matern32Math):
              every public GpRegressor method, the seeded hyper-parameter search and an EI proposal
+  linvp      GpLinearInverter with a prior that has no device kernel: the plugin Matern-3/2 (ABC only) on the tomography
+             problem and ChangePoint over [SE, RQ] on the deconvolution problem - LML, gradient, posterior
   means      LinearMean / QuadraticMean: labels, bounds, fit, predict, LML, LML gradient (mean-parameter components
              included), LOO gradient, posterior
   head16k    the metric's own size: SE, N=16384, d=8 (fit at the timing theta: alpha at 64 indices, |alpha|, diag(L),
@@ -431,6 +433,51 @@ def case_linv():
     return out
 
 
+def case_linvp():
+    """GpLinearInverter with priors that are not SE / RQ (+ WhiteNoise): any CovarianceFunction object is accepted
+    (inversion.py:117-127)."""
+    from inference.gp import GpLinearInverter
+    from inference.gp.covariance import CovarianceFunction
+
+    class Matern32(wl.Matern32Math, CovarianceFunction):
+        pass
+
+    out = {}
+    pos, A, y, y_err = wl.linv_problem("tomo")
+    gli = GpLinearInverter(y=y, y_err=y_err, model_matrix=A, parameter_spatial_positions=pos,
+                           prior_covariance_function=Matern32())
+    thetas = np.array([[0.2, np.log(0.6), np.log(0.2), np.log(0.25)], [0.0, np.log(1.1), np.log(0.35), np.log(0.15)]])
+    out["m32_thetas"] = thetas
+    out["m32_labels"] = np.array(gli.hyperpar_labels)
+    out["m32_lml"] = np.array([gli.marginal_likelihood(t) for t in thetas])
+    res = [gli.marginal_likelihood_gradient(t) for t in thetas]
+    out["m32_lml2"], out["m32_grad"] = np.array([r[0] for r in res]), np.array([r[1] for r in res])
+    pm, pc = gli.calculate_posterior(thetas[0])
+    out["m32_pmean"], out["m32_pcov"] = pm, pc[IDX_TOMO][:, IDX_TOMO]
+    out["m32_pmean_only"] = gli.calculate_posterior_mean(thetas[0])
+    pos, A, y, y_err = wl.linv_problem("deconv")
+    cp = ChangePoint(kernels=[SquaredExponential, RationalQuadratic])
+    gli = GpLinearInverter(y=y, y_err=y_err, model_matrix=A, parameter_spatial_positions=pos,
+                           prior_covariance_function=cp)
+    th = np.zeros(gli.n_hyperpars)
+    lab = gli.hyperpar_labels
+    rng = np.random.default_rng(99)
+    th[:] = 0.1 * rng.standard_normal(th.size)
+    for i, name in enumerate(lab):  # a change point inside the domain, a finite width
+        if "location" in name.lower():
+            th[i] = 0.1
+        if "width" in name.lower():
+            th[i] = np.log(0.2) if "log" in name.lower() else 0.2
+    out["cp_labels"] = np.array(lab)
+    out["cp_theta"] = th
+    out["cp_lml"] = np.array(gli.marginal_likelihood(th))
+    l2, g = gli.marginal_likelihood_gradient(th)
+    out["cp_lml2"], out["cp_grad"] = np.array(l2), g
+    pm, pc = gli.calculate_posterior(th)
+    out["cp_pmean"], out["cp_pcov"] = pm, pc
+    return out
+
+
 def t32_data():
     rng = np.random.default_rng(1)
     points = rng.uniform(low=0.0, high=2.0, size=(32, 2))
@@ -745,6 +792,7 @@ CASES = {
     "cp": case_cp,
     "het": case_het,
     "linv": case_linv,
+    "linvp": case_linvp,
     "pt": case_pt,
     "t32": case_t32,
     "cfg1": case_cfg1,

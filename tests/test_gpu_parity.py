@@ -706,9 +706,52 @@ def test_linear_inverter_optimise_and_errors(gp_mod):
         gp_mod.GpLinearInverter(y=y, y_err=y_err, model_matrix=A, parameter_spatial_positions=pos[:-1])
     with pytest.raises(ValueError):
         gli.optimize_hyperparameters(np.zeros(5))
-    with pytest.raises(NotImplementedError):
-        gp_mod.GpLinearInverter(y=y, y_err=y_err, model_matrix=A, parameter_spatial_positions=pos,
-                                prior_covariance_function=gp_mod.SquaredExponential() + gp_mod.RationalQuadratic())
+    # a prior without a device kernel is served by the dense entry points, not refused
+    both = gp_mod.GpLinearInverter(y=y, y_err=y_err, model_matrix=A, parameter_spatial_positions=pos,
+                                   prior_covariance_function=gp_mod.SquaredExponential() + gp_mod.RationalQuadratic())
+    assert both._dense and np.isfinite(both.marginal_likelihood(np.array([0.1, 0.0, np.log(0.15), -1.0, 0.0, np.log(0.3)])))
+
+
+def test_linear_inverter_with_any_covariance_object(golden, gp_mod):
+    """`prior_covariance_function` may be any CovarianceFunction (inversion.py:117-127): a user-defined Matern-3/2 written
+    against the plugin ABC only (tomography problem, 300 x 400) and ChangePoint over [SE, RQ] (deconvolution), against
+    the reference running the same objects (tests/golden/linvp.npz).  The host evaluates the object's own
+    build_covariance / covariance_and_gradients; A K A^T + Sigma, the factorisation, the solves, J^-1 and A^T J^-1 A run on
+    the device (gpmi_linv_*_dense)."""
+    from inference_amd.gp.covariance import CovarianceFunction
+
+    class Matern32(wl.Matern32Math, CovarianceFunction):
+        pass
+
+    g = golden("linvp")
+    pos, A, y, y_err = wl.linv_problem("tomo")
+    gli = gp_mod.GpLinearInverter(y=y, y_err=y_err, model_matrix=A, parameter_spatial_positions=pos,
+                                  prior_covariance_function=Matern32())
+    assert list(g["m32_labels"]) == gli.hyperpar_labels
+    th = g["m32_thetas"]
+    check([gli.marginal_likelihood(t) for t in th], g["m32_lml"], what="lml (plugin prior)")
+    res = [gli.marginal_likelihood_gradient(t) for t in th]
+    check([r[0] for r in res], g["m32_lml2"], what="lml (gradient call)")
+    for r, ref in zip(res, g["m32_grad"]):
+        check_each(r[1], ref, what="lml gradient (plugin prior)")
+    idx = np.arange(0, 400, 7)
+    pm, pc = gli.calculate_posterior(th[0])
+    check(pm, g["m32_pmean"], 2e-9, "posterior mean")
+    check(pc[idx][:, idx], g["m32_pcov"], 2e-10, "posterior covariance")
+    check(gli.calculate_posterior_mean(th[0]), g["m32_pmean_only"], 2e-9, "posterior mean only")
+    pos, A, y, y_err = wl.linv_problem("deconv")
+    cp = gp_mod.ChangePoint(kernels=[gp_mod.SquaredExponential, gp_mod.RationalQuadratic])
+    gli = gp_mod.GpLinearInverter(y=y, y_err=y_err, model_matrix=A, parameter_spatial_positions=pos,
+                                  prior_covariance_function=cp)
+    assert list(g["cp_labels"]) == gli.hyperpar_labels
+    th = g["cp_theta"]
+    check(gli.marginal_likelihood(th), g["cp_lml"], what="lml (ChangePoint prior)")
+    lml, grad = gli.marginal_likelihood_gradient(th)
+    check(lml, g["cp_lml2"])
+    check_each(grad, g["cp_grad"], what="lml gradient (ChangePoint prior)")
+    pm, pc = gli.calculate_posterior(th)
+    check(pm, g["cp_pmean"], 2e-9, "posterior mean")
+    check(pc, g["cp_pcov"], 2e-10, "posterior covariance")
 
 
 # ---------------------------------------------------------------------------------------
@@ -1315,6 +1358,37 @@ def test_append_point_equals_fit_from_scratch(gp_mod, kid, n0, mean):
     gp2.add_point(x[128], y[128], e[128])
     ref2 = gp_mod.GpRegressor(x[:129], y[:129], y_err=e[:129], hyperpars=th, **kw)
     check_each(gp2.alpha, ref2.alpha, 1e-11, what="alpha after a re-fitting append")
+
+
+def test_failed_append_leaves_the_model_untouched(gp_mod):
+    """A point that makes the factor update fail (pivot <= 0, e.g. a duplicate without an error bar at fixed
+    hyper-parameters; forced here by making the device call report it): `add_point` raises LinAlgError and the host
+    state is as before - n_points, x, y, alpha, predictions - as is GpOptimiser's own record; a following valid append
+    works.  HeteroscedasticNoise models are refused up front."""
+    from numpy.linalg import LinAlgError
+
+    x, y, _ = wl.synthetic_dataset(31, 200, 2)
+    e = np.full(200, 0.1)
+    th = np.array([y.mean(), np.log(y.std()), np.log(0.4), np.log(0.4)])
+    gp = gp_mod.GpRegressor(x[:150], y[:150], y_err=e[:150], hyperpars=th, reserve=64)
+    pts = wl.query_points(31, 20, 2)
+    mu0, sig0 = gp(pts)
+    alpha0 = gp.alpha.copy()
+    real = gp.engine.append_point
+    gp.engine.append_point = lambda *a: (None, 0.0, 151)  # the device reports pivot 151 <= 0 and has written nothing
+    with pytest.raises(LinAlgError):
+        gp.add_point(x[7], y[7], 0.0)
+    gp.engine.append_point = real
+    assert gp.n_points == 150 and gp.x.shape == (150, 2) and gp.y.size == 150
+    assert np.array_equal(gp.alpha, alpha0)
+    mu1, sig1 = gp(pts)
+    assert np.array_equal(mu1, mu0) and np.array_equal(sig1, sig0)
+    gp.add_point(x[150], y[150], e[150])
+    ref = gp_mod.GpRegressor(x[:151], y[:151], y_err=e[:151], hyperpars=th)
+    check_each(gp.alpha, ref.alpha, 1e-11, what="alpha after a failed and a valid append")
+    het = gp_mod.GpRegressor(x[:40], y[:40], kernel=gp_mod.SquaredExponential() + gp_mod.HeteroscedasticNoise())
+    with pytest.raises(NotImplementedError):
+        het.add_point(x[41], y[41])
 
 
 def test_gp_optimiser_reusing_hyperparameters(gp_mod):

@@ -37,16 +37,26 @@ def test_lockstep_runs_equal_serial_fmin_l_bfgs_b():
 
 
 def test_lockstep_falls_back_when_the_private_entry_point_differs(monkeypatch):
-    """Another SciPy whose `setulb` has a different signature (TypeError): same results from the serial fall-back."""
+    """Another SciPy: (a) a `setulb` with a different signature (raises), (b) one that runs but behaves differently (same
+    arity, other numbers) - the self-check rejects both and the serial fall-back gives the same results."""
     from inference_amd.gp import _lockstep
 
     batch, bounds, starts = _problem()
     want = lockstep_lbfgsb(batch, starts[:3], bounds, pgtol=1e-10)
+    assert _lockstep.DRIVER_STATE["ok"], _lockstep.DRIVER_STATE["why"]
+    real_drive = _lockstep._drive
 
     def other_signature(*a, **k):
         raise TypeError("setulb() takes 12 positional arguments")
 
-    monkeypatch.setattr(_lockstep, "_drive", other_signature)
-    got = lockstep_lbfgsb(batch, starts[:3], bounds, pgtol=1e-10)
-    for a, b in zip(want, got):
-        assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+    def other_numbers(setulb, fun_batch, starts_, *a, **k):
+        out = real_drive(setulb, fun_batch, starts_, *a, **k)
+        return [(x * (1 + 1e-9), f, d) for x, f, d in out]
+
+    for fake in (other_signature, other_numbers):
+        monkeypatch.setattr(_lockstep, "_drive", fake)
+        monkeypatch.setattr(_lockstep, "DRIVER_STATE", {"checked": False, "ok": False, "why": ""})
+        got = lockstep_lbfgsb(batch, starts[:3], bounds, pgtol=1e-10)
+        assert not _lockstep.DRIVER_STATE["ok"] and _lockstep.DRIVER_STATE["why"]
+        for a_, b_ in zip(want, got):
+            assert np.array_equal(a_[0], b_[0]) and a_[1] == b_[1]
