@@ -669,7 +669,7 @@ int gpmi_lml_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int
       else
         HIPCHK(c, hipMemcpyAsync(c->bMu, mu_const + t0, sizeof(double) * B, hipMemcpyHostToDevice, s));
       HIPCHK(c, hipMemsetAsync(c->bInfo, 0, sizeof(int) * B, s));
-      launch_kbuild_square_batched(s, ps[0].kernel, c->bParams, B, c->x, c->n, c->np, c->noise, c->bA, c->ld, bs.sMat);
+      launch_kbuild_square_batched(s, ps[0].kernel, c->bParams, B, c->x, c->n, c->np, c->noise, c->bA, c->ld, bs.sMat, (int)c->d);
       potrf_lower_batched(c, s, c->bA, c->np, c->ld, c->bInv, c->bInfo, bs);
       launch_residual_batched(s, c->y, mus ? c->bMu : nullptr, mus ? nullptr : c->bMu,
                               c->bVec + 2 * c->np, c->n, c->np, bs);

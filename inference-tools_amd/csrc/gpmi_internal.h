@@ -271,7 +271,7 @@ void potrf_lower_batched(gpmi_ctx* c, hipStream_t s, double* A, int64_t np, int6
                          int* info, const BatchShape& bs);
 void launch_kbuild_square_batched(hipStream_t s, int kernel, const KParams* pdev, int batch, const double* x,
                                   int64_t n, int64_t np, const double* noise, double* A, int64_t ld,
-                                  int64_t stride);
+                                  int64_t stride, int d);
 // blocked right-looking Cholesky, in place, lower; invD receives the inverses of the diagonal blocks
 // allow_lookahead = false keeps everything on the lane's full-chip stream (several lanes running
 // concurrently already fill the chip, and their masked stream pairs would only fight for HW queues)

@@ -5,19 +5,33 @@
 // every thread produces a 4 x 4 block of K, written as 32-byte row segments (16 threads -> 512
 // contiguous bytes per row).  HBM-write bound: 8 bytes per element, x is read once per tile from L2.
 #include "gpmi_internal.h"
+#include "kmath.h"
 
 namespace {
 
 constexpr int KT = 64;  // output tile edge
 
-// KERNEL is a template parameter of the builders: with the choice made at run time every one of the 16 unrolled
-// elements of a thread carried both exp and pow (6 000 instructions per kernel, well beyond the instruction cache
-// two CUs share); one function per build keeps the SquaredExponential kernel at a quarter of that.
-template <int KERNEL>
-__device__ inline double kfun(const KParams& p, double s) {
-  // s = sum_k 0.5 * dx_k^2 / l_k^2  (>= 0)
-  if (KERNEL == GPMI_KERNEL_SE) return exp(-s);                // covariance.py:254
-  return pow(1.0 + s / p.kappa, -p.kappa);                      // covariance.py:348
+// Covariance function of N elements at once (kmath.h: a thread's elements go through exp / log1p in lockstep, so a
+// polynomial coefficient is fetched once per N FMAs; the library's exp() inlined per element re-materialised its
+// constants at every use - as many v_mov_b32 as arithmetic - and its pow() is ~300 instructions per element).
+// KERNEL is a template parameter of the builders: one covariance function per kernel keeps the code within the
+// instruction cache two CUs share.   s = sum_k 0.5 * dx_k^2 / l_k^2  (>= 0)
+template <int KERNEL, int N>
+__device__ inline void kfun(const KParams& p, const double (&s)[N], double (&out)[N]) {
+  double e[N];
+  if (KERNEL == GPMI_KERNEL_SE) {  // exp(-s)  (covariance.py:254)
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = -s[i];
+  } else {  // (1 + s / kappa)^-kappa = exp(-kappa log1p(s / kappa))  (covariance.py:348)
+    const double ik = 1.0 / p.kappa;
+    double z[N], l[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) z[i] = s[i] * ik;
+    kmath::log1p_pos(z, l);
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = -p.kappa * l[i];
+  }
+  kmath::exp_neg(e, out);
 }
 
 // SQUARE: U == V, jitter + noise on the diagonal, identity in the padding (rows/cols >= n).
@@ -66,10 +80,13 @@ __device__ inline void kbuild_body(const KParams& p, const double* __restrict__ 
   } else if (SQUARE && lower_only && tj > ti) {
     return;
   }
-  __shared__ double su[GPMI_MAX_D * KT];
-  __shared__ double sv[GPMI_MAX_D * KT];
+  // the two point panels, [dim][point]: 2 x d x 64 doubles of dynamic LDS (a static 2 x GPMI_MAX_D x 64 = 64 KiB held
+  // the kernel at two workgroups per CU whatever d was; at d = 8 it needs 8 KiB)
+  extern __shared__ double kb_lds[];
   const int tid = threadIdx.x;
   const int d = p.d;
+  double* su = kb_lds;
+  double* sv = kb_lds + d * KT;
   const int64_t i0 = (int64_t)ti * KT, j0 = (int64_t)tj * KT;
   // stage panels transposed: s[k][pt]
   for (int idx = tid; idx < KT * d; idx += 256) {
@@ -101,6 +118,19 @@ __device__ inline void kbuild_body(const KParams& p, const double* __restrict__ 
       }
   }
 #pragma unroll
+  for (int h = 0; h < 2; ++h) {  // two halves of eight elements: 16 at once cost occupancy, 8 already amortise the constants
+    double sv8[8], cf8[8];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sv8[4 * r + c] = s[2 * h + r][c];
+    kfun<KERNEL>(p, sv8, cf8);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s[2 * h + r][c] = cf8[4 * r + c];
+  }
+#pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t gi = i0 + ty * 4 + r;
     double v[4];
@@ -109,7 +139,7 @@ __device__ inline void kbuild_body(const KParams& p, const double* __restrict__ 
       const int64_t gj = j0 + tx * 4 + c;
       double val;
       if (gi < nu && gj < nv) {
-        double cfun = kfun<KERNEL>(p, s[r][c]);
+        double cfun = s[r][c];
         if (SQUARE && gi == gj) {
           // a^2 (C + 1e-12) + WhiteNoise + sig   (covariance.py:254-255, 163-169; regression.py:239)
           val = p.a2 * (cfun + 1e-12);
@@ -138,16 +168,18 @@ __global__ void add_full_kernel(double* __restrict__ A, int64_t ld, const double
 
 }  // namespace
 
+static size_t kb_lds_bytes(int d) { return sizeof(double) * 2 * (size_t)d * KT; }
+
 // dispatch on the covariance function (a template parameter of the kernels)
 template <bool SQUARE>
 static void launch_kb(dim3 grid, hipStream_t s, const KParams& p, const double* U, int64_t nu, const double* V,
                       int64_t nv, const double* noise, double* out, int64_t ld, int lower_only) {
   if (p.kernel == GPMI_KERNEL_SE)
-    hipLaunchKernelGGL((kbuild_kernel<SQUARE, GPMI_KERNEL_SE>), grid, dim3(256), 0, s, p, U, nu, V, nv, noise, out, ld,
-                       lower_only);
+    hipLaunchKernelGGL((kbuild_kernel<SQUARE, GPMI_KERNEL_SE>), grid, dim3(256), kb_lds_bytes(p.d), s, p, U, nu, V, nv,
+                       noise, out, ld, lower_only);
   else
-    hipLaunchKernelGGL((kbuild_kernel<SQUARE, GPMI_KERNEL_RQ>), grid, dim3(256), 0, s, p, U, nu, V, nv, noise, out, ld,
-                       lower_only);
+    hipLaunchKernelGGL((kbuild_kernel<SQUARE, GPMI_KERNEL_RQ>), grid, dim3(256), kb_lds_bytes(p.d), s, p, U, nu, V, nv,
+                       noise, out, ld, lower_only);
 }
 
 void launch_kbuild_square(hipStream_t s, const KParams& p, const double* x, int64_t n, int64_t np,
@@ -173,13 +205,15 @@ void launch_kbuild_square_part(hipStream_t s, const KParams& p, const double* x,
 
 void launch_kbuild_square_batched(hipStream_t s, int kernel, const KParams* pdev, int batch, const double* x,
                                   int64_t n, int64_t np, const double* noise, double* A, int64_t ld,
-                                  int64_t stride) {
+                                  int64_t stride, int d) {
   const unsigned nt = (unsigned)(np / KT);
   dim3 grid(nt * (nt + 1) / 2, 1, (unsigned)batch);  // lower tiles only, one-dimensional (kbuild_body, mode 2)
   if (kernel == GPMI_KERNEL_SE)
-    hipLaunchKernelGGL(kbuild_batched_kernel<GPMI_KERNEL_SE>, grid, dim3(256), 0, s, pdev, x, n, noise, A, ld, stride);
+    hipLaunchKernelGGL(kbuild_batched_kernel<GPMI_KERNEL_SE>, grid, dim3(256), kb_lds_bytes(d), s, pdev, x, n, noise, A,
+                       ld, stride);
   else
-    hipLaunchKernelGGL(kbuild_batched_kernel<GPMI_KERNEL_RQ>, grid, dim3(256), 0, s, pdev, x, n, noise, A, ld, stride);
+    hipLaunchKernelGGL(kbuild_batched_kernel<GPMI_KERNEL_RQ>, grid, dim3(256), kb_lds_bytes(d), s, pdev, x, n, noise, A,
+                       ld, stride);
 }
 
 void launch_kbuild_cross(hipStream_t s, const KParams& p, const double* U, int64_t mu, int64_t mp,
