@@ -357,7 +357,7 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
         mu, sig = gp(pts)  # cross-covariance + TRSM + reductions
         # plain NumPy reductions only: a BLAS call here (np.linalg.norm -> OpenBLAS nrm2) starts OpenBLAS's
         # spinning worker pool, which starves the HIP runtime's completion handling and doubled the
-        # step time from the next step on (tools/phase_times3.py)
+        # step time from the next step on (tools/scratch/phase_times3.py)
         res = np.array([gp._logdet, float(np.sqrt(np.sum(gp.alpha**2))), float(mu.sum()), float(sig.sum())])
         if world > 1:
             res = allgather(res)

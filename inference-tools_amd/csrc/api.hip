@@ -68,7 +68,7 @@ int lane_streams(gpmi_ctx* c, Lane& L) {
 // so the first 8 m bits are m CUs on every XCD.  The pair is created together with the lane's main stream, before any
 // work is queued, and destroyed with it: created later (on first use, with kernels already in flight on the lane)
 // hipStreamDestroy blocked forever on ROCm 7.2, and a pair that is never destroyed ends the process in a SIGSEGV
-// inside the runtime's static destructors when rocprofv3 is attached (tools/probe_exit.py).  Only the lanes that
+// inside the runtime's static destructors when rocprofv3 is attached (tools/scratch/probe_exit.py).  Only the lanes that
 // can factorise with look-ahead get one: lane 0 (the fitted model) and lane 1 (single evaluations).
 bool ensure_masked_pair(gpmi_ctx* c, Lane& L, int k) {
   (void)c;
@@ -141,7 +141,7 @@ void lane_free(Lane& L) {
   if (L.ev_slice) (void)hipEventDestroy(L.ev_slice);
   DBG_FREE("lane: destroy masked streams");
   // hipStreamDestroy on a CU-masked stream blocks forever on ROCm 7.2 when it follows the stream's last
-  // synchronisation too closely (tools/probe_exit.py: 1 hang in 6 closes without the pause, 0 in 36 with 5 .. 300 ms; the round-1
+  // synchronisation too closely (tools/scratch/probe_exit.py: 1 hang in 6 closes without the pause, 0 in 36 with 5 .. 300 ms; the round-1
   // library only got away with it because loading librccl happened to sit in between)
   if (L.sp[0] || L.su[0]) {
     static const int pause_ms = [] {
@@ -502,7 +502,7 @@ int gpmi_destroy(gpmi_ctx* c) {
   if (!c) return GPMI_OK;
   (void)hipSetDevice(c->device);
   // every stream of the handle synchronised once here and once more in lane_free: hipStreamDestroy on a CU-masked
-  // stream that has only been synchronised once blocked forever on ROCm 7.2 (tools/probe_exit.py)
+  // stream that has only been synchronised once blocked forever on ROCm 7.2 (tools/scratch/probe_exit.py)
   (void)gpmi_sync(c);
   DBG_FREE("comm destroy");
   (void)gpmi_comm_destroy(c);

@@ -38,7 +38,7 @@ def mean(k, c):
 
 KB = 1024.0
 out = {
-    "command": "rocprofv3 --pmc <one group per pass> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline  (tools/pmc_bench.sh; passes: FETCH_SIZE | WRITE_SIZE | SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 | TCC_HIT_sum TCC_MISS_sum | GRBM_GUI_ACTIVE)",
+    "command": "rocprofv3 --pmc <one group per pass> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sharded, GPMI_FLOW=0  (tools/pmc_bench.sh; passes: FETCH_SIZE | WRITE_SIZE | SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 | TCC_HIT_sum TCC_MISS_sum | GRBM_GUI_ACTIVE)",
     "correction": "FETCH_SIZE x 2 (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md), WRITE_SIZE exact; both in KiB",
     "kernels": {},
     "cross_check": {"rocprof_kernel_stats_avg_us_of_the_dominant_kernel": upd_us, "launches": int(upd["Calls"]),

@@ -6,7 +6,7 @@ cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   d=$out/$(echo $c | tr ' ' '+')
   # (GPMI_FLOW=0: counter collection serialises kernels; the flag-ordered tail needs its two launches side by side)
-  GPMI_FLOW=0 BENCH_NO_PROF=1 timeout 600 rocprofv3 --pmc $c --output-format csv -d $d -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $d.log 2>&1
+  GPMI_FLOW=0 BENCH_NO_PROF=1 timeout 600 rocprofv3 --pmc $c --output-format csv -d $d -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sharded > $d.log 2>&1
 done
 python3 - "$out" <<'PY'
 import csv, glob, collections, sys, json

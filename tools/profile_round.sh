@@ -2,13 +2,13 @@
 # One GPU session that produces every profile artefact of a round under gpurun_out/prof_<tag>/ ; copy into profiles/ with
 #   python tools/make_profiles.py <tag>
 # usage (on the GPU box, through gpurun):  tools/profile_round.sh r02
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/prof_$tag
 rm -rf $GRAFT_REPO_ROOT/$out
 mkdir -p $GRAFT_REPO_ROOT/$out
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 # 1. headline: kernel trace + stats of the bench command, then the bench line itself (un-profiled)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline > $out/bench_traced.json 2> $out/bench_traced.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-sharded > $out/bench_traced.json 2> $out/bench_traced.err
 python3 tools/timeline_full.py $out/bench $out/bench_timeline.txt > /dev/null 2>&1
 timeout 300 python3 bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err
 # 2. the other BASELINE configurations and the LML-gradient path: per-kernel stats of the same public calls
