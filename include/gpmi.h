@@ -126,6 +126,14 @@ int gpmi_set_option(gpmi_ctx* ctx, int option, int value);
 int gpmi_lml_grad(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_theta,
                   double extra_diag, const double* mu_host, double* lml_host,
                   double* grad_theta_host, double* trace_q_host, double* alpha_host, int* info);
+/* T evaluations of gpmi_lml_grad (marginal_likelihood_gradient, regression.py:544-567) in one call - the L-BFGS-B starts
+ * of the hyper-parameter search (regression.py:585-605: the reference farms them over a multiprocessing.Pool).  For
+ * padded N <= 4096 the evaluations of a chunk advance in LOCKSTEP (every launch carries the chunk, as in
+ * gpmi_lml_batch); larger problems run one after another.  thetas: T x n_theta; extra, mu_const: T (or mus: T x n);
+ * outputs lml (T), grad_theta (T x n_theta), trace_q (T, may be NULL), alpha_host (T x n, may be NULL), info (T). */
+int gpmi_lml_grad_batch(gpmi_ctx* ctx, int kernel, int64_t T, const double* thetas_host, int n_theta,
+                        const double* extra_diag_host, const double* mus_host, const double* mu_const_host,
+                        double* lml, double* grad_theta, double* trace_q, double* alpha_host, int* info);
 
 /* ---- prediction (needs a prior gpmi_fit) --------------------------------------------
  * Replaces the per-point loop of GpRegressor.__call__ (regression.py:188-216) by one batched

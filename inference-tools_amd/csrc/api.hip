@@ -11,6 +11,7 @@
 #include <thread>
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -372,6 +373,12 @@ int ensure_batch_ws(gpmi_ctx* c, int want) {
   fr(c->bVec);
   fr(c->bRed);
   fr(c->bMu);
+  fr(c->bB2);
+  fr(c->bGws);
+  fr(c->bGout);
+  if (c->h_bGout) (void)hipHostFree(c->h_bGout);
+  c->h_bGout = nullptr;
+  c->bgrad_cap = c->bgrad_ntheta = 0;
   if (c->bInfo) (void)hipFree(c->bInfo);
   if (c->bParams) (void)hipFree(c->bParams);
   if (c->h_bRed) (void)hipHostFree(c->h_bRed);
@@ -392,6 +399,30 @@ int ensure_batch_ws(gpmi_ctx* c, int want) {
   HIPCHK(c, hipHostMalloc(&c->h_bRed, sizeof(double) * 2 * want));
   HIPCHK(c, hipHostMalloc(&c->h_bInfo, sizeof(int) * want));
   c->bcap = want;
+  return GPMI_OK;
+}
+
+// second matrix, contraction partials and result slots for gradient batches of `want` problems (after ensure_batch_ws)
+int ensure_batch_grad_ws(gpmi_ctx* c, int want, int n_theta) {
+  if (want > c->bcap) want = c->bcap;
+  if (want <= c->bgrad_cap && n_theta <= c->bgrad_ntheta) return GPMI_OK;
+  auto fr = [](double*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  };
+  fr(c->bB2);
+  fr(c->bGws);
+  fr(c->bGout);
+  if (c->h_bGout) (void)hipHostFree(c->h_bGout);
+  c->h_bGout = nullptr;
+  c->bgrad_cap = c->bgrad_ntheta = 0;
+  const int cap = c->bcap;
+  HIPCHK(c, hipMalloc(&c->bB2, sizeof(double) * cap * c->np * c->ld));
+  HIPCHK(c, hipMalloc(&c->bGws, sizeof(double) * cap * grad_ws_doubles(c->np, n_theta)));
+  HIPCHK(c, hipMalloc(&c->bGout, sizeof(double) * cap * (n_theta + 1)));
+  HIPCHK(c, hipHostMalloc(&c->h_bGout, sizeof(double) * cap * (n_theta + 1)));
+  c->bgrad_cap = cap;
+  c->bgrad_ntheta = n_theta;
   return GPMI_OK;
 }
 
@@ -771,6 +802,88 @@ int gpmi_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
   if (trace_q) *trace_q = L.h_red[16 + n_theta];
   INFOCHK(c, L.h_info[0]);
   if (info) *info = L.h_info[0];
+  return GPMI_OK;
+}
+
+int gpmi_lml_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int n_theta, const double* extra,
+                        const double* mus, const double* mu_const, double* lml, double* grad_theta, double* trace_q,
+                        double* alpha_out, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, T >= 1 && T <= RED_SLOTS, "T out of range");
+  ARGCHK(c, thetas && lml && grad_theta, "thetas / lml / grad_theta is NULL");
+  ARGCHK(c, mus || mu_const, "one of mus / mu_const is required");
+  if (int rc = set_device(c)) return rc;
+  const bool lockstep = (T >= 2 || c->lockstep_always) && c->np <= 4096 && !c->ycov;
+  if (!lockstep) {
+    // large problems are throughput-bound one at a time: the single-evaluation path, one after another
+    std::vector<double> mu_row((size_t)c->n);
+    for (int64_t t = 0; t < T; ++t) {
+      const double* mu_t = mus ? mus + t * c->n : mu_row.data();
+      if (!mus) std::fill(mu_row.begin(), mu_row.end(), mu_const[t]);
+      int inf = 0;
+      const int rc = gpmi_lml_grad(c, kernel, thetas + t * n_theta, n_theta, extra ? extra[t] : 0.0, mu_t, lml + t,
+                                   grad_theta + t * n_theta, trace_q ? trace_q + t : nullptr,
+                                   alpha_out ? alpha_out + t * c->n : nullptr, &inf);
+      if (info) info[t] = inf;
+      if (rc != GPMI_OK) return rc;
+    }
+    return GPMI_OK;
+  }
+  if (c->lanes.size() < 2)
+    if (int rc = ensure_lanes(c, 2)) return rc;
+  std::vector<KParams> ps((size_t)T);
+  for (int64_t t = 0; t < T; ++t)
+    if (int rc = make_params(c, kernel, thetas + t * n_theta, n_theta, extra ? extra[t] : 0.0, ps[(size_t)t])) return rc;
+  // lockstep: every launch carries the chunk in blockIdx.z - K-build, factorisation, both sweeps, L^-T by forward
+  // substitution on the identity, the k-skipped SYRK K^-1 = L^-T L^-1 (regression.py:556-557) and the fused contraction
+  if (int rc = ensure_batch_ws(c, (int)(T < 64 ? (T < 2 ? 2 : T) : 64))) return rc;
+  if (int rc = ensure_batch_grad_ws(c, c->bcap, n_theta)) return rc;
+  hipStream_t s = c->lanes[1].stream;
+  const int nt = (int)(c->np / GPMI_NB);
+  const BatchShape shape0{1, c->np * c->ld, (c->np / GPMI_NB) * GPMI_NB * GPMI_NB, 4 * c->np};
+  const int W = n_theta + 1;
+  for (int64_t t0 = 0; t0 < T; t0 += c->bgrad_cap) {
+    const int B = (int)((T - t0 < c->bgrad_cap) ? T - t0 : c->bgrad_cap);
+    BatchShape bs = shape0;
+    bs.count = B;
+    HIPCHK(c, hipMemcpyAsync(c->bParams, ps.data() + t0, sizeof(KParams) * B, hipMemcpyHostToDevice, s));
+    if (mus)
+      HIPCHK(c, hipMemcpyAsync(c->bMu, mus + t0 * c->n, sizeof(double) * B * c->n, hipMemcpyHostToDevice, s));
+    else
+      HIPCHK(c, hipMemcpyAsync(c->bMu, mu_const + t0, sizeof(double) * B, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(c->bInfo, 0, sizeof(int) * B, s));
+    launch_kbuild_square_batched(s, ps[0].kernel, c->bParams, B, c->x, c->n, c->np, c->noise, c->bA, c->ld, bs.sMat,
+                                 (int)c->d);
+    potrf_lower_batched(c, s, c->bA, c->np, c->ld, c->bInv, c->bInfo, bs);
+    launch_residual_batched(s, c->y, mus ? c->bMu : nullptr, mus ? nullptr : c->bMu, c->bVec + 2 * c->np, c->n, c->np,
+                            bs);
+    trsv_forward(c, s, c->bA, c->np, c->ld, c->bInv, c->bVec + 2 * c->np, c->bVec, c->bInfo, bs);
+    launch_lml_reduce(s, c->bVec, c->bA, c->ld, c->np, c->bRed, bs);
+    double* alpha_dev = c->bVec + c->np;  // slot 1 of every problem's four work vectors
+    trsv_backward(c, s, c->bA, c->np, c->ld, c->bInv, c->bVec, alpha_dev, c->bInfo, bs);
+    trsm_identity_batched(s, c->bA, c->np, c->ld, c->bInv, c->bB2, bs);
+    const GemmBatch syrk{B, bs.sMat, bs.sMat, bs.sMat};
+    launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, 1, c->bA, c->ld, c->bB2, c->ld, c->bB2, c->ld, nt, nt, (int)c->np,
+                nullptr, syrk);
+    launch_lml_grad_batched(s, c->bParams, B, n_theta, c->x, c->n, c->np, c->bA, c->ld, bs.sMat, alpha_dev, bs.sVec,
+                            c->bGws, c->bGout);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_bRed, c->bRed, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_bGout, c->bGout, sizeof(double) * W * B, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_bInfo, c->bInfo, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    if (alpha_out)
+      HIPCHK(c, hipMemcpy2DAsync(alpha_out + t0 * c->n, sizeof(double) * c->n, alpha_dev, sizeof(double) * bs.sVec,
+                                 sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int b = 0; b < B; ++b) {
+      const int inf = c->h_bInfo[b];
+      INFOCHK(c, inf);
+      lml[t0 + b] = -0.5 * c->h_bRed[2 * b] - c->h_bRed[2 * b + 1];
+      for (int j = 0; j < n_theta; ++j) grad_theta[(t0 + b) * n_theta + j] = c->h_bGout[b * W + j];
+      if (trace_q) trace_q[t0 + b] = c->h_bGout[b * W + n_theta];
+      if (info) info[t0 + b] = inf;
+    }
+  }
   return GPMI_OK;
 }
 

@@ -123,6 +123,11 @@ struct gpmi_ctx {
   double* bVec = nullptr;
   double* bRed = nullptr;
   double* bMu = nullptr;
+  double* bB2 = nullptr;     // second matrix per problem (L^-T), gradient batches only
+  double* bGws = nullptr;    // partial sums of the fused contraction
+  double* bGout = nullptr;   // (n_theta + 1) results per problem
+  double* h_bGout = nullptr;
+  int bgrad_cap = 0, bgrad_ntheta = 0;
   int* bInfo = nullptr;
   KParams* bParams = nullptr;
   double* h_bRed = nullptr;
@@ -191,6 +196,9 @@ int64_t grad_ws_doubles(int64_t np, int n_theta);
 void launch_lml_grad(hipStream_t s, const KParams& p, int n_theta, const double* x, int64_t n,
                      int64_t np, const double* iK, int64_t ld, const double* u, const double* v,
                      double* ws, double* out);
+void launch_lml_grad_batched(hipStream_t s, const KParams* pdev, int batch, int n_theta, const double* x, int64_t n,
+                             int64_t np, const double* iK, int64_t ld, int64_t sK, const double* alpha, int64_t sV,
+                             double* ws, double* out);
 void launch_mirror_lower(hipStream_t s, double* A, int64_t ld, int64_t np);
 void launch_scale_columns(hipStream_t s, const double* A, const double* sc, double* G, int64_t ld,
                           int64_t np);
@@ -291,7 +299,11 @@ void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64
                   const BatchShape& bs = BatchShape());
 // backward substitution  L^T a = v : the solution goes to `out` (no aliasing; `r` is only read)
 void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                   const double* invD, const double* r, double* out, int* err = nullptr);
+                   const double* invD, const double* r, double* out, int* err = nullptr,
+                   const BatchShape& bs = BatchShape());
+// lockstep batch: Q_z <- L_z^-T (np <= 4096), every launch carries the batch
+void trsm_identity_batched(hipStream_t s, const double* L, int64_t np, int64_t ld, const double* invD, double* Q,
+                           const BatchShape& bs);
 // inverses of the 512-wide diagonal blocks of L from the 128-wide ones: inv2 (slots of 512 x 512, ld 512),
 // tmp: slots of 256 x 256
 constexpr int GPMI_OB = 512;
@@ -303,7 +315,7 @@ void build_inv2(hipStream_t s, const double* L, int64_t np, int64_t ld, const do
 void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
                        const double* inv2, double* Q, int64_t mp, bool upper_rhs, double* Qout,
                        double* panel);
-void launch_set_identity(hipStream_t s, double* Q, int64_t ld, int64_t np);
+void launch_set_identity(hipStream_t s, double* Q, int64_t ld, int64_t np, int batch = 1, int64_t sMat = 0);
 // device-to-device vector copy as a kernel (a runtime D2D memcpy stalled the stream for tens of ms)
 void launch_copy(hipStream_t s, const double* src, double* dst, int64_t n);
 // r = y - mu (padded with zeros)

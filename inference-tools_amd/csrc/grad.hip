@@ -30,12 +30,35 @@ __device__ inline double block_sum(double v, double* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// batch (blockIdx.z, lockstep evaluations of gpmi_lml_grad_batch): problem z takes pdev[z], iK + z sK, u / v + z sV,
+// ws + z sW
+__device__ __forceinline__ void lml_grad_body(const KParams& p, int n_theta, const double* __restrict__ x, int64_t n,
+                                              const double* __restrict__ iK, int64_t ld,
+                                              const double* __restrict__ uvec, const double* __restrict__ vvec,
+                                              double* __restrict__ ws);
+
 __global__ __launch_bounds__(256) void lml_grad_kernel(KParams p, int n_theta,
                                                        const double* __restrict__ x, int64_t n,
                                                        const double* __restrict__ iK, int64_t ld,
                                                        const double* __restrict__ uvec,
                                                        const double* __restrict__ vvec,
                                                        double* __restrict__ ws) {
+  lml_grad_body(p, n_theta, x, n, iK, ld, uvec, vvec, ws);
+}
+
+__global__ __launch_bounds__(256) void lml_grad_batched_kernel(const KParams* __restrict__ pdev, int n_theta,
+                                                               const double* __restrict__ x, int64_t n,
+                                                               const double* __restrict__ iK, int64_t ld,
+                                                               const double* __restrict__ uvec, double* __restrict__ ws,
+                                                               int64_t sK, int64_t sV, int64_t sW) {
+  const int64_t z = blockIdx.z;
+  lml_grad_body(pdev[z], n_theta, x, n, iK + z * sK, ld, uvec + z * sV, uvec + z * sV, ws + z * sW);
+}
+
+__device__ __forceinline__ void lml_grad_body(const KParams& p, int n_theta, const double* __restrict__ x, int64_t n,
+                                              const double* __restrict__ iK, int64_t ld,
+                                              const double* __restrict__ uvec, const double* __restrict__ vvec,
+                                              double* __restrict__ ws) {
   const int ti = blockIdx.y, tj = blockIdx.x;
   if (tj > ti) return;
   __shared__ double su[GPMI_MAX_D * KT];
@@ -129,9 +152,11 @@ __global__ __launch_bounds__(256) void lml_grad_kernel(KParams p, int n_theta,
 // out[j] = sum over tiles of ws[tile][j], fixed order: thread-strided partial sums, then a tree
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restrict__ ws,
                                                           int64_t ntiles, int width,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, int64_t sW) {
   __shared__ double red[4];
   const int j = blockIdx.x;
+  ws += (int64_t)blockIdx.z * sW;        // batch: partials of problem z, results at out + z * width
+  out += (int64_t)blockIdx.z * width;
   double acc = 0.0;
   for (int64_t t = threadIdx.x; t < ntiles; t += 256) acc += ws[t * width + j];
   const double v = block_sum(acc, red);
@@ -210,5 +235,17 @@ void launch_lml_grad(hipStream_t s, const KParams& p, int n_theta, const double*
   dim3 grid((unsigned)t, (unsigned)t);
   hipLaunchKernelGGL(lml_grad_kernel, grid, dim3(256), 0, s, p, n_theta, x, n, iK, ld, u, v, ws);
   hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(n_theta + 1)), dim3(256), 0, s, ws,
-                     t * (t + 1) / 2, n_theta + 1, out);
+                     t * (t + 1) / 2, n_theta + 1, out, (int64_t)0);
+}
+
+// B lockstep evaluations: out[z * (n_theta + 1) ..] = gradient and trace of problem z (u = v = alpha_z)
+void launch_lml_grad_batched(hipStream_t s, const KParams* pdev, int batch, int n_theta, const double* x, int64_t n,
+                             int64_t np, const double* iK, int64_t ld, int64_t sK, const double* alpha, int64_t sV,
+                             double* ws, double* out) {
+  const int64_t t = np / KT;
+  const int64_t sW = grad_ws_doubles(np, n_theta);
+  dim3 grid((unsigned)t, (unsigned)t, (unsigned)batch);
+  hipLaunchKernelGGL(lml_grad_batched_kernel, grid, dim3(256), 0, s, pdev, n_theta, x, n, iK, ld, alpha, ws, sK, sV, sW);
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(n_theta + 1), 1, (unsigned)batch), dim3(256), 0, s, ws,
+                     t * (t + 1) / 2, n_theta + 1, out, sW);
 }

@@ -164,8 +164,14 @@ __global__ __launch_bounds__(FLOW_THREADS) void trsv_fwd_flow_kernel(
 // persist across blocks and the eight waves are folded once through LDS.
 __global__ __launch_bounds__(FLOW_THREADS) void trsv_bwd_flow_kernel(
     const double* __restrict__ L, int64_t ld, const double* __restrict__ invD,
-    const double* __restrict__ w, double* __restrict__ a, int* __restrict__ err, int nt) {
+    const double* __restrict__ w, double* __restrict__ a, int* __restrict__ err, int nt, int64_t sMat,
+    int64_t sInv, int64_t sVec) {
   const int k = nt - 1 - (int)blockIdx.x;
+  L += (int64_t)blockIdx.z * sMat;  // batch (lockstep evaluations)
+  invD += (int64_t)blockIdx.z * sInv;
+  w += (int64_t)blockIdx.z * sVec;
+  a += (int64_t)blockIdx.z * sVec;
+  if (err) err += blockIdx.z;
   invD += (int64_t)k * NB * NB;
   __shared__ double part[8][NB];
   __shared__ double u[NB];
@@ -259,9 +265,10 @@ __global__ void copy_panel_kernel(const double* __restrict__ src, int64_t lds, d
   *reinterpret_cast<d2_t*>(dst + r * ldd + c) = *reinterpret_cast<const d2_t*>(src + r * lds + c);
 }
 
-__global__ void set_identity_kernel(double* __restrict__ Q, int64_t ld, int64_t np) {
+__global__ void set_identity_kernel(double* __restrict__ Q, int64_t ld, int64_t np, int64_t sMat) {
   const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
   const int64_t i = blockIdx.y;
+  Q += (int64_t)blockIdx.z * sMat;
   if (j < np)
     *reinterpret_cast<d2_t*>(Q + i * ld + j) = d2_t{j == i ? 1.0 : 0.0, j + 1 == i ? 1.0 : 0.0};
 }
@@ -409,13 +416,14 @@ void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64
 }
 
 void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                   const double* invD, const double* r, double* out, int* err) {
+                   const double* invD, const double* r, double* out, int* err, const BatchShape& bs) {
   const int nt = (int)(np / NB);
   flow_gate_enter(c, s, (int64_t)nt);
   ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)np * np, 4.0 * np * np);
-  hipLaunchKernelGGL(flow_fill_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, out, np, (int64_t)0);
-  hipLaunchKernelGGL(trsv_bwd_flow_kernel, dim3((unsigned)nt), dim3(FLOW_THREADS), 0, s, L, ld, invD, r, out, err,
-                     nt);
+  hipLaunchKernelGGL(flow_fill_kernel, dim3((unsigned)((np + 255) / 256), 1, (unsigned)bs.count), dim3(256), 0, s, out,
+                     np, bs.sVec);
+  hipLaunchKernelGGL(trsv_bwd_flow_kernel, dim3((unsigned)nt, 1, (unsigned)bs.count), dim3(FLOW_THREADS), 0, s, L, ld,
+                     invD, r, out, err, nt, bs.sMat, bs.sInv, bs.sVec);
   flow_gate_leave(c, s, (int64_t)nt);
 }
 
@@ -507,9 +515,41 @@ void trsm_rows_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np,
   }
 }
 
-void launch_set_identity(hipStream_t s, double* Q, int64_t ld, int64_t np) {
-  dim3 grid((unsigned)((np / 2 + 255) / 256), (unsigned)np);
-  hipLaunchKernelGGL(set_identity_kernel, grid, dim3(256), 0, s, Q, ld, np);
+void launch_set_identity(hipStream_t s, double* Q, int64_t ld, int64_t np, int batch, int64_t sMat) {
+  dim3 grid((unsigned)((np / 2 + 255) / 256), (unsigned)np, (unsigned)batch);
+  hipLaunchKernelGGL(set_identity_kernel, grid, dim3(256), 0, s, Q, ld, np, sMat);
+}
+
+// B lockstep problems (np <= 4096): Q_z <- L_z^-T, rows = columns of L_z^-1 (Q_z starts as the identity), by forward
+// substitution over the 128-blocks with the inverses of the diagonal blocks - two-level like potrf_lower_batched: inside
+// an outer panel of 4 tile columns the K = 128 steps touch the panel's own columns only, the columns to its right take
+// the panel at once with K = 512.  Q is upper triangular throughout (row r has non-zeros from column r on), so block
+// row t only joins at its own panel.  Every launch carries the whole batch (blockIdx.z).
+void trsm_identity_batched(hipStream_t s, const double* L, int64_t np, int64_t ld, const double* invD, double* Q,
+                           const BatchShape& bs) {
+  const int nt = (int)(np / NB);
+  const int OBT = 4;
+  launch_set_identity(s, Q, ld, np, bs.count, bs.sMat);
+  const GemmBatch inplace{bs.count, bs.sMat, bs.sMat, bs.sInv};
+  const GemmBatch upd{bs.count, bs.sMat, bs.sMat, bs.sMat};
+  for (int J = 0; J < nt; J += OBT) {
+    const int Je = (J + OBT < nt) ? J + OBT : nt;
+    for (int j = J; j < Je; ++j) {
+      const int rows = j + 1;  // block rows 0 .. j have entries in column block j
+      double* Qj = Q + (int64_t)j * NB;
+      // Q[:, j] <- Q[:, j] invD_j^T   (in place, one tile column)
+      launch_gemm_nt(s, TILES_RECT, OP_ASSIGN, Qj, ld, Qj, ld, invD + (int64_t)j * NB * NB, NB, rows, 1, NB, nullptr,
+                     inplace);
+      const int pc = Je - j - 1;
+      if (pc > 0)  // Q[:, j+1 .. Je) -= Q[:, j] L[j+1 .. Je, j]^T
+        launch_gemm_nt(s, TILES_RECT, OP_SUB, Qj + NB, ld, Qj, ld, L + (int64_t)(j + 1) * NB * ld + (int64_t)j * NB, ld,
+                       rows, pc, NB, nullptr, upd);
+    }
+    const int rest = nt - Je;
+    if (rest > 0)  // Q[:, Je ..) -= Q[:, J .. Je) L[Je .., J .. Je)^T
+      launch_gemm_nt(s, TILES_RECT, OP_SUB, Q + (int64_t)Je * NB, ld, Q + (int64_t)J * NB, ld,
+                     L + (int64_t)Je * NB * ld + (int64_t)J * NB, ld, Je, rest, (Je - J) * NB, nullptr, upd);
+  }
 }
 
 void launch_copy(hipStream_t s, const double* src, double* dst, int64_t n) {

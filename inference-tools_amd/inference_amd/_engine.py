@@ -165,6 +165,21 @@ class GpEngine:
                     C.byref(lml), dptr(grad), C.byref(trq), dptr(alpha), C.byref(info))
         return lml.value, grad, trq.value, alpha, info.value
 
+    def lml_grad_batch(self, kernel, thetas_cov, extra_diag, mus=None, mu_const=None):
+        """T evaluations of `lml_grad` in one call (gpmi_lml_grad_batch: lockstep for padded N <= 4096):
+        (lml (T,), grad (T, n_theta), trace_q (T,), alpha (T, n), info (T,))."""
+        th = as_f64(np.atleast_2d(thetas_cov))
+        T, nth = th.shape
+        ex = as_f64(np.broadcast_to(np.asarray(extra_diag, dtype=float), (T,)))
+        lml, trq = np.empty(T), np.empty(T)
+        grad, alpha = np.empty((T, nth)), np.empty((T, self.n))
+        info = np.zeros(T, dtype=np.int32)
+        mus_p = dptr(as_f64(mus)) if mus is not None else None
+        muc_p = dptr(as_f64(np.broadcast_to(np.asarray(mu_const, dtype=float), (T,)))) if mus is None else None
+        self.h.call("gpmi_lml_grad_batch", kernel, T, dptr(th), nth, dptr(ex), mus_p, muc_p, dptr(lml), dptr(grad),
+                    dptr(trq), dptr(alpha), info.ctypes.data_as(C.POINTER(C.c_int)))
+        return lml, grad, trq, alpha, info
+
     # -- prediction -------------------------------------------------------------------
     def predict(self, pts, want_var=True):
         p = as_f64(pts)

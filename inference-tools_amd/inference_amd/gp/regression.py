@@ -557,6 +557,35 @@ class GpRegressor:
         grad[self.cov_slice] = g_cov
         return lml, grad
 
+    def marginal_likelihood_gradient_batch(self, thetas: ndarray):
+        """(extension) `marginal_likelihood_gradient` for T hyper-parameter vectors in one device call
+        (gpmi_lml_grad_batch: for N <= 4096 the evaluations advance in lockstep, every launch carrying all of them):
+        returns (lml (T,), grad (T, P)).  What the lockstep multi-start search evaluates per round."""
+        thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
+        if self._generic or self._het_slice is not None or self._mix is not None:  # per-point terms: one at a time
+            res = [self.marginal_likelihood_gradient(t) for t in thetas]
+            return np.array([r[0] for r in res]), np.array([r[1] for r in res])
+        split = [self._split_cov_theta(t[self.cov_slice]) for t in thetas]
+        th = np.array([s_[0] for s_ in split])
+        ex = np.array([s_[1] for s_ in split])
+        means = [self.mean.mean_and_gradients(t[self.mean_slice]) for t in thetas]
+        if isinstance(self.mean, ConstantMean):
+            lml, g_stat, trace_q, alpha, info = self.engine.lml_grad_batch(self._kernel_id, th, ex, mu_const=thetas[:, 0])
+        else:
+            lml, g_stat, trace_q, alpha, info = self.engine.lml_grad_batch(self._kernel_id, th, ex,
+                                                                            mus=np.array([m[0] for m in means]))
+        if (info != 0).any():
+            raise LinAlgError("Matrix is not positive definite")  # regression.py:555 has no guard
+        grads = zeros((len(thetas), self.n_hyperpars))
+        for t in range(len(thetas)):
+            grads[t, self.mean_slice] = array([(alpha[t] * dmu).sum() for dmu in means[t][1]])
+            g_cov = zeros(self.cov.n_params)
+            g_cov[self._stat_slice] = g_stat[t]
+            if self._wn_index is not None:
+                g_cov[self._wn_index] = ex[t] * trace_q[t]
+            grads[t, self.cov_slice] = g_cov
+        return lml, grads
+
     def _mixture_gradient(self, theta_cp, extra, mu):
         """LML gradient with respect to a ChangePoint block (covariance.py:561-594): the sub-kernels' parameters
         from the device contraction on the weight-scaled inverse, the window parameters from the device row
@@ -761,8 +790,30 @@ class GpRegressor:
             if sharding.world()[1] > 1:
                 thetas, fvals = sharding.multistart_sweep(self, array(starting_positions))
                 return thetas[int(np.argsort(fvals, kind="stable")[0])]
-        results = [self.launch_bfgs(x0) for x0 in starting_positions]
+        if self._lockstep_search():
+            # every start advances in lockstep (gp/_lockstep.py: SciPy's own L-BFGS-B through its reverse-communication
+            # interface, iterates identical to fmin_l_bfgs_b's): one batched device evaluation of the objective and
+            # its gradient per round instead of one latency-bound call per start and iteration
+            from ._lockstep import lockstep_lbfgsb
+
+            def neg_batch(X):
+                f, g = self.marginal_likelihood_gradient_batch(X)
+                return -f, -g
+
+            results = lockstep_lbfgsb(neg_batch, array(starting_positions), self.hp_bounds)
+        else:
+            results = [self.launch_bfgs(x0) for x0 in starting_positions]
+        # (start, optimum, objective) of every run, in the order of the starts: what the search did, for inspection
+        self.search_log = [(array(x0), array(r[0]), float(r[1])) for x0, r in zip(starting_positions, results)]
         return sorted(results, key=lambda r: r[1])[0][0]
+
+    def _lockstep_search(self):
+        """The multi-start search runs in lockstep when its objective is the marginal likelihood of a kernel with a
+        fused device gradient and the problem is small enough for batched (lockstep) device evaluations; the values of
+        a start are then those of `launch_bfgs` evaluated through the same batched kernels (`batch_independent_values`)."""
+        return (self.model_selector_gradient == self.marginal_likelihood_gradient and not self._generic
+                and self._mix is None and self._het_slice is None and self._y_cov is None
+                and self.engine.capacity() <= 4096)
 
     def __str__(self):
         pad = max(len(label) for label in self.hyperpar_labels) + 2

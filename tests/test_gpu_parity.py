@@ -506,6 +506,49 @@ def test_batched_lockstep_equals_single_evaluations(gp_mod):
     check(np.delete(vals, 3), np.delete(single[:6], 3), 1e-12)
 
 
+@pytest.mark.parametrize("kid,wn,mean", [(wl.SE, False, "const"), (wl.RQ, True, "const"), (wl.SE, False, "linear")])
+def test_batched_gradient_equals_single_evaluations(gp_mod, kid, wn, mean):
+    """gpmi_lml_grad_batch (lockstep: K-build, factorisation, both sweeps, L^-T, the k-skipped SYRK and the fused
+    contraction all carry the batch in blockIdx.z) against one-at-a-time `marginal_likelihood_gradient` calls: value,
+    every gradient component (mean, amplitude, shape, length scales, WhiteNoise), ragged batch sizes; and the multi-start
+    search driven in lockstep off it finds the optimum of the serial search."""
+    n, d = 700, 3
+    x, y, e = wl.synthetic_dataset(21, n, d)
+    cov = kernel_cls(gp_mod, kid)()
+    if wn:
+        cov = cov + gp_mod.WhiteNoise()
+    kw = dict(kernel=cov)
+    if mean == "linear":
+        kw["mean"] = gp_mod.LinearMean
+    base = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=None, n_starts=1, **kw) if False else None
+    thetas = wl.theta_set(kid, y, d, 9)
+    if wn:
+        thetas = np.hstack([thetas, np.linspace(-3.0, -1.0, len(thetas))[:, None]])
+    if mean == "linear":
+        rng = np.random.default_rng(4)
+        thetas = np.hstack([thetas[:, :1], 0.2 * rng.standard_normal((len(thetas), d)), thetas[:, 1:]])
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=thetas[0], **kw)
+    single = [gp.marginal_likelihood_gradient(t) for t in thetas]
+    for b in (9, 4, 1):
+        f, g = gp.marginal_likelihood_gradient_batch(thetas[:b])
+        check(f, [r[0] for r in single[:b]], 1e-12, f"LML, batch of {b}")
+        for k in range(b):
+            check_each(g[k], single[k][1], 1e-11, what=f"gradient, batch of {b}")
+    if kid == wl.SE and mean == "const":
+        np.random.seed(5)
+        a = gp_mod.GpRegressor(x, y, y_err=e, n_starts=4, **kw)  # lockstep search
+        assert a._lockstep_search()
+        np.random.seed(5)
+        starts_ref = gp_mod.GpRegressor.__new__(gp_mod.GpRegressor)
+        b_ = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=thetas[0], **kw)
+        np.random.seed(5)
+        lwr, upr = [np.array([k[i] for k in b_.hp_bounds]) for i in (0, 1)]
+        starts = [lwr + (upr - lwr) * np.random.random(size=len(b_.hp_bounds)) for _ in range(3)] + [0.5 * (lwr + upr)]
+        serial = sorted((b_.launch_bfgs(s0) for s0 in starts), key=lambda r: r[1])[0]
+        check(a.marginal_likelihood(a.hyperpars), -serial[1], 1e-9, "LML at the optimum: lockstep vs serial search")
+        check(a.hyperpars, serial[0], 1e-6, "theta*: lockstep vs serial search")
+
+
 def test_rccl_gather_single_rank(gp_mod):
     """gpmi_comm_* with world = 1 (the only RCCL configuration a 1-GPU box offers): unique id,
     communicator, all-gather through the library's own stream."""
@@ -955,20 +998,9 @@ def test_multistart_bfgs_reproduces_reference_search(golden, gp_mod, tag, kw):
     kw = dict(kw)
     if kw.get("kernel") == "rq":
         kw["kernel"] = gp_mod.RationalQuadratic
-    log = []
-    orig = gp_mod.GpRegressor.launch_bfgs
-
-    def spy(self, x0):
-        res = orig(self, x0)
-        log.append((np.array(x0), np.array(res[0]), float(res[1])))
-        return res
-
-    gp_mod.GpRegressor.launch_bfgs = spy
-    try:
-        np.random.seed(3)
-        gp = gp_mod.GpRegressor(x, y, y_err=e, optimizer="bfgs", n_starts=4, **kw)
-    finally:
-        gp_mod.GpRegressor.launch_bfgs = orig
+    np.random.seed(3)
+    gp = gp_mod.GpRegressor(x, y, y_err=e, optimizer="bfgs", n_starts=4, **kw)
+    log = gp.search_log  # (start, optimum, objective) per run; the LML search advances its runs in lockstep (round 3)
     check(np.array(gp.hp_bounds, dtype=float), g[f"ms_{tag}_bounds"], 1e-12, "bounds")
     # same random numbers in the same order; the bounds they scale come from the O(N log N) identity (1e-15 apart)
     check(np.array([l[0] for l in log]), g[f"ms_{tag}_starts"], 1e-13, "start positions")

@@ -1,0 +1,27 @@
+"""Constructor-with-search time (multi-start L-BFGS-B over the hyper-parameters, regression.py:585-605) for BASELINE
+configs 1 and 4, lockstep (one batched gradient evaluation per round for all starts) against one start after another.
+usage: python tools/search_time.py"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "inference-tools_amd")]
+import numpy as np
+import workloads as wl
+from inference_amd.gp import GpRegressor
+
+out = []
+for cfg, n, d in ((1, 512, 2), (5, 2048, 4), (4, 4096, 4)):
+    x, y, e = wl.synthetic_dataset(cfg, n, d)
+    row = {"config": cfg, "N": n, "d": d}
+    GpRegressor(x, y, y_err=e, hyperpars=wl.timing_theta(wl.SE, y, d)).marginal_likelihood_gradient_batch(
+        np.array([wl.timing_theta(wl.SE, y, d)] * 5))  # warm-up: library, workspaces
+    keep = GpRegressor._lockstep_search
+    for mode in ("serial", "lockstep"):
+        np.random.seed(3)
+        t0 = time.perf_counter()
+        GpRegressor._lockstep_search = (lambda self: False) if mode == "serial" else keep
+        gp = GpRegressor(x, y, y_err=e)
+        row[mode + "_seconds"] = time.perf_counter() - t0
+        row[mode + "_lml"] = float(gp.marginal_likelihood(gp.hyperpars))
+        row["starts"] = int(2 * np.sqrt(len(gp.hp_bounds))) + 1
+    out.append(row)
+print(json.dumps(out, indent=1))
