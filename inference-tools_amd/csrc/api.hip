@@ -688,28 +688,48 @@ int gpmi_lml_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int
     // small problems: all evaluations of a chunk advance in lockstep, one launch per step for the
     // whole chunk (blockIdx.z), instead of one latency-bound launch sequence per evaluation
     if (int rc = ensure_batch_ws(c, (int)(T < 256 ? (T < 2 ? 2 : T) : 256))) return rc;
-    hipStream_t s = c->lanes[1].stream;
+    // A chunk runs as TWO half-batches on two streams (the chunk's workspace split in the middle): while one half is in
+    // a latency-bound step - potrf_diag: one workgroup per matrix, 32 of 256 CUs for a half of 32 - the other half's
+    // GEMM launches fill the chip.  A value does not depend on the batch it is evaluated in (§4.3), so the split is
+    // invisible in the results.  GPMI_BATCH_SPLIT=0: one stream (A/B).
+    static const bool split_ok = [] {
+      const char* e = std::getenv("GPMI_BATCH_SPLIT");
+      return !e || std::atoi(e) != 0;
+    }();
+    const bool two = split_ok && T >= 16 && ensure_lanes(c, 3) == GPMI_OK;
     const BatchShape shape0{1, c->np * c->ld, (c->np / GPMI_NB) * GPMI_NB * GPMI_NB, 4 * c->np};
-    for (int64_t t0 = 0; t0 < T; t0 += c->bcap) {
-      const int B = (int)((T - t0 < c->bcap) ? T - t0 : c->bcap);
+    auto enqueue = [&](hipStream_t s, int64_t t_first, int off, int B) -> int {
       BatchShape bs = shape0;
       bs.count = B;
-      HIPCHK(c, hipMemcpyAsync(c->bParams, ps.data() + t0, sizeof(KParams) * B, hipMemcpyHostToDevice, s));
+      double* A = c->bA + (int64_t)off * bs.sMat;
+      double* Inv = c->bInv + (int64_t)off * bs.sInv;
+      double* Vec = c->bVec + (int64_t)off * bs.sVec;
+      double* Mu = c->bMu + (int64_t)off * (mus ? c->n : 1);
+      HIPCHK(c, hipMemcpyAsync(c->bParams + off, ps.data() + t_first, sizeof(KParams) * B, hipMemcpyHostToDevice, s));
       if (mus)
-        HIPCHK(c, hipMemcpyAsync(c->bMu, mus + t0 * c->n, sizeof(double) * B * c->n, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(Mu, mus + t_first * c->n, sizeof(double) * B * c->n, hipMemcpyHostToDevice, s));
       else
-        HIPCHK(c, hipMemcpyAsync(c->bMu, mu_const + t0, sizeof(double) * B, hipMemcpyHostToDevice, s));
-      HIPCHK(c, hipMemsetAsync(c->bInfo, 0, sizeof(int) * B, s));
-      launch_kbuild_square_batched(s, ps[0].kernel, c->bParams, B, c->x, c->n, c->np, c->noise, c->bA, c->ld, bs.sMat, (int)c->d);
-      potrf_lower_batched(c, s, c->bA, c->np, c->ld, c->bInv, c->bInfo, bs);
-      launch_residual_batched(s, c->y, mus ? c->bMu : nullptr, mus ? nullptr : c->bMu,
-                              c->bVec + 2 * c->np, c->n, c->np, bs);
-      trsv_forward(c, s, c->bA, c->np, c->ld, c->bInv, c->bVec + 2 * c->np, c->bVec, c->bInfo, bs);
-      launch_lml_reduce(s, c->bVec, c->bA, c->ld, c->np, c->bRed, bs);
+        HIPCHK(c, hipMemcpyAsync(Mu, mu_const + t_first, sizeof(double) * B, hipMemcpyHostToDevice, s));
+      HIPCHK(c, hipMemsetAsync(c->bInfo + off, 0, sizeof(int) * B, s));
+      launch_kbuild_square_batched(s, ps[0].kernel, c->bParams + off, B, c->x, c->n, c->np, c->noise, A, c->ld, bs.sMat,
+                                   (int)c->d);
+      potrf_lower_batched(c, s, A, c->np, c->ld, Inv, c->bInfo + off, bs);
+      launch_residual_batched(s, c->y, mus ? Mu : nullptr, mus ? nullptr : Mu, Vec + 2 * c->np, c->n, c->np, bs);
+      trsv_forward(c, s, A, c->np, c->ld, Inv, Vec + 2 * c->np, Vec, c->bInfo + off, bs);
+      launch_lml_reduce(s, Vec, A, c->ld, c->np, c->bRed + 2 * off, bs);
       HIPCHK(c, hipGetLastError());
-      HIPCHK(c, hipMemcpyAsync(c->h_bRed, c->bRed, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, s));
-      HIPCHK(c, hipMemcpyAsync(c->h_bInfo, c->bInfo, sizeof(int) * B, hipMemcpyDeviceToHost, s));
-      HIPCHK(c, hipStreamSynchronize(s));
+      HIPCHK(c, hipMemcpyAsync(c->h_bRed + 2 * off, c->bRed + 2 * off, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipMemcpyAsync(c->h_bInfo + off, c->bInfo + off, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+      return GPMI_OK;
+    };
+    for (int64_t t0 = 0; t0 < T; t0 += c->bcap) {
+      const int B = (int)((T - t0 < c->bcap) ? T - t0 : c->bcap);
+      const int B1 = (two && B >= 16) ? B / 2 : B;
+      if (int rc = enqueue(c->lanes[1].stream, t0, 0, B1)) return rc;
+      if (B1 < B)
+        if (int rc = enqueue(c->lanes[2].stream, t0 + B1, B1, B - B1)) return rc;
+      HIPCHK(c, hipStreamSynchronize(c->lanes[1].stream));
+      if (B1 < B) HIPCHK(c, hipStreamSynchronize(c->lanes[2].stream));
       for (int b = 0; b < B; ++b) {
         const int inf = c->h_bInfo[b];
         INFOCHK(c, inf);

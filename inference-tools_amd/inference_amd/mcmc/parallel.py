@@ -21,7 +21,7 @@ from random import choice
 from time import time
 from warnings import warn
 
-from numpy import arange, exp, identity, zeros
+from numpy import arange, array, exp, identity, zeros
 from numpy.random import default_rng
 
 from inference_amd.mcmc.gibbs import advance_lockstep
@@ -161,18 +161,106 @@ class ParallelTempering:
 
 
 def advance_ladders(ladders, n: int, swap_interval=10, batch_posterior=None):
-    """Advance several ParallelTempering ladders together: all chains of all ladders propose in
-    lockstep (one batched device evaluation per proposal round), then every ladder performs its own
-    swaps.  This is the per-GPU unit of config 5 (whole ladders per GPU, swaps GPU-local)."""
+    """Advance several ParallelTempering ladders together: the chains of all ladders propose in lockstep (one batched
+    device evaluation per proposal round), and every ladder performs its own swaps.  This is the per-GPU unit of
+    config 5 (whole ladders per GPU, swaps GPU-local).
+
+    Ladders synchronise with THEMSELVES only: a ladder whose chains have all finished a swap interval swaps at once and
+    starts its next interval while other ladders are still in theirs.  (Round 2 stopped every ladder at every swap point:
+    the rounds before it shrank to the few chains still retrying - the slowest of 64 chains needs ~1.5x the average
+    number of proposals - and a batch of one costs what a batch of twenty costs.)  A chain draws from its own
+    generators, a ladder's swaps from the ladder's, so every trajectory and every swap decision is what it would be
+    with the ladder run alone: results do not depend on how ladders are grouped or sharded.  (Ladders that still pair
+    their chains with the module-level `random.choice` of parallel.py:172 share ONE stream; for those every swap point
+    stays a common one and the swaps are made in ladder order, as before.)
+    Returns the number of posterior evaluations made."""
     bp = batch_posterior or ladders[0].batch_posterior
     if bp is None:
         raise ValueError("advance_ladders needs a batched posterior")
+    if n <= 0 or not ladders:
+        return 0
     chains = [c for lad in ladders for c in lad.chains]
-    evals = 0
-    for _ in range(n // swap_interval):
-        evals += advance_lockstep(chains, swap_interval, bp)
-        for lad in ladders:
+    owner = [k for k, lad in enumerate(ladders) for _ in lad.chains]
+    P = chains[0].n_parameters
+    # per ladder: steps of the current interval, steps left after it
+    def interval(done):
+        left = n - done
+        return swap_interval if left >= swap_interval else left
+    done = [0] * len(ladders)                 # completed steps (at interval boundaries)
+    goal = [interval(0) for _ in ladders]     # steps of the interval in progress
+    busy = [len(lad.chains) for lad in ladders]  # chains of the ladder still inside the interval
+    step = [0] * len(chains)
+    par = [0] * len(chains)
+    p_old = [c.probs[-1] for c in chains]
+    p_acc = list(p_old)
+    prop = [c.get_last() for c in chains]
+    active = list(range(len(chains)))
+    first_of = []
+    k0 = 0
+    for lad in ladders:
+        first_of.append(k0)
+        k0 += len(lad.chains)
+    def _next_interval(k):
+        """Ladder k has finished an interval: swap, and hand back the chains that start its next one."""
+        lad = ladders[k]
+        done[k] += goal[k]
+        if goal[k] == swap_interval:  # (a trailing partial interval ends without a swap, as in `advance`)
             lad.swap()
-    if n % swap_interval:
-        evals += advance_lockstep(chains, n % swap_interval, bp)
+        if done[k] >= n:
+            return []
+        goal[k] = interval(done[k])
+        busy[k] = len(lad.chains)
+        again = list(range(first_of[k], first_of[k] + len(lad.chains)))
+        for c in again:
+            step[c] = 0
+            par[c] = 0
+            p_old[c] = chains[c].probs[-1]
+            p_acc[c] = p_old[c]
+            prop[c] = chains[c].get_last()
+        return again
+
+    evals = 0
+    common = len(ladders) > 1 and any(lad.pair_choice is choice for lad in ladders)  # a shared random stream
+    held = []
+    while active or held:
+        if not active:  # common swap points: every ladder has arrived
+            finished, held = sorted(held), []
+            still = []
+            for k in finished:
+                still += _next_interval(k)
+            active = sorted(still)
+            continue
+        for c in active:
+            prop[c][par[c]] = chains[c].params[par[c]].proposal()
+        vals = bp(array([prop[c] for c in active]))
+        evals += len(active)
+        still, finished = [], []
+        for c, v in zip(active, vals):
+            chain = chains[c]
+            p_new = float(v) * chain.inv_temp
+            if chain._mh_test(chain.params[par[c]], p_new, p_old[c]):
+                p_old[c] = p_new
+                p_acc[c] = p_new
+                par[c] += 1
+                if par[c] == P:
+                    chain._commit(prop[c], p_acc[c])
+                    step[c] += 1
+                    par[c] = 0
+                    if step[c] < goal[owner[c]]:
+                        p_old[c] = chain.probs[-1]
+                        p_acc[c] = p_old[c]
+                        prop[c] = chain.get_last()
+            if step[c] < goal[owner[c]]:
+                still.append(c)
+            else:
+                busy[owner[c]] -= 1
+                if busy[owner[c]] == 0:
+                    finished.append(owner[c])
+        if common:
+            held += finished
+        else:
+            for k in finished:  # the ladder's interval is complete: swap, then on to its next interval
+                still += _next_interval(k)
+        still.sort()  # a fixed order of the batch rows (values do not depend on it; the order of host work does)
+        active = still
     return evals
