@@ -321,6 +321,13 @@ int gpmi_timer_start(gpmi_ctx* ctx);
 int gpmi_timer_stop(gpmi_ctx* ctx, float* ms);
 /* per-kernel-class accounting: when enabled every launch of the class is bracketed by events; the two
  * trailing-update classes (SYRK, SYRK_REST, SYRK_SLICE) are timed by in-kernel stamps instead and cost nothing */
+/* Host-only (no device call): the task lists of the flag-ordered factorisation of a tail of `m` tile rows dealt to `nwg`
+ * workgroups (csrc/potrf_flow.hip; replaces nothing in the reference - it is the schedule of numpy.linalg.cholesky's
+ * replacement, regression.py:241).  out: 8 ints per task {type (0 panel TRSM slab, 1 one-column update of a 64 x 64
+ * sub-tile, 2 K = 512 chunk), i, j, k, s, flag increment, owner workgroup, 0}, list after list; out == NULL: only the
+ * count.  tests/test_flow_cpu.py replays them with NumPy tile operations. */
+int gpmi_flow_task_lists(int m, int nwg, int64_t cap, int32_t* out, int64_t* ntasks);
+
 #define GPMI_PROF_KBUILD 0  /* covariance build            (HBM-write bound) */
 #define GPMI_PROF_SYRK 1    /* potrf trailing SYRK/GEMM    (fp64 MFMA bound) */
 #define GPMI_PROF_PANEL 2   /* potrf diagonal block + panel TRSM (latency bound) */

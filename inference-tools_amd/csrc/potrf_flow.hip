@@ -419,6 +419,30 @@ FlowLists flow_build(int m, int nwg) {
 
 }  // namespace
 
+// Host-only view of the task lists (no device call): what tests/test_flow_cpu.py replays with NumPy tile operations.
+// out: 8 ints per task {type (0 T, 1 U, 2 Z), i, j, k (column, or outer panel for Z), s, fadd, owner, 0}, list after list.
+extern "C" int gpmi_flow_task_lists(int m, int nwg, int64_t cap, int32_t* out, int64_t* ntasks) {
+  if (m < 1 || nwg < 1 || !ntasks) return GPMI_ERR_ARG;
+  const FlowLists fl = flow_build(m, nwg);
+  *ntasks = (int64_t)fl.tasks.size();
+  if (!out) return GPMI_OK;
+  if (cap < *ntasks) return GPMI_ERR_ARG;
+  for (int w = 0; w < nwg; ++w)
+    for (int n = fl.off[(size_t)w]; n < fl.off[(size_t)w + 1]; ++n) {
+      const FlowTask& t = fl.tasks[(size_t)n];
+      int32_t* o = out + 8 * (int64_t)n;
+      o[0] = t.type;
+      o[1] = t.i;
+      o[2] = t.j;
+      o[3] = t.k;
+      o[4] = t.s;
+      o[5] = t.fadd;
+      o[6] = w;
+      o[7] = 0;
+    }
+  return GPMI_OK;
+}
+
 bool ensure_masked_pair(gpmi_ctx* c, Lane& L, int k);  // api.hip
 
 // One flag-ordered factorisation per device at a time, process-wide: a workgroup of the task kernel may wait for a task

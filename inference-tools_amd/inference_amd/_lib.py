@@ -52,6 +52,7 @@ SIGNATURES = {
     "gpmi_set_streams": (C.c_int, [_vp, C.c_int]),
     "gpmi_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
     "gpmi_lml_grad": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_flow_task_lists": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "gpmi_lml_grad_batch": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_predict": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
     "gpmi_posterior": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
