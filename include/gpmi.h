@@ -101,6 +101,17 @@ int gpmi_lml(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_theta, d
 int gpmi_lml_batch(gpmi_ctx* ctx, int kernel, int64_t T, const double* thetas_host, int n_theta,
                    const double* extra_diag_host, const double* mus_host,
                    const double* mu_const_host, double* lml_host, int* info_host);
+/* Asynchronous form of gpmi_lml_batch for the lockstep sizes (n <= 4096, diagonal data errors): submit enqueues the T
+ * (<= 128) evaluations of slot 0 or 1 and returns at once, wait blocks until they are through and delivers lml[T] /
+ * info[T] in the order submitted.  The two slots are the two halves of the lockstep workspace and run side by side; a
+ * value is bit-identical to what gpmi_lml_batch returns for the same hyper-parameters.  What it is for: a tempering
+ * driver (mcmc/parallel.py:190-231 in the reference: one process per chain, results over pipes) splits its ladders
+ * in two groups and does the accept / reject bookkeeping of one group while the device evaluates the other.
+ * While a slot is pending, gpmi_lml_batch / gpmi_lml_grad_batch on the same handle are refused (GPMI_ERR_ARG). */
+int gpmi_lml_batch_submit(gpmi_ctx* ctx, int kernel, int64_t T, const double* thetas_host, int n_theta,
+                          const double* extra_diag, const double* mus_host, const double* mu_const, int slot);
+int gpmi_lml_batch_wait(gpmi_ctx* ctx, int slot, double* lml, int* info);
+
 /* number of concurrent worker streams (each with its own n x n scratch) used by gpmi_lml_batch */
 int gpmi_set_streams(gpmi_ctx* ctx, int n_streams);
 /* Handle options.

@@ -224,6 +224,12 @@ void free_data(gpmi_ctx* c) {
   c->h_bRed = nullptr;
   if (c->h_bInfo) (void)hipHostFree(c->h_bInfo);
   c->h_bInfo = nullptr;
+  for (int k = 0; k < 2; ++k) {
+    if (c->h_bStage[k]) (void)hipHostFree(c->h_bStage[k]);
+    c->h_bStage[k] = nullptr;
+    c->h_bStage_bytes[k] = 0;
+    c->bpend[k] = 0;
+  }
   c->bcap = 0;
   c->mq_cap = 0;
   c->fitted = false;
@@ -364,6 +370,8 @@ int ensure_batch_ws(gpmi_ctx* c, int want) {
   if (cap < 1) cap = 1;
   if (want > cap) want = cap;
   if (want <= c->bcap) return GPMI_OK;
+  ARGCHK(c, c->bpend[0] == 0 && c->bpend[1] == 0,
+         "the batch workspace cannot grow while an asynchronous batch is pending (gpmi_lml_batch_wait first)");
   auto fr = [](double*& p) {
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -687,6 +695,8 @@ int gpmi_lml_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int
   if ((T >= 2 || c->lockstep_always) && c->np <= 4096 && !c->ycov) {
     // small problems: all evaluations of a chunk advance in lockstep, one launch per step for the
     // whole chunk (blockIdx.z), instead of one latency-bound launch sequence per evaluation
+    ARGCHK(c, c->bpend[0] == 0 && c->bpend[1] == 0,
+           "gpmi_lml_batch: an asynchronous batch is pending on this handle (gpmi_lml_batch_wait first)");
     if (int rc = ensure_batch_ws(c, (int)(T < 256 ? (T < 2 ? 2 : T) : 256))) return rc;
     // A chunk runs as TWO half-batches on two streams (the chunk's workspace split in the middle): while one half is in
     // a latency-bound step - potrf_diag: one workgroup per matrix, 32 of 256 CUs for a half of 32 - the other half's
@@ -778,6 +788,85 @@ int gpmi_lml_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int
   return GPMI_OK;
 }
 
+// Asynchronous lockstep batches: gpmi_lml_batch_submit enqueues the T evaluations of a slot and returns; the caller does
+// its own work (a tempering driver: the accept / reject bookkeeping of the OTHER half of its chains) and collects the
+// values with gpmi_lml_batch_wait.  Two slots, the two halves of the lockstep workspace, on two streams - the same
+// device work as one gpmi_lml_batch call of both halves (which runs them as two half-batches side by side), so a value
+// is bit-identical either way.  Lockstep sizes only (np <= 4096, no dense y covariance).
+int gpmi_lml_batch_submit(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int n_theta, const double* extra,
+                          const double* mus, const double* mu_const, int slot) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, slot == 0 || slot == 1, "slot must be 0 or 1");
+  ARGCHK(c, T >= 1 && T <= 128, "T out of range (1 .. 128 per slot)");
+  ARGCHK(c, thetas, "thetas is NULL");
+  ARGCHK(c, mus || mu_const, "one of mus / mu_const is required");
+  ARGCHK(c, c->np <= 4096 && !c->ycov, "asynchronous batches: lockstep sizes only (n <= 4096, diagonal data errors)");
+  ARGCHK(c, c->bpend[slot] == 0, "this slot has a batch pending (gpmi_lml_batch_wait first)");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = ensure_lanes(c, 3)) return rc;
+  // each slot owns half of the workspace: at least 2 T matrices (grown only while nothing is pending)
+  if (c->bcap < 2 * T || c->bcap < 2) {
+    ARGCHK(c, c->bpend[1 - slot] == 0, "the other slot's batch was submitted with a smaller workspace: submit the larger batch first");
+    if (int rc = ensure_batch_ws(c, (int)(2 * T))) return rc;
+    ARGCHK(c, c->bcap >= 2 * T, "not enough device memory for two batches of this size");
+  }
+  const int off = slot * (c->bcap / 2);
+  // inputs through pinned staging that lives until the wait (the copies are asynchronous)
+  const int64_t mu_doubles = mus ? T * c->n : T;
+  const int64_t need = (int64_t)sizeof(KParams) * T + (int64_t)sizeof(double) * mu_doubles;
+  if (c->h_bStage_bytes[slot] < need) {
+    if (c->h_bStage[slot]) (void)hipHostFree(c->h_bStage[slot]);
+    c->h_bStage[slot] = nullptr;
+    c->h_bStage_bytes[slot] = 0;
+    HIPCHK(c, hipHostMalloc(&c->h_bStage[slot], (size_t)need));
+    c->h_bStage_bytes[slot] = need;
+  }
+  KParams* ps = reinterpret_cast<KParams*>(c->h_bStage[slot]);
+  double* mu_stage = reinterpret_cast<double*>(c->h_bStage[slot] + sizeof(KParams) * T);
+  for (int64_t t = 0; t < T; ++t)
+    if (int rc = make_params(c, kernel, thetas + t * n_theta, n_theta, extra ? extra[t] : 0.0, ps[t])) return rc;
+  std::memcpy(mu_stage, mus ? mus : mu_const, sizeof(double) * mu_doubles);
+  hipStream_t s = c->lanes[1 + slot].stream;
+  BatchShape bs{(int)T, c->np * c->ld, (c->np / GPMI_NB) * GPMI_NB * GPMI_NB, 4 * c->np};
+  double* A = c->bA + (int64_t)off * bs.sMat;
+  double* Inv = c->bInv + (int64_t)off * bs.sInv;
+  double* Vec = c->bVec + (int64_t)off * bs.sVec;
+  double* Mu = c->bMu + (int64_t)off * (mus ? c->n : 1);
+  HIPCHK(c, hipMemcpyAsync(c->bParams + off, ps, sizeof(KParams) * T, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(Mu, mu_stage, sizeof(double) * mu_doubles, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemsetAsync(c->bInfo + off, 0, sizeof(int) * T, s));
+  launch_kbuild_square_batched(s, ps[0].kernel, c->bParams + off, (int)T, c->x, c->n, c->np, c->noise, A, c->ld, bs.sMat,
+                               (int)c->d);
+  potrf_lower_batched(c, s, A, c->np, c->ld, Inv, c->bInfo + off, bs);
+  launch_residual_batched(s, c->y, mus ? Mu : nullptr, mus ? nullptr : Mu, Vec + 2 * c->np, c->n, c->np, bs);
+  trsv_forward(c, s, A, c->np, c->ld, Inv, Vec + 2 * c->np, Vec, c->bInfo + off, bs);
+  launch_lml_reduce(s, Vec, A, c->ld, c->np, c->bRed + 2 * off, bs);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_bRed + 2 * off, c->bRed + 2 * off, sizeof(double) * 2 * T, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(c->h_bInfo + off, c->bInfo + off, sizeof(int) * T, hipMemcpyDeviceToHost, s));
+  c->bpend[slot] = (int)T;
+  return GPMI_OK;
+}
+
+int gpmi_lml_batch_wait(gpmi_ctx* c, int slot, double* lml, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, slot == 0 || slot == 1, "slot must be 0 or 1");
+  ARGCHK(c, c->bpend[slot] > 0, "nothing pending in this slot");
+  ARGCHK(c, lml, "lml is NULL");
+  if (int rc = set_device(c)) return rc;
+  const int T = c->bpend[slot];
+  const int off = slot * (c->bcap / 2);
+  c->bpend[slot] = 0;  // whatever happens below, the slot is free again
+  HIPCHK(c, hipStreamSynchronize(c->lanes[1 + slot].stream));
+  for (int b = 0; b < T; ++b) {
+    const int inf = c->h_bInfo[off + b];
+    INFOCHK(c, inf);
+    lml[b] = (inf == 0) ? (-0.5 * c->h_bRed[2 * (off + b)] - c->h_bRed[2 * (off + b) + 1]) : -1e50;
+    if (info) info[b] = inf;
+  }
+  return GPMI_OK;
+}
+
 int gpmi_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,
                   const double* mu, double* lml, double* grad_theta, double* trace_q,
                   double* alpha_out, int* info) {
@@ -856,6 +945,8 @@ int gpmi_lml_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas
     if (int rc = make_params(c, kernel, thetas + t * n_theta, n_theta, extra ? extra[t] : 0.0, ps[(size_t)t])) return rc;
   // lockstep: every launch carries the chunk in blockIdx.z - K-build, factorisation, both sweeps, L^-T by forward
   // substitution on the identity, the k-skipped SYRK K^-1 = L^-T L^-1 (regression.py:556-557) and the fused contraction
+  ARGCHK(c, c->bpend[0] == 0 && c->bpend[1] == 0,
+         "gpmi_lml_grad_batch: an asynchronous batch is pending on this handle (gpmi_lml_batch_wait first)");
   if (int rc = ensure_batch_ws(c, (int)(T < 64 ? (T < 2 ? 2 : T) : 64))) return rc;
   if (int rc = ensure_batch_grad_ws(c, c->bcap, n_theta)) return rc;
   hipStream_t s = c->lanes[1].stream;

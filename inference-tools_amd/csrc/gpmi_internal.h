@@ -130,6 +130,11 @@ struct gpmi_ctx {
   int bgrad_cap = 0, bgrad_ntheta = 0;
   int* bInfo = nullptr;
   KParams* bParams = nullptr;
+  // asynchronous lockstep batches (gpmi_lml_batch_submit / _wait): two slots = the two halves of the workspace, on the
+  // streams of lanes 1 and 2; evaluations pending per slot (0: free), pinned staging of their inputs
+  int bpend[2] = {0, 0};
+  char* h_bStage[2] = {nullptr, nullptr};
+  int64_t h_bStage_bytes[2] = {0, 0};
   double* h_bRed = nullptr;
   int* h_bInfo = nullptr;
   LinvState linv;

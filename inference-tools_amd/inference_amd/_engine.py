@@ -57,6 +57,33 @@ class GpEngine:
                     dptr(out), info.ctypes.data_as(C.POINTER(C.c_int)))
         return out, info
 
+    ASYNC_MAX = 128  # evaluations per slot of the asynchronous form (gpmi.h)
+
+    def async_slot_capacity(self):
+        """Evaluations one asynchronous slot can hold: half of the lockstep workspace (api.hip: ensure_batch_ws keeps it
+        below 256 matrices and 6 GiB)."""
+        cap = self.capacity()
+        per = cap * (cap + 32) * 8
+        return max(0, min(self.ASYNC_MAX, min(256, (6 << 30) // per) // 2))
+
+    def lml_batch_submit(self, slot, kernel, thetas_cov, extra_diag=None, mus=None, mu_const=None):
+        """gpmi_lml_batch_submit: enqueue the evaluations of `slot` (0 / 1) and return; `lml_batch_wait(slot)` delivers."""
+        thetas = as_f64(thetas_cov)
+        T, nt = thetas.shape
+        ex = None if extra_diag is None else as_f64(extra_diag)
+        mus = None if mus is None else as_f64(mus)
+        mc = None if mu_const is None else as_f64(mu_const)
+        self.h.call("gpmi_lml_batch_submit", kernel, T, dptr(thetas), nt, dptr(ex), dptr(mus), dptr(mc), int(slot))
+        self._pending = getattr(self, "_pending", {})
+        self._pending[int(slot)] = T
+
+    def lml_batch_wait(self, slot):
+        T = self._pending.pop(int(slot))
+        out = np.empty(T)
+        info = np.zeros(T, dtype=np.int32)
+        self.h.call("gpmi_lml_batch_wait", int(slot), dptr(out), info.ctypes.data_as(C.POINTER(C.c_int)))
+        return out, info
+
     # -- mixture covariance (ChangePoint): sub-kernel ids / parameter vectors + per-point weights ------------
     @staticmethod
     def _mix_args(kernels, thetas, weights):

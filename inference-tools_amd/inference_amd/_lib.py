@@ -49,6 +49,8 @@ SIGNATURES = {
     "gpmi_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _ip]),
     "gpmi_lml": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _ip]),
     "gpmi_lml_batch": (C.c_int, [_vp, C.c_int, _i64, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_lml_batch_submit": (C.c_int, [_vp, C.c_int, _i64, _dp, C.c_int, _dp, _dp, _dp, C.c_int]),
+    "gpmi_lml_batch_wait": (C.c_int, [_vp, C.c_int, _dp, _ip]),
     "gpmi_set_streams": (C.c_int, [_vp, C.c_int]),
     "gpmi_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
     "gpmi_lml_grad": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _ip]),

@@ -528,6 +528,33 @@ class GpRegressor:
             warn("Cholesky decomposition failure in marginal_likelihood")
         return vals
 
+    def async_batches(self):
+        """(extension) Can `marginal_likelihood_batch_submit` / `_wait` serve this model?  (A device kernel, a model small
+        enough for lockstep batches, diagonal data errors: the cases `gpmi_lml_batch_submit` takes.)"""
+        return (not self._generic and self._het_slice is None and self._mix is None and self._y_cov is None
+                and self.engine.capacity() <= 4096)
+
+    def marginal_likelihood_batch_submit(self, thetas: ndarray, slot: int):
+        """(extension) Start `marginal_likelihood_batch(thetas)` in slot 0 or 1 and return at once; at most
+        `engine.ASYNC_MAX` vectors per slot.  The two slots run side by side on the device: a driver with two groups of
+        chains does the bookkeeping of one group while the other group's likelihoods are being evaluated."""
+        thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
+        split = [self._split_cov_theta(t[self.cov_slice]) for t in thetas]
+        th = np.array([s[0] for s in split])
+        ex = np.array([s[1] for s in split])
+        if isinstance(self.mean, ConstantMean):
+            self.engine.lml_batch_submit(slot, self._kernel_id, th, ex, mu_const=thetas[:, 0])
+        else:
+            mus = np.array([self.mean.build_mean(t[self.mean_slice]) for t in thetas])
+            self.engine.lml_batch_submit(slot, self._kernel_id, th, ex, mus=mus)
+
+    def marginal_likelihood_batch_wait(self, slot: int) -> ndarray:
+        """(extension) The values of the batch submitted in `slot` (same values as `marginal_likelihood_batch`)."""
+        vals, info = self.engine.lml_batch_wait(slot)
+        if (info != 0).any():
+            warn("Cholesky decomposition failure in marginal_likelihood")
+        return vals
+
     def marginal_likelihood_gradient(self, theta: ndarray):
         """LML and its gradient, R&W eqs. 5.8-5.9 (regression.py:544-567)."""
         theta = np.asarray(theta, dtype=float)

@@ -16,7 +16,9 @@ together by `advance_ladders`; ladders are the unit sharded over GPUs (every swa
 stays GPU-local, nothing but the final samples is gathered).
 `swap_diagnostics` (matplotlib) is out of scope.
 """
+import os
 import sys
+from collections import deque
 from random import choice
 from time import time
 from warnings import warn
@@ -219,21 +221,8 @@ def advance_ladders(ladders, n: int, swap_interval=10, batch_posterior=None):
             prop[c] = chains[c].get_last()
         return again
 
-    evals = 0
-    common = len(ladders) > 1 and any(lad.pair_choice is choice for lad in ladders)  # a shared random stream
-    held = []
-    while active or held:
-        if not active:  # common swap points: every ladder has arrived
-            finished, held = sorted(held), []
-            still = []
-            for k in finished:
-                still += _next_interval(k)
-            active = sorted(still)
-            continue
-        for c in active:
-            prop[c][par[c]] = chains[c].params[par[c]].proposal()
-        vals = bp(array([prop[c] for c in active]))
-        evals += len(active)
+    def _settle(active, vals):
+        """The accept / reject bookkeeping of one round: returns (chains still inside their interval, ladders finished)."""
         still, finished = [], []
         for c, v in zip(active, vals):
             chain = chains[c]
@@ -256,6 +245,71 @@ def advance_ladders(ladders, n: int, swap_interval=10, batch_posterior=None):
                 busy[owner[c]] -= 1
                 if busy[owner[c]] == 0:
                     finished.append(owner[c])
+        return still, finished
+
+    evals = 0
+    common = len(ladders) > 1 and any(lad.pair_choice is choice for lad in ladders)  # a shared random stream
+    # Two (or more) groups of whole ladders, evaluated in turn through the model's two asynchronous slots: while the
+    # device works on one group's proposals the host settles the other's - the bookkeeping above is ~10 us per chain
+    # and round, a sixth of the device time of a round of 64 chains.  Ladders never interact, generators are per chain
+    # and per ladder, and a value does not depend on its batch: the trajectories are those of the one-batch loop below.
+    model = getattr(bp, "__self__", None)
+    gmax = 0
+    if (not common and len(ladders) > 1 and getattr(bp, "__name__", "") == "marginal_likelihood_batch"
+            and hasattr(model, "marginal_likelihood_batch_submit") and model.async_batches()):
+        gmax = min(getattr(model.engine, "ASYNC_MAX", 128), model.engine.async_slot_capacity())
+    if gmax >= max(len(lad.chains) for lad in ladders) and os.environ.get("GPMI_PT_ASYNC", "1") != "0":
+        groups, cur = [], []
+        per = max(len(lad.chains) for lad in ladders)
+        want = max(2, -(-len(chains) // gmax))  # groups needed
+        size = -(-len(ladders) // want)         # ladders per group
+        while size * per > gmax:
+            size -= 1
+        for k in range(len(ladders)):
+            cur.append(k)
+            if len(cur) == size:
+                groups.append(cur)
+                cur = []
+        if cur:
+            groups.append(cur)
+        act = [[c for k in g for c in range(first_of[k], first_of[k] + len(ladders[k].chains))] for g in groups]
+        ready = deque(range(len(groups)))  # groups with work, not in flight
+        flying = deque()                   # (slot, group), oldest first
+        free = [0, 1]
+        while ready or flying:
+            while ready and free:
+                g = ready.popleft()
+                for c in act[g]:
+                    prop[c][par[c]] = chains[c].params[par[c]].proposal()
+                slot = free.pop(0)
+                model.marginal_likelihood_batch_submit(array([prop[c] for c in act[g]]), slot)
+                flying.append((slot, g))
+            slot, g = flying.popleft()
+            vals = model.marginal_likelihood_batch_wait(slot)
+            free.append(slot)
+            evals += len(act[g])
+            still, finished = _settle(act[g], vals)
+            for k in finished:
+                still += _next_interval(k)
+            still.sort()
+            act[g] = still
+            if still:
+                ready.append(g)
+        return evals
+    held = []
+    while active or held:
+        if not active:  # common swap points: every ladder has arrived
+            finished, held = sorted(held), []
+            still = []
+            for k in finished:
+                still += _next_interval(k)
+            active = sorted(still)
+            continue
+        for c in active:
+            prop[c][par[c]] = chains[c].params[par[c]].proposal()
+        vals = bp(array([prop[c] for c in active]))
+        evals += len(active)
+        still, finished = _settle(active, vals)
         if common:
             held += finished
         else:

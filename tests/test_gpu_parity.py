@@ -1187,6 +1187,50 @@ def test_config5_ladders_in_lockstep_at_stated_shape(gp_mod):
     check(ch.probs[-1] / ch.inv_temp, ref.marginal_likelihood(ch.get_last()), what="LML of a chain's last position")
 
 
+def test_async_batches_match_the_synchronous_call(gp_mod, monkeypatch):
+    """gpmi_lml_batch_submit / gpmi_lml_batch_wait (two slots side by side) against gpmi_lml_batch: bit-identical
+    values, in the order submitted; a slot cannot be submitted twice, the synchronous calls are refused while a slot
+    is pending; and the tempering driver gives the same trajectories with and without the pipelined rounds."""
+    from inference_amd._lib import GpmiError
+    from inference_amd.mcmc import advance_ladders
+
+    n, d = 1024, 3
+    x, y, e = wl.synthetic_dataset(55, n, d)
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=wl.timing_theta(wl.SE, y, d))
+    gp.batch_independent_values(True)
+    assert gp.async_batches()
+    rng = np.random.default_rng(3)
+    base = wl.timing_theta(wl.SE, y, d)
+    th = base + 0.3 * rng.normal(size=(40, len(base)))
+    ref = gp.marginal_likelihood_batch(th)
+    gp.marginal_likelihood_batch_submit(th[:25], 0)
+    gp.marginal_likelihood_batch_submit(th[25:], 1)
+    with pytest.raises(GpmiError):
+        gp.marginal_likelihood_batch_submit(th[:3], 0)  # the slot is taken
+    with pytest.raises(GpmiError):
+        gp.marginal_likelihood_batch(th[:4])  # the workspace is in use
+    b = gp.marginal_likelihood_batch_wait(1)
+    a = gp.marginal_likelihood_batch_wait(0)
+    assert np.array_equal(np.concatenate([a, b]), ref)
+    with pytest.raises(GpmiError):
+        gp.engine.h.call("gpmi_lml_batch_wait", 0, None, None)  # nothing pending
+    assert np.array_equal(gp.marginal_likelihood_batch(th[:4]), ref[:4])  # and the handle is usable again
+    # the driver: pipelined rounds (two groups of ladders through the two slots) against one batch per round
+    def run(flag):
+        monkeypatch.setenv("GPMI_PT_ASYNC", flag)
+        lads = [wl.cfg5_ladder(gp, k, n_temps=4) for k in range(6)]
+        ev = advance_ladders(lads, 4, swap_interval=2)
+        return ev, lads
+    ev1, l1 = run("1")
+    ev0, l0 = run("0")
+    assert ev1 == ev0
+    for u, v in zip(l1, l0):
+        for cu, cv in zip(u.chains, v.chains):
+            assert np.array_equal(cu.get_sample(burn=0), cv.get_sample(burn=0))
+            assert np.array_equal(np.array(cu.probs), np.array(cv.probs))
+        assert np.array_equal(u.successful_swaps, v.successful_swaps)
+
+
 # ---------------------------------------------------------------------------------------
 # user-defined covariance functions through the plugin ABC (SURVEY.md section 8(b)): host builds the dense
 # matrices with the plugin's own methods, the device factorises / solves (gpmi_*_dense)
