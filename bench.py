@@ -221,7 +221,8 @@ def sharded_configs(args, wl, sharding, rank, world, local_rank, rdv, gather, en
         chains = state.shape[0] * state.shape[1]
         res["config5"] = {
             "workload": f"{n_lad} ParallelTempering ladders x {state.shape[1]} temperatures, GibbsChain over the GP log-marginal "
-                        f"likelihood (SE N={n5} d={d5}), {steps5} steps, swap interval 10, tempering_run",
+                        f"likelihood (SE N={n5} d={d5}), {steps5} steps, swap interval 10, tempering_run (ladders built inside "
+                        f"the timed call; the likelihood of their common start is evaluated once)",
             "seconds": dt, "chain_steps_per_s": chains * steps5 / dt, "lml_evals_per_s": evals / dt,
             "tflops_aggregate": evals / dt * (n5**3 / 3.0) / 1e12,
             "frac_of_aggregate_fp64_mfma_peak": evals / dt * (n5**3 / 3.0) / 1e12 / (world * PEAK_FP64_MFMA_TFLOPS),

@@ -147,10 +147,23 @@ def cfg5_ladder(gp, k: int, n_temps: int = 8, t_max: float = 100.0):
     start = np.array([0.5 * (a + b) for a, b in gp.hp_bounds])
     start[0] = gp.y.mean()
     widths = np.array([0.05 * (b - a) for a, b in gp.hp_bounds])
+    # every chain of every ladder starts at the same point, and a GibbsChain evaluates its start twice when it is built
+    # (validation + first log-probability, as the reference's does): that likelihood is computed once per model here,
+    # not 2 x 8 x n_ladders times one by one; the chains then get the model's own bound method back, which is what lets
+    # the tempering driver find the batched form
+    memo = gp.__dict__.setdefault("_cfg5_start_memo", {})
+
+    def start_posterior(theta):
+        key = np.asarray(theta, dtype=float).tobytes()
+        if key not in memo:
+            memo[key] = gp.marginal_likelihood(theta)
+        return memo[key]
+
     chains = []
     for t_i, temp in enumerate(10.0 ** np.linspace(0.0, np.log10(t_max), n_temps)):
-        ch = GibbsChain(posterior=gp.marginal_likelihood, start=start, widths=widths, temperature=float(temp),
+        ch = GibbsChain(posterior=start_posterior, start=start, widths=widths, temperature=float(temp),
                         display_progress=False)
+        ch.posterior = gp.marginal_likelihood
         for i, b in enumerate(gp.hp_bounds):
             ch.set_boundaries(i, b)
         ch.rng = default_rng(100_000 * k + 100 * t_i)
