@@ -16,7 +16,11 @@ for cfg in cfg2 cfg3 cfg4 cfg5; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$cfg -- python3 tools/config_bench.py $cfg > $out/$cfg.txt 2> $out/$cfg.err
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/lmlgrad -- python3 tools/grad_times.py 16384 > $out/lmlgrad.txt 2> $out/lmlgrad.err
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/pt -- python3 tools/config5_bench.py 10 > $out/pt.json 2> $out/pt.err
+# (the driver's rate un-traced - rocprofv3's per-launch cost lands on the host thread that the driver's bookkeeping shares -,
+# the per-kernel stats from a traced run of the same command)
+timeout 300 python3 tools/config5_bench.py 50 > $out/pt.json 2> $out/pt_plain.err
+timeout 300 python3 tools/config5_bench.py 20 16 > $out/pt16.json 2>> $out/pt_plain.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/pt -- python3 tools/config5_bench.py 10 > $out/pt_traced.json 2> $out/pt.err
 timeout 300 python3 tools/propose_bench.py 4096 32 > $out/propose.json 2> $out/propose.err
 # keep the stats, drop the bulky traces (gpurun_out is capped at 64 MiB)
 find $out -name "*kernel_trace.csv" -delete
