@@ -804,11 +804,14 @@ int gpmi_lml_batch_submit(gpmi_ctx* c, int kernel, int64_t T, const double* thet
   ARGCHK(c, c->bpend[slot] == 0, "this slot has a batch pending (gpmi_lml_batch_wait first)");
   if (int rc = set_device(c)) return rc;
   if (int rc = ensure_lanes(c, 3)) return rc;
-  // each slot owns half of the workspace: at least 2 T matrices (grown only while nothing is pending)
-  if (c->bcap < 2 * T || c->bcap < 2) {
-    ARGCHK(c, c->bpend[1 - slot] == 0, "the other slot's batch was submitted with a smaller workspace: submit the larger batch first");
-    if (int rc = ensure_batch_ws(c, (int)(2 * T))) return rc;
+  // each slot owns half of the workspace: at least 2 T matrices - and room for 64 per slot from the start where the
+  // memory cap of ensure_batch_ws allows, because the workspace can only grow while nothing is pending
+  if (c->bpend[1 - slot] == 0) {
+    if (int rc = ensure_batch_ws(c, (int)(2 * T > 128 ? 2 * T : 128))) return rc;  // (a no-op once it is that large)
     ARGCHK(c, c->bcap >= 2 * T, "not enough device memory for two batches of this size");
+  } else {
+    ARGCHK(c, c->bcap >= 2 * T,
+           "this batch does not fit the slot (half of the lockstep workspace) and the workspace cannot grow while the other slot is pending");
   }
   const int off = slot * (c->bcap / 2);
   // inputs through pinned staging that lives until the wait (the copies are asynchronous)

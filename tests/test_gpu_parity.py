@@ -1215,6 +1215,13 @@ def test_async_batches_match_the_synchronous_call(gp_mod, monkeypatch):
     with pytest.raises(GpmiError):
         gp.engine.h.call("gpmi_lml_batch_wait", 0, None, None)  # nothing pending
     assert np.array_equal(gp.marginal_likelihood_batch(th[:4]), ref[:4])  # and the handle is usable again
+    # a mean function with per-point values (the `mus` path: T x n doubles through the pinned staging)
+    gl = gp_mod.GpRegressor(x[:512], y[:512], y_err=e[:512], mean=gp_mod.LinearMean)
+    tl = gl.hyperpars + 0.2 * rng.normal(size=(9, gl.n_hyperpars))
+    want = gl.marginal_likelihood_batch(tl)
+    gl.marginal_likelihood_batch_submit(tl[:4], 1)
+    gl.marginal_likelihood_batch_submit(tl[4:], 0)
+    assert np.array_equal(np.concatenate([gl.marginal_likelihood_batch_wait(1), gl.marginal_likelihood_batch_wait(0)]), want)
     # the driver: pipelined rounds (two groups of ladders through the two slots) against one batch per round
     def run(flag):
         monkeypatch.setenv("GPMI_PT_ASYNC", flag)
@@ -1542,3 +1549,39 @@ def test_kernel_call_reuses_its_device_context(gp_mod):
     from oracle import gp_oracle as orc
 
     check(c1, orc.kernel_cross(wl.SE, u, other, th), 1e-13, "cross-covariance against another point set")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kid", [wl.SE, wl.RQ])
+def test_covariance_at_extreme_hyperparameters_vs_oracle(gp_mod, kid):
+    """The K-build's own exp / log1p (csrc/kmath.h) where the library routines they replace are exercised least:
+    length scales from e^-6 to e^+6 (arguments of exp from 0 to far below the underflow threshold), RationalQuadratic
+    kappa from e^-5 to e^+8 (log1p of 1e-12 .. 1e+9), points that coincide (s = 0 exactly) - against the oracle's NumPy
+    values element by element: an entry is held to 4 ulp of the amplitude plus 1e-13 of itself (plus, for the
+    RationalQuadratic kernel, the 4 kappa ulp that the REFERENCE's `(1 + z / kappa) ** -kappa` loses to the rounding of its
+    base - the device form exp(-kappa log1p(z / kappa)) does not).
+    Reference: covariance.py:247-255 (SquaredExponential.__call__), :343-348 (RationalQuadratic.__call__)."""
+    from oracle import gp_oracle as orc
+
+    rng = np.random.default_rng(17)
+    d = 3
+    u = rng.uniform(-1, 1, (150, d))
+    v = np.concatenate([rng.uniform(-1, 1, (200, d)), u[:20]])  # (coincident points included)
+    cov = kernel_cls(gp_mod, kid)()
+    cov.pass_spatial_data(v)
+    worst = 0.0
+    for log_a in (-3.0, 0.0, 4.0):
+        for log_l in (-6.0, -2.5, 0.0, 2.5, 6.0):
+            for log_k in ((None,) if kid == wl.SE else (-5.0, -1.0, 0.0, 3.0, 8.0)):
+                head = [log_a] if kid == wl.SE else [log_a, log_k]
+                th = np.array(head + [log_l + 0.1 * i for i in range(d)])
+                got = cov(u, v, th)
+                ref = orc.kernel_cross(kid, u, v, th)
+                a2 = np.exp(2 * log_a)
+                eps = np.finfo(float).eps
+                rel_ref = 1e-13 + (0.0 if kid == wl.SE else 4 * eps * np.exp(log_k))
+                err = np.abs(got - ref) / (4 * eps * a2 + rel_ref * np.abs(ref))
+                worst = max(worst, float(err.max()))
+                assert np.isfinite(got).all() and (got >= 0).all() and (got <= a2 * (1 + 1e-15)).all(), th
+    _record("K entries at extreme hyper-parameters (units of the stated bound)", worst * 1e-13, 1e-13)
+    assert worst <= 1.0, worst
