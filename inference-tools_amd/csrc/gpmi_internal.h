@@ -36,6 +36,7 @@ struct ProfSlot {
 // One independent evaluation lane: a stream with its own n x n scratch matrix and vectors.
 struct Lane {
   hipStream_t stream = nullptr;    // full-chip stream: covariance build, solves, small factorisations
+  bool owns_stream = true;         // false: one of the process-wide pooled streams (api.hip: pooled_stream)
   // look-ahead pairs (CU-masked, disjoint; lanes 0 and 1 only, created with the lane): pair k factors the next panel on
   // gpmi_ctx::pair_cus[k] CUs (sp) while the trailing update runs on all the others (su)
   hipStream_t sp[GPMI_NPAIRS] = {nullptr};

@@ -119,13 +119,6 @@ def load():
                 f"{LIB_PATH} not found - build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()' or make -C inference-tools_amd/csrc)"
             )
-        # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and two
-        # streams on one queue run in order.  A handle keeps 3 - 7 streams; with a second handle alive in the process
-        # (a regressor beside the one being evaluated) the two evaluation lanes of a sweep shared a queue and config 3
-        # lost 14 % (30.2 against 26.5 ms per likelihood at N = 16384).  Eight queues remove that and cost the
-        # single-handle workloads nothing (tools/scratch/ab_hwq.sh).  Read by the runtime when it initialises: set here,
-        # before the library (and with it HIP) is loaded, unless the user has chosen a value.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header / library mismatch
