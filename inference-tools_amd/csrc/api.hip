@@ -50,55 +50,21 @@ thread_local std::string g_create_err;
 
 constexpr int RED_SLOTS = 8192;  // per-lane result slots for batched evaluations
 
-// The full-chip stream of lane i of EVERY handle of the process on a device is one of TWO pooled streams (i mod 2),
-// created together the first time a handle needs one and used at once, in order.  Why: the HIP runtime multiplexes a
-// process's streams onto 4 hardware queues (GPU_MAX_HW_QUEUES), and two streams on one queue run in order.  With
-// per-handle streams a second handle alive in the process (a regressor beside the one being evaluated) put the two
-// evaluation lanes of a likelihood sweep on one queue: config 3 lost 14 % (30.2 against 26.5 ms per evaluation at N = 16384).
-// Asking the runtime for more queues fixes that too, but with two processes on one device it oversubscribes the
-// hardware's queue slots and the flag-ordered kernels then wait for a queue that is not mapped (bench.py --gpus 2 on one
-// GPU timed out).  Two streams taken in this order get two distinct queues, and every pair the library runs side by side
-// is a pair of neighbouring lanes (the half-batches of a lockstep chunk and the asynchronous slots: lanes 1 | 2; a sweep
-// on two lanes: 1 | 2); with three or four pooled streams the CU-masked pair of the look-ahead lost its own queues
-// (headline 33.8 -> 37.1 ms, tools/scratch/ab_pool.sh).  The handles of a process are driven by host-synchronous calls,
-// so sharing streams between them only orders work that was ordered already.  GPMI_STREAM_POOL=<n>: n pooled streams
-// (0: a stream per lane, as before round 3).
-namespace pool {
-std::mutex mu;
-hipStream_t streams[64][4];
-bool made[64] = {false};
-}  // namespace pool
-
-static hipStream_t pooled_stream(int device, int lane_index) {
-  static const int npool = [] {
-    const char* e = std::getenv("GPMI_STREAM_POOL");
-    const int v = e ? std::atoi(e) : 2;
-    return v < 0 ? 0 : v > 4 ? 4 : v;
-  }();
-  if (npool == 0 || device < 0 || device >= 64) return nullptr;
-  std::lock_guard<std::mutex> lk(pool::mu);
-  if (!pool::made[device]) {
-    hipEvent_t ev = nullptr;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
-    for (int k = 0; k < npool; ++k) {
-      if (hipStreamCreateWithFlags(&pool::streams[device][k], hipStreamNonBlocking) != hipSuccess) {
-        for (int j = 0; j < k; ++j) (void)hipStreamDestroy(pool::streams[device][j]);
-        (void)hipEventDestroy(ev);
-        (void)hipGetLastError();
-        return nullptr;
-      }
-      (void)hipEventRecord(ev, pool::streams[device][k]);  // first use: the runtime assigns the hardware queue here
-    }
-    (void)hipEventSynchronize(ev);
-    (void)hipEventDestroy(ev);
-    pool::made[device] = true;
-  }
-  return pool::streams[device][lane_index % npool];
-}
-
+// A handle has TWO full-chip streams, those of its lanes 0 and 1; lane i >= 2 runs on the stream of lane i mod 2 (its
+// buffers are its own).  Why: the HIP runtime multiplexes a process's streams onto 4 hardware queues (GPU_MAX_HW_QUEUES),
+// and two streams on one queue run in order.  With a stream per lane a second handle alive in the process (a regressor
+// beside the one being evaluated: 2 + 3 streams) put the two evaluation lanes of a likelihood sweep on one queue: config
+// 3 lost 14 % (30.2 against 26.5 ms per evaluation at N = 16384).  Every pair the library runs side by side is a pair
+// of neighbouring lanes (the half-batches of a lockstep chunk and the asynchronous slots: lanes 1 | 2; a sweep on two
+// lanes: 1 | 2), lane 0's stream is idle while other lanes evaluate, and more than two evaluations at a time were never
+// faster than two (§5).  Measured alternatives (tools/scratch/ab_hwq.sh, ab_pool*.sh): GPU_MAX_HW_QUEUES=8 cures the
+// sweep but two processes on one device then time out in the flag-ordered kernels (bench.py --gpus 2 on one GPU);
+// process-wide pooled streams cure it too but change the order in which a handle's queues are created, and the
+// look-ahead of lane 1 (its stream and its CU-masked pair) lost 10 % (LML at N = 16384: 27.7 -> 31 ms).
 int lane_streams(gpmi_ctx* c, Lane& L) {
-  L.stream = pooled_stream(c->device, (int)c->lanes.size() - 1);  // (the lane has just been appended)
-  L.owns_stream = L.stream == nullptr;
+  const size_t index = c->lanes.size() - 1;  // (the lane has just been appended)
+  L.owns_stream = index < 2;
+  if (!L.owns_stream) L.stream = c->lanes[index % 2].stream;
   if (L.owns_stream) HIPCHK(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
   hipDeviceProp_t prop;
   HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
@@ -245,7 +211,7 @@ void free_data(gpmi_ctx* c) {
   }
   c->mix_nk = 0;
   c->q3_cap = 0;
-  for (auto& L : c->lanes) lane_free(L);
+  for (size_t i = c->lanes.size(); i-- > 0;) lane_free(c->lanes[i]);  // (lanes >= 2 borrow the streams of lanes 0, 1)
   c->lanes.clear();
   auto fr = [](double*& p) {
     if (p) (void)hipFree(p);
