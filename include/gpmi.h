@@ -124,6 +124,13 @@ int gpmi_set_streams(gpmi_ctx* ctx, int n_streams);
 /*   GPMI_OPT_RESERVE_POINTS   r >= 0, read by the NEXT gpmi_set_data: room for r more training points in the padded
  *       device matrices (identity in the padding: the factor is unaffected), to be filled by gpmi_append_point */
 #define GPMI_OPT_RESERVE_POINTS 2
+/*   GPMI_OPT_NO_FLOW          1: factorisations of this handle keep the stream-ordered schedule for their chain-bound
+ *     part instead of the flag-ordered tile-task launch (same factor, bit for bit; slower).  The flag-ordered launch
+ *     needs its two kernels side by side on the device; when something outside the library prevents that for about
+ *     a second (a heavily oversubscribed device, a tool that serialises kernels) the call fails with
+ *     GPMI_ERR_INTERNAL instead of hanging - a caller can then set this option and repeat the call (the Python layer
+ *     does, once, with a warning). */
+#define GPMI_OPT_NO_FLOW 3
 int gpmi_set_option(gpmi_ctx* ctx, int option, int value);
 
 /* Replaces GpRegressor.marginal_likelihood_gradient (regression.py:544-567):

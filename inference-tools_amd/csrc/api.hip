@@ -635,8 +635,10 @@ int gpmi_set_streams(gpmi_ctx* c, int n_streams) {
 
 int gpmi_set_option(gpmi_ctx* c, int option, int value) {
   if (!c) return GPMI_ERR_ARG;
-  ARGCHK(c, option == GPMI_OPT_LOCKSTEP_ALWAYS || option == GPMI_OPT_RESERVE_POINTS, "unknown option");
+  ARGCHK(c, option == GPMI_OPT_LOCKSTEP_ALWAYS || option == GPMI_OPT_RESERVE_POINTS || option == GPMI_OPT_NO_FLOW,
+         "unknown option");
   if (option == GPMI_OPT_LOCKSTEP_ALWAYS) c->lockstep_always = value != 0;
+  if (option == GPMI_OPT_NO_FLOW) c->no_flow = value != 0;
   if (option == GPMI_OPT_RESERVE_POINTS) {
     ARGCHK(c, value >= 0, "reserve must be >= 0");
     c->reserve = value;

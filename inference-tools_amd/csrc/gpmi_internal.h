@@ -103,6 +103,7 @@ struct gpmi_ctx {
   std::vector<Lane> lanes;
   bool fitted = false;
   bool lockstep_always = false;  // GPMI_OPT_LOCKSTEP_ALWAYS
+  bool no_flow = false;          // GPMI_OPT_NO_FLOW
   int64_t reserve = 0;           // GPMI_OPT_RESERVE_POINTS: extra rows of padding at the next gpmi_set_data
   KParams fit_params{};
   double* alpha = nullptr;  // np (device) — fitted alpha

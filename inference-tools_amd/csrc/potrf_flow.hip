@@ -490,7 +490,7 @@ bool potrf_flow_enabled(gpmi_ctx* c, Lane& lane, int m) {
     const char* e = std::getenv("GPMI_FLOW_MIN");
     return e ? std::atoi(e) : 8;
   }();
-  return on && m >= min_rows && m < 4096 && ensure_masked_pair(c, lane, 0);
+  return on && !c->no_flow && m >= min_rows && m < 4096 && ensure_masked_pair(c, lane, 0);
 }
 
 void potrf_flow_free(Lane& lane) {

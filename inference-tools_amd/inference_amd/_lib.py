@@ -21,7 +21,8 @@ LIB_PATH = os.environ.get("GPMI_LIB") or os.path.join(_HERE, "lib", "libgpmi.so"
 KERNEL_SE = 0
 KERNEL_RQ = 1
 PROF_KBUILD, PROF_SYRK, PROF_PANEL, PROF_SOLVE, PROF_SYRK_REST, PROF_TRSM, PROF_SYRK_SLICE, PROF_FLOW = 0, 1, 2, 3, 4, 5, 6, 7
-OPT_LOCKSTEP_ALWAYS, OPT_RESERVE_POINTS = 1, 2
+OPT_LOCKSTEP_ALWAYS, OPT_RESERVE_POINTS, OPT_NO_FLOW = 1, 2, 3
+ERR_INTERNAL = -5  # GPMI_ERR_INTERNAL
 
 
 class GpmiUnavailable(RuntimeError):
@@ -183,8 +184,24 @@ class Handle:
             raise GpmiUnavailable(f"gpmi_create(device={device}) failed with status {rc}: {msg}")
         _live_handles.add(self)
 
+    # entry points that factorise a matrix from their own inputs: safe to repeat after a failed attempt
+    _REPEATABLE = frozenset(("gpmi_fit", "gpmi_fit_mix", "gpmi_fit_dense", "gpmi_lml", "gpmi_lml_batch", "gpmi_lml_grad",
+                             "gpmi_lml_grad_batch", "gpmi_lml_mix", "gpmi_lml_grad_mix", "gpmi_lml_dense", "gpmi_loo_dense",
+                             "gpmi_linv_lml", "gpmi_linv_lml_grad", "gpmi_linv_posterior", "gpmi_linv_lml_dense",
+                             "gpmi_linv_lml_grad_dense", "gpmi_linv_posterior_dense"))
+
     def call(self, name, *args):
         rc = getattr(self.lib, name)(self.ctx, *args)
+        if rc == ERR_INTERNAL and name in self._REPEATABLE and not getattr(self, "_no_flow", False):
+            # a flag-ordered launch did not get its kernels side by side within its time limit (gpmi.h: GPMI_OPT_NO_FLOW):
+            # once, with the stream-ordered schedule - the same factor, bit for bit, only slower
+            import warnings
+
+            warnings.warn(f"{name}: {self.lib.gpmi_last_error(self.ctx).decode()} - repeating the call with the "
+                          "stream-ordered schedule (GPMI_OPT_NO_FLOW) for the rest of this handle's life", RuntimeWarning)
+            self._no_flow = True
+            self.lib.gpmi_set_option(self.ctx, OPT_NO_FLOW, 1)
+            rc = getattr(self.lib, name)(self.ctx, *args)
         if rc != 0:
             raise GpmiError(f"{name} failed with status {rc}: {self.lib.gpmi_last_error(self.ctx).decode()}")
 
