@@ -132,6 +132,21 @@ def pmc_traffic():
     return None, None
 
 
+def rocprof_duration_ratio():
+    """(rocprofv3's average duration of the dominant kernel / the in-kernel stamps' average over the same launches,
+    file): from the committed kernel-trace summary of this command (profiles/rNN_pmc.json `cross_check`).  rocprofv3
+    times a launch from its dispatch to its completion signal - the end-of-kernel write-back included -, the stamps
+    from the first workgroup's first instruction to the last workgroup's last acknowledged store."""
+    for name in ("r03_pmc.json", "r02_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                x = json.load(f)["cross_check"]
+            return x["rocprof_kernel_stats_avg_us_of_the_dominant_kernel"] / x["bench_stamp_avg_us_all_launches_of_this_kernel_name"], "profiles/" + name
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            continue
+    return None, None
+
+
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable with a plain copy)
 
 
@@ -446,6 +461,12 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                 "frac": ach / PEAK_FP64_MFMA_TFLOPS,
                 "traffic": traffic,
                 "traffic_source": f"{traffic_src}: separate rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run; per launch, averaged over every launch of this kernel name (slices included: compare with same_kernel_name_all_launches.algorithmic_bytes_per_launch_avg)" if traffic_src else None,
+                "with_rocprofv3_durations": (lambda q: None if q[0] is None else {
+                    "achieved": ach / q[0], "frac": ach / q[0] / PEAK_FP64_MFMA_TFLOPS, "duration_ratio": q[0],
+                    "source": f"{q[1]} cross_check: rocprofv3 --kernel-trace --stats of this command gives this kernel "
+                              "an average duration that much longer than the stamps over the same launches (dispatch "
+                              "-> completion signal, end-of-kernel write-back included); not measured in this run"})(
+                    rocprof_duration_ratio()),
                 "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
                 "flop_per_launch_avg": prof["flops"] / max(prof["launches"], 1),
