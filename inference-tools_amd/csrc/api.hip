@@ -131,6 +131,9 @@ int lane_alloc(gpmi_ctx* c, Lane& L) {
   const int64_t nt = c->np / GPMI_NB;
   HIPCHK(c, hipMalloc(&L.A, sizeof(double) * c->np * c->ld));
   HIPCHK(c, hipMalloc(&L.invD, sizeof(double) * nt * GPMI_NB * GPMI_NB));
+  // potrf_diag writes the block-lower part of an inverse only: the zeros above stay from here (round 4: zeroing them
+  // in the kernel cost it 57 KB of stores per launch through one CU's memory path, as much as loading the block)
+  HIPCHK(c, hipMemset(L.invD, 0, sizeof(double) * nt * GPMI_NB * GPMI_NB));
   HIPCHK(c, hipMalloc(&L.vec, sizeof(double) * 4 * c->np));
   HIPCHK(c, hipMalloc(&L.red, sizeof(double) * 2 * RED_SLOTS));
   HIPCHK(c, hipMalloc(&L.info, sizeof(int) * RED_SLOTS));
@@ -414,6 +417,7 @@ int ensure_batch_ws(gpmi_ctx* c, int want) {
   const int64_t nt = c->np / GPMI_NB;
   HIPCHK(c, hipMalloc(&c->bA, sizeof(double) * want * c->np * c->ld));
   HIPCHK(c, hipMalloc(&c->bInv, sizeof(double) * want * nt * GPMI_NB * GPMI_NB));
+  HIPCHK(c, hipMemset(c->bInv, 0, sizeof(double) * want * nt * GPMI_NB * GPMI_NB));  // see lane_alloc
   HIPCHK(c, hipMalloc(&c->bVec, sizeof(double) * want * 4 * c->np));
   HIPCHK(c, hipMalloc(&c->bRed, sizeof(double) * 2 * want));
   HIPCHK(c, hipMalloc(&c->bMu, sizeof(double) * want * c->np));
@@ -1547,19 +1551,37 @@ int gpmi_dev_potrf(gpmi_ctx* c, double* A, int64_t n, int64_t ld, int* info) {
   double* invD = nullptr;
   int* dinfo = nullptr;
   HIPCHK(c, hipMalloc(&invD, sizeof(double) * (n / GPMI_NB) * GPMI_NB * GPMI_NB));
+  HIPCHK(c, hipMemset(invD, 0, sizeof(double) * (n / GPMI_NB) * GPMI_NB * GPMI_NB));  // see lane_alloc
   HIPCHK(c, hipMalloc(&dinfo, sizeof(int)));
   HIPCHK(c, hipMemsetAsync(dinfo, 0, sizeof(int), s));
   if (n == GPMI_NB && std::getenv("GPMI_DIAG_STAMPS")) {
     // tools only: phase cycle counts of one potrf_diag launch
+    // tools only: phase cycle counts and the per-wave timeline of one potrf_diag launch (potrf.hip: DIAG_TRACE_*)
+    constexpr int TRACE_WORDS = 8 * 9 * 6;
     unsigned long long* dbg = nullptr;
-    HIPCHK(c, hipMalloc(&dbg, GPMI_STAMP_WORDS * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&dbg, (GPMI_STAMP_WORDS + TRACE_WORDS) * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(dbg, 0, (GPMI_STAMP_WORDS + TRACE_WORDS) * sizeof(unsigned long long), s));
+    const unsigned long long magic = 0x7ACEull;
+    HIPCHK(c, hipMemcpyAsync(dbg + 22, &magic, sizeof(magic), hipMemcpyHostToDevice, s));
     launch_potrf_diag(s, A, ld, invD, dinfo, 0, dbg);
-    unsigned long long hw[GPMI_STAMP_WORDS];
+    std::vector<unsigned long long> hw(GPMI_STAMP_WORDS + TRACE_WORDS);
     HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, hipMemcpy(hw, dbg, sizeof(hw), hipMemcpyDeviceToHost));
-    const unsigned long long* h = hw + 16;
-    std::fprintf(stderr, "[potrf_diag] %.2f us | cycles: load %llu | wave 0 waits at the barrier %llu | sub-diagonal panel + trailing tile %llu | end %llu | factor16 x8 %llu | %llu\n",
-                 (double)(hw[8] - hw[0]) * 0.01, h[0], h[1], h[2], h[3], h[4], h[5]);
+    HIPCHK(c, hipMemcpy(hw.data(), dbg, hw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const unsigned long long* h = hw.data() + 16;
+    std::fprintf(stderr, "[potrf_diag] %.2f us | wave 0 cycles: load %llu | waits for its two tiles %llu | sub-diagonal panel + trailing tile %llu | end %llu | factor16 x8 %llu\n",
+                 (double)(hw[8] - hw[0]) * 0.01, h[0], h[1], h[2], h[3], h[4]);
+    for (int w = 0; w < 8; ++w) {
+      if (w == 4) continue;
+      std::fprintf(stderr, "[potrf_diag] wave %d (%s):", w, w == 0 ? "chain: start, W published, tiles seen, next block ready" : w < 4 ? "factor: start, W seen, panel done, panels seen, updates done" : "inverse: start, W seen, row done, operands seen, sums done");
+      for (int k = 0; k < 9; ++k) {
+        std::fprintf(stderr, " |");
+        for (int e = 0; e < 6; ++e) {
+          const unsigned long long v = hw[GPMI_STAMP_WORDS + (w * 9 + k) * 6 + e];
+          if (v) std::fprintf(stderr, " %llu", v);
+        }
+      }
+      std::fprintf(stderr, "\n");
+    }
     (void)hipFree(dbg);
   } else
   potrf_lower(c, c->lanes[0], A, n, ld, invD, dinfo);
@@ -1964,6 +1986,7 @@ void linv_free(LinvState& S) {
 int linv_alloc(gpmi_ctx* c, double** p, int64_t doubles) {
   if (*p) return GPMI_OK;
   HIPCHK(c, hipMalloc(p, sizeof(double) * doubles));
+  HIPCHK(c, hipMemset(*p, 0, sizeof(double) * doubles));  // (the inverses' upper 16-blocks rely on it, see lane_alloc)
   return GPMI_OK;
 }
 

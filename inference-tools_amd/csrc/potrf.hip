@@ -11,6 +11,8 @@
 // column + 1); the factorisation then continues with a unit pivot so that the launch sequence stays
 // asynchronous — the host inspects `info` once at the end (regression.py:540-542 behaviour).
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "gpmi_internal.h"
@@ -21,14 +23,6 @@ constexpr int NB = GPMI_NB;
 constexpr int BS = 16;      // base block = one MFMA tile
 constexpr int NBLK = NB / BS;
 constexpr int WP = BS + 1;  // pitch of the 16 x 16 inverse diagonal blocks
-
-// value of `v` in lane `src` (compile-time constant) as a wave-uniform scalar
-__device__ inline double lane_bcast(double v, int src) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, src);
-  hi = __builtin_amdgcn_readlane(hi, src);
-  return __hiloint2double(hi, lo);
-}
 
 __device__ inline double rcp_newton(double p) {
   double y = __builtin_amdgcn_rcp(p);
@@ -44,151 +38,202 @@ __device__ inline double rcp_newton(double p) {
 // workgroup; since the panel chain has CUs of its own - CU-masked streams - the kernel also keeps the inverse in LDS,
 // 153 KiB in all: one workgroup per CU.)
 constexpr int S_DOUBLES = 16 * (16 * 36 + 8);
-__device__ inline int prow(int r) {
-  const int ib = r >> 4;
-  return 16 * (8 * ib * (ib + 1) + ib) + (r & 15) * ((ib + 1) * 16 + 1);
-}
-
-// value of lane C of the lane's own 16-lane row (DPP row_newbcast: VALU only, no LDS round trip)
+// value of lane C of the lane's own 16-lane row (DPP row_newbcast on the 64-bit pair: VALU only, no LDS round trip)
 template <int C>
 __device__ inline double row_bcast(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_mov_dpp(lo, 0x150 + C, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_mov_dpp(hi, 0x150 + C, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
+  long long x = __builtin_bit_cast(long long, v);
+  x = __builtin_amdgcn_mov_dpp(x, 0x150 + C, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, x);
 }
 
-// State of the 16 x 16 elimination: lane (g = lane >> 4, k = lane & 15) holds column k of the rows
-// i = 4 j + g (j = 0..3) of the block (a) and of the accumulated row operations (e).
+// State of the 16 x 16 elimination ("column per lane", round 4).  Lane (g = lane >> 4, k = lane & 15) holds ALL 16
+// rows of column k of the block - x[0..15], the four 16-lane groups redundantly - and the entries E[k][4 q + g]
+// (q = 0..3) of row k of the accumulated row operations E (A = M D M^T, E -> M^-1).  Elimination step C is then
+//   x[i] += bcast_C(x[i]) * nt     i > C     nt  = -(x[C] / p_C): the lane's own pivot-row element - no cross-lane
+//   e[q] += bcast_C(e[q]) * nte    4q+g <= C nte = nt in the rows below the pivot (lanes k > C), 0 elsewhere
+// with bcast_C = DPP row_newbcast:C folded into the instruction (v_fmac_f64_dpp): ONE instruction per row and step, no
+// LDS round trip, no wave-wide shuffle.  (Round 1-3 spread a column over the four lane groups and moved the pivot
+// row between them with ds_bpermute: 380 cycles per step; this form: ~120, bound by the issue rate of fp64 vector
+// instructions of one wave - 6.6 cycles each, tools/probes/factor16_probe.hip - not by the dependency chain.)
 struct Elim16 {
-  double a[4], e[4];
-  double p, ip;        // current pivot and its reciprocal (wave-uniform)
-  double arow, erow;   // pivot row elements of this lane's column
-  double myp;          // lane (., k): pivot k
-  int badcol;
+  double x[16], e[4];
+  double p, ip;  // current pivot and its reciprocal (uniform over a 16-lane row)
+  double myp;    // lane (., k): pivot k
   int k, g;
 };
 
-// Elimination step C: row_i -= (A[i][C] / p_C) row_C for the rows i > C.  Three things keep the dependency
-// chain of a step down to one LDS round trip:
-//  * the multiplier A[i][C] of a lane's row comes from lane C of its own 16-lane row through DPP;
-//  * the pivot and its reciprocal are wave-uniform scalars kept one step ahead: p_{C+1} is formed from three
-//    lane reads at the start of step C exactly as the owning lane forms it, so the Newton chain of the
-//    reciprocal overlaps the row operations;
-//  * row C + 1 is updated first and sent on its way to the other lane groups (ds_bpermute) before the
-//    remaining rows of step C are updated.
+#include "factor16_steps.h"  // ElimStepAsm<C>: one asm block per step (tools/gen_factor16.py)
+
 template <int C>
 struct ElimStep {
-  static __device__ inline void run(Elim16& s) {
-    constexpr int jc = C >> 2, gc = C & 3;
-    constexpr int j1 = (C + 1) >> 2, g1 = (C + 1) & 3;  // slot / lane group of row C + 1
-    double pn = 1.0, ipn = 1.0;
-    if (C + 1 < BS) {
-      const double s1 = lane_bcast(s.a[j1 & 3], g1 * 16 + C);             // A[C+1][C]
-      const double s2 = lane_bcast(s.a[j1 & 3], g1 * 16 + ((C + 1) & 15));  // A[C+1][C+1]
-      const double s3 = lane_bcast(s.a[jc], gc * 16 + ((C + 1) & 15));      // A[C][C+1]
-      const double m1 = s1 * s.ip;
-      pn = fma(-m1, s3, s2);
-      if (!(pn > 0.0) || !(pn < 1.79e308)) {  // wave-uniform
-        if (s.badcol < 0) s.badcol = C + 1;
-        pn = 1.0;
-      }
-      ipn = rcp_newton(pn);
-    }
+  static __device__ __forceinline__ void run(Elim16& s) {
     if (s.k == C) s.myp = s.p;
-    auto update = [&](int j) {
-      double m = row_bcast<C>(s.a[j]) * s.ip;  // A[i][C] / p_C for this lane's row i = 4 j + g
-      if (j == jc && s.g <= gc) m = 0.0;       // row i <= C: untouched
-      s.a[j] = fma(-m, s.arow, s.a[j]);
-      s.e[j] = fma(-m, s.erow, s.e[j]);
-    };
-    double arow_n = 0.0, erow_n = 0.0;
-    if (C + 1 < BS) {
-      update(j1 & 3);
-      arow_n = __shfl(s.a[j1 & 3], g1 * 16 + s.k, 64);
-      erow_n = __shfl(s.e[j1 & 3], g1 * 16 + s.k, 64);
+    if constexpr (C + 1 < BS) {
+      const double nt = -(s.x[C] * s.ip);
+      const double nte = (s.k > C) ? nt : 0.0;
+      double pn, ipn;
+      ElimStepAsm<C>::run(s, nt, nte, pn, ipn);
+      s.p = pn;
+      s.ip = ipn;
+      ElimStep<C + 1>::run(s);
     }
-#pragma unroll
-    for (int j = jc; j < 4; ++j)
-      if (!(C + 1 < BS && j == (j1 & 3))) update(j);
-    s.arow = arow_n;
-    s.erow = erow_n;
-    s.p = pn;
-    s.ip = ipn;
-    ElimStep<C + 1>::run(s);
   }
-};
-template <>
-struct ElimStep<BS> {
-  static __device__ inline void run(Elim16&) {}
 };
 
-// One wave: factor the symmetric 16 x 16 diagonal block `kb` of S (both triangles valid) and
-// invert the factor.  Gaussian elimination without square roots on the critical path (ElimStep); the
-// same row operations applied to the identity give M^-1 (A = M D M^T); then
-// L[k][i] = U[i][k] / sqrt(p_i) and W = L^-1 = D^-1/2 M^-1 (to LDS for the panel phase and to the
-// diagonal block of invD in global memory); L itself also goes straight to the matrix in global memory.
-// `blk`: the block itself, lane (g = lane >> 4, k = lane & 15) element j = entry (4 j + g, k) - the D layout of the MFMA
-// that produced it (potrf_diag_kernel keeps it in registers from the trailing product to the elimination).
-__device__ inline void factor16(double* S, double* Wl, double* __restrict__ invD, double* __restrict__ A,
-                                int64_t ld, int kb, int* info, int col0, int lane, const d4_t& blk) {
+// 1 / sqrt(p) to 1 ulp: v_rsq_f64 (2^-23) and one cubic step, y (1 + e/2 + 3 e^2 / 8) with e = 1 - p y^2
+__device__ inline double rsqrt_refined(double p) {
+  const double y = __builtin_amdgcn_rsq(p);
+  const double e = fma(-(p * y), y, 1.0);
+  return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+
+// Scratch of the elimination in LDS, one per parity of the block index: T receives the block in the MFMA D layout and
+// hands it back as whole columns; afterwards the same words carry the raw columns of U (and rs the 1 / sqrt(p_i)) to
+// the wave that writes L to global memory one step later.
+constexpr int TP = 18;  // row pitch of T (16-byte aligned rows for ds_read_b128)
+struct ElimScratch {
+  double T[BS * TP];
+  double rs[BS];
+};
+
+// One wave: factor the symmetric 16 x 16 diagonal block `kb` (both triangles valid) and invert the factor.  Gaussian
+// elimination without square roots on the critical path (ElimStep); the same row operations applied to the identity
+// give M^-1; then L[k][i] = U[i][k] / sqrt(p_i) and W = L^-1 = D^-1/2 M^-1.
+// `blk`: the block itself, lane (g = lane >> 4, k = lane & 15) element j = entry (4 j + g, k) - the D layout of the
+// MFMA that produced it.  Returns W in the A-operand layout of the next product: w[q] = W[k][4 q + g]; W also goes
+// to Wl (LDS, pitch WP); the raw U and 1 / sqrt(p) go to `sc` for flush_diag.
+__device__ inline d4_t factor16(ElimScratch& sc, double* Wl, int kb, int* info, int col0, int lane, const d4_t& blk) {
   const int k = lane & 15, g = lane >> 4;
-  const int base = kb * BS;
   Elim16 s;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int i = 4 * j + g;
-    s.a[j] = blk[j];
-    s.e[j] = (i == k) ? 1.0 : 0.0;
+  for (int j = 0; j < 4; ++j) sc.T[(4 * j + g) * TP + k] = blk[j];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave: its own LDS writes are visible to it in order
+#pragma unroll
+  for (int m = 0; m < BS / 2; ++m) {
+    const d2_t v = *reinterpret_cast<const d2_t*>(&sc.T[k * TP + 2 * m]);  // column k = row k (symmetric)
+    s.x[2 * m] = v[0];
+    s.x[2 * m + 1] = v[1];
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s.e[q] = (4 * q + g == k) ? 1.0 : 0.0;
   s.k = k;
   s.g = g;
   s.myp = 1.0;
-  s.badcol = -1;
-  s.p = lane_bcast(s.a[0], 0);  // A[0][0]
-  if (!(s.p > 0.0) || !(s.p < 1.79e308)) {
-    s.badcol = 0;
-    s.p = 1.0;
-  }
+  s.p = row_bcast<0>(s.x[0]);
   s.ip = rcp_newton(s.p);
-  s.arow = __shfl(s.a[0], k, 64);  // row 0
-  s.erow = __shfl(s.e[0], k, 64);
   ElimStep<0>::run(s);
-  const double myp = s.myp;
-  const int badcol = s.badcol;
-  const double* a = s.a;
-  const double* e = s.e;
-  const double rs = 1.0 / sqrt(myp);  // lane (., k): 1 / sqrt(p_k)
-  const int rowk = prow(base + k);
+  // Pivots are examined once, behind the chain: lane k holds p_k.  A non-positive or non-finite pivot is reported
+  // (LAPACK-style) and the block's values are then whatever the arithmetic gave - the factorisation is void.
+  const bool badp = !(s.myp > 0.0) || !(s.myp < 1.79e308);
+  const unsigned long long bad = __ballot(badp) & 0xffffull;
+  const double rs = rsqrt_refined(badp ? 1.0 : s.myp);
+  d4_t w;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int i = 4 * j + g;
-    const double rsi = __shfl(rs, i, 64);
-    if (i <= k) {
-      const double lki = a[j] * rsi;  // L[k][i] = U[i][k] / sqrt(p_i)
-      S[rowk + base + i] = lki;
-      A[(int64_t)(base + k) * ld + base + i] = lki;
-    }
-    const double w = e[j] * rsi;                    // W[i][k] (zero above the diagonal)
-    Wl[i * WP + k] = w;
-    invD[(base + i) * NB + base + k] = w;
+  for (int q = 0; q < 4; ++q) {
+    w[q] = s.e[q] * rs;  // W[k][4 q + g] (zero above the diagonal)
+    Wl[k * WP + 4 * q + g] = w[q];
   }
-  if (badcol >= 0 && lane == 0 && *info == 0) *info = col0 + base + badcol + 1;
+  if (g == 0) {
+#pragma unroll
+    for (int m = 0; m < BS / 2; ++m) *reinterpret_cast<d2_t*>(&sc.T[k * TP + 2 * m]) = d2_t{s.x[2 * m], s.x[2 * m + 1]};
+    sc.rs[k] = rs;
+  }
+  if (bad && lane == 0 && *info == 0) *info = col0 + kb * BS + __builtin_ctzll(bad) + 1;
+  return w;
 }
 
-// One workgroup (8 waves): L = chol(A_blk) in place (lower part of A), invD = L^-1 (dense
-// 128 x 128, zero above the diagonal).  Blocked by 16 inside LDS; everything except the 16 x 16
-// eliminations runs as 16 x 16 x 16 products on v_mfma_f64_16x16x4_f64.  The eliminations (factor16,
-// one wave, ~2.7 us each) are the critical path, so wave 0 does nothing but that chain:
-//   wave 0, step kb:   factor16(kb) | barrier | panel tile (kb+1, kb), trailing tile (kb+1, kb+1)
-//   waves 1-7, step kb (one step behind, "bulk(kb - 1)"):  the other panel tiles of column kb - 1, row
-//       block kb - 1 of the inverse (X[kb-1][jb] = -W sum_k L[kb-1][k] X[k][jb], earlier X rows read back
-//       from invD through L2), the other trailing tiles of step kb - 1 | barrier
-// One barrier per step; inside bulk() the seven waves order themselves through two LDS counters
-// (panel tiles of the column finished / wave 0's sub-diagonal tile finished).  L and the inverse go to
-// global memory tile by tile as they are produced.
-constexpr int DIAG_THREADS = 512;  // wave 0: elimination chain; waves 1-7: everything else
-constexpr int DIAG_BULK = DIAG_THREADS / 64 - 1;
+// The diagonal 16 x 16 block of L and of the inverse, from LDS to global memory (one wave, one step behind factor16):
+// L[k][i] = U[i][k] / sqrt(p_i) for i <= k, W in full.
+__device__ inline void flush_diag(const ElimScratch& sc, const double* Wl, double* __restrict__ invD,
+                                  double* __restrict__ A, int64_t ld, int kb, int lane) {
+  const int base = kb * BS;
+  const int k = lane >> 2, i0 = (lane & 3) * 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = i0 + t;
+    if (i <= k) A[(int64_t)(base + k) * ld + base + i] = sc.T[k * TP + i] * sc.rs[i];
+    invD[(base + k) * NB + base + i] = Wl[k * WP + i];
+  }
+}
+
+// One workgroup (8 waves): L = chol(A_blk) in place (lower part of A), invD = L^-1 (dense 128 x 128, zero above
+// the diagonal).  Blocked by 16; everything except the 16 x 16 eliminations runs as 16 x 16 x 16 products on
+// v_mfma_f64_16x16x4_f64 - 72 cycles each on a SIMD (tools/probes/factor16_probe.hip), 840 of them: the MFMA time of
+// one CU is a third of the kernel, so who computes what, when, decides the kernel as much as the chain does.
+//
+// Round 4 - three roles, ordered by six LDS counters (data flow; the one barrier is at the very start):
+//   wave 0 (SIMD 0, alone: wave 4 leaves at once) - the chain: factor16(kb) -> W_kb published | sub-diagonal tile
+//       (kb+1, kb) = A W^T and the trailing product of tile (kb+1, kb+1), in registers -> factor16(kb+1) ...
+//   waves 1-3 (one per SIMD 1-3, priority 2) - the factor: every other tile (i, j) of the matrix has ONE owner for the
+//       whole kernel (dealt round-robin in column-major order: any step's active tiles are a contiguous range of that
+//       order, every step is balanced to within one tile) and lives in its owner's registers from its load (global
+//       memory -> registers, one step before its first use: the fetch path of one CU, ~10 B / clk, needs 6600 cycles
+//       for the 66 KB of the block - spread over the kernel instead of in front of it) to its last use, TRANSPOSED in the
+//       MFMA D layout (accT[r] = tile[fr][fk + 4 r]) - at once the B operand of the panel step P^T = W tile^T.  Step kb of
+//       an owner: A - panel step of its tiles of column kb (P to LDS: the operand of everybody's updates, and to global
+//       memory); E - tile -= P_i,c P_j,c^T, lazily: a tile next used at step je receives the columns 0 .. je - 2 in one
+//       chain of MFMAs at step je - 2 and column je - 1 at step je - 1 (13 - 17 products per step instead of 33, 25,
+//       18, ...).  A tile leaves the registers once: after A, or - the two tiles wave 0 takes over next - after E.
+//   waves 5-7 (the same SIMDs, priority 0) - the inverse, right-looking, tiles owned the same way: B - row block kb,
+//       X[kb][jb] = -W T[kb][jb]; D - T[i][jb] += L[i][kb] X[kb][jb] for the rows below.  More than half of the kernel's
+//       MFMAs and on nobody's critical path until the last row.
+// A product's operands are requested while the MFMAs of the product before it run (the sequence of products of a
+// step is generated on the fly by scalar code; the accumulator is picked by a scalar switch over the slot, since
+// registers cannot be indexed): ~300 cycles per product against 1000 for the straightforward loop over slots, whose
+// LDS reads the compiler placed right in front of their MFMAs.
+// Counters (monotonic, LDS atomics behind the writer's own LDS traffic; nothing written to global memory is read
+// again in this kernel, so no fence ever waits for a store acknowledgement): w_done (W_kb published), sub_ready (wave
+// 0's tile (kb+1, kb)), panel_cnt (panel tiles, cumulative over the columns), hand_cnt (tiles handed to wave 0),
+// xrow_cnt (finished tiles of the inverse, cumulative over its row blocks), flush_cnt (elimination scratch consumed).
+#ifdef GPMI_DIAG_NOINV  // experiment (tools/build_variant.sh): the factor without the inverse's MFMAs beside it
+#define GPMI_DIAG_NOINV_COND &&kb > 100
+#define GPMI_DIAG_NOINV_SKIP true
+#else
+#define GPMI_DIAG_NOINV_COND
+#define GPMI_DIAG_NOINV_SKIP false
+#endif
+constexpr int DIAG_THREADS = 512;
+constexpr int DIAG_FACTOR = 3, DIAG_INVERSE = 3;     // owner waves of the matrix tiles / of the inverse's tiles
+constexpr int NE_TILES = NBLK * (NBLK + 1) / 2 - 3;  // tiles (i, j), j <= i, without (0,0), (1,0), (1,1): wave 0's from the start
+constexpr int ND_TILES = NBLK * (NBLK - 1) / 2;      // tiles of the inverse below the diagonal
+constexpr int E_SLOTS = (NE_TILES + DIAG_FACTOR - 1) / DIAG_FACTOR;
+constexpr int D_SLOTS = (ND_TILES + DIAG_INVERSE - 1) / DIAG_INVERSE;
+#ifdef GPMI_DIAG_TRACE
+constexpr int ES_BUFS = 2;
+constexpr int DIAG_TRACE_EV = 6;
+constexpr unsigned long long DIAG_TRACE_MAGIC = 0x7ACEull;
+#else
+constexpr int ES_BUFS = 4;
+#endif
+
+// The tiles in the order in which they are dealt: column-major over the lower triangle - the matrix's tiles without
+// (0,0), (1,0), (1,1): (2,0) .. (7,0), (2,1) .. (7,1), (2,2) .. - and the inverse's below the diagonal: (1,0) .. (7,0),
+// (2,1) ..   tile_code(n) = row << 4 | column of the n-th tile, 0xff past the end; evaluated at compile time (the slot
+// index is a template parameter, the owner's index picks one of three constants): a table in memory cost every launch a
+// round of dependent loads before the first instruction of real work.
+constexpr int tile_code(int n, bool inverse) {
+  for (int j = 0; j < NBLK; ++j)
+    for (int i = inverse ? j + 1 : (j < 2 ? 2 : j); i < NBLK; ++i)
+      if (n-- == 0) return i << 4 | j;
+  return 0xff;
+}
+template <int S, bool INV>
+__device__ __forceinline__ int slot_code(int wb) {
+  // the inverse's tiles are dealt from the other end (evens out the slot counts of a SIMD's two waves)
+  constexpr int c0 = tile_code((INV ? 2 : 0) + 3 * S, INV), c1 = tile_code(1 + 3 * S, INV), c2 = tile_code((INV ? 0 : 2) + 3 * S, INV);
+  return wb == 0 ? c0 : (wb == 1 ? c1 : c2);
+}
+template <bool INV, int... S>
+__device__ __forceinline__ void slot_codes(int wb, int* code, std::integer_sequence<int, S...>) {
+  ((code[S] = slot_code<S, INV>(wb)), ...);
+}
+static_assert(DIAG_FACTOR == 3 && DIAG_INVERSE == 3, "slot_code deals to three owners");
+// panel tiles (rows >= c + 2) of the columns 0 .. kb; tiles of the inverse's row blocks 0 .. kb
+__device__ inline int panels_through(int kb) { return (kb + 1) * (NBLK - 2) - kb * (kb + 1) / 2; }
+__device__ inline int xtiles_through(int kb) { return kb * (kb + 1) / 2; }
+// S: first double of block row i, and its row pitch
+__device__ inline int sbase(int i) { return 16 * (8 * i * (i + 1) + i); }
+__device__ inline int spitch(int i) { return 16 * (i + 1) + 1; }
 
 __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __restrict__ A, int64_t ld,
                                                          double* __restrict__ invD,
@@ -210,216 +255,339 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
     }
   };
   if (dbg) t_prev = __builtin_amdgcn_s_memtime();
+  // LDS image of the block's lower 16 x 16 tiles (row pitch odd: row and column walks conflict-free): the panel tiles
+  // (final L) as MFMA operands, and the two tiles per step that change hands
   __shared__ double S[S_DOUBLES];
-  // the inverse as it grows: 16 x 16 block (k2, jb), jb <= k2, at Xl[k2 (k2 + 1) / 2 + jb] (row pitch 17).  Later row
-  // blocks are built from the earlier ones; keeping them here (78 KiB) instead of reading them back through L2 takes
-  // the store fence - the wait for the acknowledgement of every global store of a step - out of the waves' steps
+  // the inverse as it grows: 16 x 16 block (k2, jb), jb <= k2, at Xl[k2 (k2 + 1) / 2 + jb] (row pitch 17): finished
+  // row blocks are the operands of the later ones' sums
   __shared__ double Xl[NBLK * (NBLK + 1) / 2][BS * WP];
-  __shared__ int sub_ready;   // wave 0: sub-diagonal tiles (k + 1, k) finished for k < sub_ready
-  __shared__ int panel_done;  // waves 1-7: 7 (k + 1) once every one of them has finished its panel tiles of column k
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // factor16's scratch, by block index modulo 4: wave 0 is never held up by the wave that writes a block's L out
+  __shared__ __attribute__((aligned(16))) ElimScratch Es[ES_BUFS];
+  __shared__ int w_done, sub_ready, panel_cnt, hand_cnt, xrow_cnt, flush_cnt;
+#ifdef GPMI_DIAG_TRACE
+  // tools only (a build of its own, tools/build_variant.sh trace -DGPMI_DIAG_TRACE: the table takes LDS that the regular
+  // build gives to the elimination's scratch; dbg[22] == DIAG_TRACE_MAGIC: a buffer of 8 x 9 x DIAG_TRACE_EV more words
+  // follows the 24): per wave and step, the clock at up to DIAG_TRACE_EV points (tools/diag_stamps.py prints the timeline)
+  __shared__ unsigned int trace_t[8][NBLK + 1][DIAG_TRACE_EV];
+  const bool tracing = dbg && dbg[22] == DIAG_TRACE_MAGIC;
+  const unsigned long long trace_t0 = tracing ? __builtin_amdgcn_s_memtime() : 0;
+  auto ev = [&](int step, int e) {
+    if (tracing && (threadIdx.x & 63) == 0)
+      trace_t[threadIdx.x >> 6][step][e] = (unsigned int)(__builtin_amdgcn_s_memtime() - trace_t0);
+  };
+  if (tracing)
+    for (int i = threadIdx.x; i < 8 * (NBLK + 1) * DIAG_TRACE_EV; i += DIAG_THREADS) (&trace_t[0][0][0])[i] = 0;
+#else
+  auto ev = [](int, int) {};
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: roles and tile indices stay in SGPRs
   const int fr = lane & 15, fk = lane >> 4;
   if (tid == 0) {
+    w_done = 0;
     sub_ready = 0;
-    panel_done = 0;
+    panel_cnt = 0;
+    hand_cnt = 0;
+    xrow_cnt = 0;
+    flush_cnt = 0;
   }
-  // Wave 0 starts the elimination chain at once: it fetches the first 16 x 16 block straight into the registers of
-  // factor16 (both triangles from the lower one).  Waves 1-7 meanwhile bring the block-lower part of the 128 x 128
-  // block into LDS (coalesced 16-byte loads, all of a thread's loads in flight before its first LDS store) -
-  // everything except block (0, 0), which wave 0 writes itself; the barrier of step 0 is the first point where
-  // anybody reads what somebody else loaded.  (Wave 0 running its sub-diagonal step of step 0 ahead of that barrier, on
-  // operands of its own, was measured: 30.9 instead of 29.5 us - the other waves' step 0, the heaviest, then starts
-  // later and wave 0 waits for it at the next barrier.)
-  d4_t blk = {0.0, 0.0, 0.0, 0.0};  // wave 0: diagonal block kb, in factor16's layout
-  if (wave == 0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = 4 * j + fk;  // entry (i, fr), from the lower triangle
-      blk[j] = A[(int64_t)(i > fr ? i : fr) * ld + (i > fr ? fr : i)];
-    }
-  } else {
-    // the strictly-upper 16-blocks of the inverse are zero: in row r the contiguous columns from 16 ((r >> 4) + 1) on,
-    // one predicated 16-byte store per row and lane (fire-and-forget, acknowledged while the loads are in flight)
-#pragma unroll
-    for (int i = 0; i < (NB - BS + DIAG_BULK - 1) / DIAG_BULK; ++i) {
-      const int r = (wave - 1) + DIAG_BULK * i;
-      const int c = ((r >> 4) + 1) * BS + 2 * lane;
-      if (r < NB - BS && c < NB) *reinterpret_cast<d2_t*>(invD + r * NB + c) = d2_t{0.0, 0.0};
-    }
-    // rows 16 .. 127, one 1 KiB row per wave and load, dealt round-robin to the seven waves (16 rows each); only the
-    // lower triangle is stored - the first readers of a diagonal 16-block (sub_chain, trailing_tile) take its upper
-    // entries from the mirror position
-    const int cc = lane * 2;
-    d2_t v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int r = BS + (wave - 1) + DIAG_BULK * i;
-      v[i] = (cc <= r) ? *reinterpret_cast<const d2_t*>(A + (int64_t)r * ld + cc) : d2_t{0.0, 0.0};
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int r = BS + (wave - 1) + DIAG_BULK * i;
-      const int pr = prow(r) + cc;
-      if (cc <= r) S[pr] = v[i][0];
-      if (cc + 1 <= r) S[pr + 1] = v[i][1];
-    }
-  }
-  lap(0);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the counters are zero for everybody
+  if (wave == 4) return;  // the chain has SIMD 0 to itself
 
-  // A[ib][kb] <- A[ib][kb] * W_kb^T, to LDS and to the matrix in global memory
-  auto panel_tile = [&](int kb, int ib) {
-    const double* W = Xl[kb * (kb + 1) / 2 + kb];
-    d4_t acc = {0.0, 0.0, 0.0, 0.0};
-    const int ra = prow(ib * BS + fr) + kb * BS + fk;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[ra + 4 * q], W[fr * WP + fk + 4 * q], acc, 0, 0, 0);  // B[k][j] = W[j][k]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      S[prow(ib * BS + fk + 4 * r) + kb * BS + fr] = acc[r];
-      A[(int64_t)(ib * BS + fk + 4 * r) * ld + kb * BS + fr] = acc[r];
-    }
-  };
-  // A[ib][jb] -= P_ib P_jb^T  (P = column block kb after the panel step); diagonal tiles in full (symmetric)
-  auto trailing_tile = [&](int kb, int ib, int jb) {
-    d4_t acc;
-    int rc[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = fk + 4 * r;
-      rc[r] = prow(ib * BS + i) + jb * BS + fr;
-      // a diagonal tile is symmetric and only its lower triangle is kept up to date
-      acc[r] = S[(ib == jb && i < fr) ? prow(ib * BS + fr) + jb * BS + i : rc[r]];
-    }
-    const int ra = prow(ib * BS + fr) + kb * BS + fk, rb = prow(jb * BS + fr) + kb * BS + fk;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-S[ra + 4 * q], S[rb + 4 * q], acc, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (ib != jb || fk + 4 * r >= fr) S[rc[r]] = acc[r];
-  };
+  // (every wave of the workgroup is resident, so a counter always arrives; the bound - ~0.1 s - only keeps a bug from
+  // hanging the GPU: the factorisation is then wrong and says so through info)
   auto wait_for = [&](int* counter, int target) {
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+    int polls = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
       __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (++polls > (1 << 21)) {
+        if (lane == 0) *info = col0 + 1;
+        break;
+      }
+    }
+    asm volatile("" ::: "memory");
   };
   auto signal = [&](int* counter, int add) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes are done: in order behind them
     if (lane == 0) __hip_atomic_fetch_add(counter, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
-  // wave 0, step kb: the sub-diagonal tile P = A[kb+1][kb] W^T and the trailing product of tile (kb+1, kb+1), without an
-  // LDS round trip between them: P is computed transposed (P^T = W A^T), which makes its D registers at once the A and
-  // the B operand of the trailing product (P[fr][fk + 4 q] = pt[q]); the result lands in factor16's layout and stays
-  // in registers.  (Same products, same summation order as panel_tile / trailing_tile.)
-  auto sub_chain_regs = [&](int kb, const d4_t& b, d4_t t) -> d4_t {
-    const double* W = Xl[kb * (kb + 1) / 2 + kb];
-    const int ib = kb + 1;
-    d4_t pt = {0.0, 0.0, 0.0, 0.0};
-    const int rb = prow(ib * BS + fr) + kb * BS + fk;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      pt = __builtin_amdgcn_mfma_f64_16x16x4f64(W[fr * WP + fk + 4 * q], b[q], pt, 0, 0, 0);
+
+  if (wave == 0) {
+    // ---------------------------------------------------------------------------------------------- the chain
+    __builtin_amdgcn_s_setprio(3);
+    d4_t blk, t, b;  // diagonal block kb / the next one / the sub-diagonal tile (kb+1, kb), from the lower triangle
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      S[rb + 4 * r] = pt[r];
-      A[(int64_t)(ib * BS + fr) * ld + kb * BS + fk + 4 * r] = pt[r];
+      const int i = 4 * r + fk;  // entry (i, fr)
+      blk[r] = A[(int64_t)(i > fr ? i : fr) * ld + (i > fr ? fr : i)];
     }
-    signal(&sub_ready, 1);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) t = __builtin_amdgcn_mfma_f64_16x16x4f64(-pt[q], pt[q], t, 0, 0, 0);
-    return t;
-  };
-  auto sub_chain = [&](int kb) -> d4_t {
-    const int ib = kb + 1;
-    d4_t t, b;
-    const int rb = prow(ib * BS + fr) + kb * BS + fk;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = fk + 4 * r;  // entry (i, fr) of the symmetric tile: from the lower triangle
-      t[r] = S[prow(ib * BS + (i > fr ? i : fr)) + ib * BS + (i > fr ? fr : i)];
-      b[r] = S[rb + 4 * r];
+    for (int r = 0; r < 4; ++r) {  // its first operands come straight from global memory, under the first elimination
+      const int i = fk + 4 * r;
+      t[r] = A[(int64_t)(BS + (i > fr ? i : fr)) * ld + BS + (i > fr ? fr : i)];
+      b[r] = A[(int64_t)(BS + fr) * ld + fk + 4 * r];
     }
-    return sub_chain_regs(kb, b, t);
-  };
-  // everything of step kb that is not on the elimination chain (waves 1-7)
-  auto bulk = [&](int kb) {
-    const int wb = wave - 1;
-    const int base = kb * BS;
-    const int jb = wb;  // this wave's column of the inverse row block (tiles jb < kb)
-    if (kb + 2 + wb < NBLK) panel_tile(kb, kb + 2 + wb);
-    signal(&panel_done, 1);
-    if (jb < kb) {
-      double bx[NBLK - 1][4];
+    lap(0);
+#pragma nounroll
+    for (int kb = 0; kb < NBLK; ++kb) {
+      if (kb >= ES_BUFS) wait_for(&flush_cnt, kb - ES_BUFS + 1);  // the scratch of step kb - ES_BUFS has been written out
+      ev(kb, 0);
+      const d4_t w = factor16(Es[kb % ES_BUFS], Xl[kb * (kb + 1) / 2 + kb], kb, info, col0, lane, blk);
+      signal(&w_done, 1);
+      ev(kb, 1);
+      lap(4);
+      if (kb + 1 == NBLK) break;
+      // the sub-diagonal tile P = A[kb+1][kb] W^T and the trailing product of tile (kb+1, kb+1), without an LDS round trip
+      // between them: P is computed transposed (P^T = W A^T), which makes its D registers at once the A and the B operand
+      // of the trailing product (P[fr][fk + 4 q] = pt[q]); W comes in registers from factor16 (w[q] = W[fr][fk + 4 q]:
+      // its A-operand layout) and the result stays in registers for the next factor16.
+      const int ib = kb + 1;
+      const int rb = sbase(ib) + fr * spitch(ib) + kb * BS + fk;
+      if (kb > 0) {
+        wait_for(&hand_cnt, 2 * kb);  // both tiles carry every column before kb
 #pragma unroll
-      for (int kk = 0; kk < NBLK - 1; ++kk) {
-        const int k2 = jb + kk;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          bx[kk][q] = (k2 < kb) ? Xl[k2 * (k2 + 1) / 2 + jb][(fk + 4 * q) * WP + fr] : 0.0;  // X[k2][jb]
-      }
-      const double* W = Xl[kb * (kb + 1) / 2 + kb];
-      double wv[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) wv[q] = -W[fr * WP + fk + 4 * q];  // A operand: -W[i = fr][k = fk + 4 q]
-      const int ra = prow(base + fr) + fk;
-      d4_t T = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = 0; kk < NBLK - 1; ++kk) {
-        const int k2 = jb + kk;
-        if (k2 < kb) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            T = __builtin_amdgcn_mfma_f64_16x16x4f64(S[ra + k2 * BS + 4 * q], bx[kk][q], T, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) {
+          const int i = fk + 4 * r;  // entry (i, fr) of the symmetric tile: from the lower triangle
+          t[r] = S[sbase(ib) + (i > fr ? i : fr) * spitch(ib) + ib * BS + (i > fr ? fr : i)];
+          b[r] = S[rb + 4 * r];
         }
       }
-      // the D layout of T (row = fk + 4 r) is exactly the B-operand layout of k-step q = r
-      d4_t X = {0.0, 0.0, 0.0, 0.0};
+      ev(kb, 2);
+      lap(1);
+      d4_t pt = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) X = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q], T[q], X, 0, 0, 0);
+      for (int q = 0; q < 4; ++q) pt = __builtin_amdgcn_mfma_f64_16x16x4f64(w[q], b[q], pt, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        Xl[kb * (kb + 1) / 2 + jb][(fk + 4 * r) * WP + fr] = X[r];
-        invD[(base + fk + 4 * r) * NB + jb * BS + fr] = X[r];
-      }
-    }
-    if (kb + 1 < NBLK) {
-      // trailing tiles (ib, jb), kb < jb <= ib, except (kb + 1, kb + 1) which wave 0 keeps on its chain; they
-      // read the panel tiles of the other waves and wave 0's tile (kb + 1, kb)
-      wait_for(&panel_done, DIAG_BULK * (kb + 1));
-      wait_for(&sub_ready, kb + 1);
-      const int m = NBLK - 1 - kb;
-      const int ntile = m * (m + 1) / 2;
-      for (int t = 1 + wb; t < ntile; t += DIAG_BULK) {
-        int i = 0;
-        while ((i + 1) * (i + 2) / 2 <= t) ++i;
-        const int j = t - i * (i + 1) / 2;
-        trailing_tile(kb, kb + 1 + i, kb + 1 + j);
-      }
-    }
-  };
-
-  for (int kb = 0; kb < NBLK; ++kb) {
-    // The barrier of a step orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): nothing a wave writes to global
-    // memory is read again inside this kernel (L and the inverse go out tile by tile; the inverse is also kept in Xl).
-    if (wave == 0) {
-      factor16(S, Xl[kb * (kb + 1) / 2 + kb], invD, A, ld, kb, info, col0, lane, blk);
-      lap(4);
-    } else if (kb > 0) {
-      bulk(kb - 1);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    lap(1);
-    if (wave == 0 && kb + 1 < NBLK) {
-      blk = sub_chain(kb);
+      for (int r = 0; r < 4; ++r) S[rb + 4 * r] = pt[r];  // (an inverse wave copies it to global memory)
+      signal(&sub_ready, 1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t = __builtin_amdgcn_mfma_f64_16x16x4f64(pt[q], pt[q], t, 0, 0, 1);  // BLGP 1: -A B + C
+      blk = t;
+      ev(kb, 3);
       lap(2);
     }
+  } else if (wave <= 3) {
+    // ---------------------------------------------------------------------------------------------- the factor
+    __builtin_amdgcn_s_setprio(2);
+    const int wb = wave - 1;
+    // The tiles of this wave, in registers for the whole kernel (declared per role: the three roles' registers overlap
+    // instead of adding up): slot s = tile (ti, tj) of the matrix, transposed; je = the step of its next use by somebody
+    // else - its panel step, or, for the tiles (i, i), (i, i - 1) that receive column i - 1 from wave 0 itself, i - 1.
+    d4_t acc[E_SLOTS];
+    int code[E_SLOTS], ti[E_SLOTS], tj[E_SLOTS], je[E_SLOTS];
+    slot_codes<false>(wb, code, std::make_integer_sequence<int, E_SLOTS>{});
+#pragma unroll
+    for (int s = 0; s < E_SLOTS; ++s) {
+      ti[s] = tj[s] = -1;
+      je[s] = 100;
+      if (code[s] != 0xff) {
+        ti[s] = code[s] >> 4;
+        tj[s] = code[s] & 15;
+        je[s] = ti[s] - tj[s] <= 1 ? ti[s] - 1 : tj[s];
+      }
+      acc[s] = d4_t{0.0, 0.0, 0.0, 0.0};
+    }
+    // tiles first used at step `step` (their first update is at step max(je - 2, 0)): global memory -> registers,
+    // transposed (accT[r] = tile[fr][fk + 4 r]; the upper half of a diagonal tile from its mirror image).  Nothing waits for
+    // the data before the first use; requested one step ahead, it is there by then.
+    auto fetch_tiles = [&](int step, bool also_next) {
+#pragma unroll
+      for (int s = 0; s < E_SLOTS; ++s) {
+        const int fu = je[s] >= 2 ? je[s] - 2 : 0;
+        if (ti[s] >= 0 && (fu == step || (also_next && fu == step + 1))) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int row = fr, col = fk + 4 * r;
+            if (ti[s] == tj[s] && col > row) {
+              row = fk + 4 * r;
+              col = fr;
+            }
+            acc[s][r] = A[(int64_t)(ti[s] * BS + row) * ld + tj[s] * BS + col];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    fetch_tiles(0, true);  // steps 0 and 1
+#pragma nounroll
+    for (int kb = 0; kb < NBLK; ++kb) {
+      ev(kb, 0);
+      wait_for(&w_done, kb + 1);
+      ev(kb, 1);
+      const double* W = Xl[kb * (kb + 1) / 2 + kb];
+      // A: panel step of the tiles of column kb (rows kb + 2 ..): P^T = W tile^T; P to LDS and to global memory
+      double wv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wv[q] = W[fr * WP + fk + 4 * q];  // A operand: W[fr][fk + 4 q]
+      int npanel = 0;
+#pragma unroll
+      for (int s = 0; s < E_SLOTS; ++s)
+        if (tj[s] == kb && ti[s] >= kb + 2) {
+          d4_t pt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pt = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q], acc[s][q], pt, 0, 0, 0);
+          const int rb = sbase(ti[s]) + fr * spitch(ti[s]) + kb * BS + fk;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) S[rb + 4 * r] = pt[r];  // (an inverse wave copies it to global memory)
+          ++npanel;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      if (npanel) signal(&panel_cnt, npanel);
+      ev(kb, 2);
+      if (kb + 1 == NBLK) break;
+      wait_for(&panel_cnt, panels_through(kb));
+      wait_for(&sub_ready, kb + 1);
+      ev(kb, 3);
+      // E: tile (i, j) -= P_i,c P_j,c^T, transposed: accT -= P_j,c P_i,c^T (the MFMA's BLGP field negates A).  First the
+      // tiles that are used next at step kb + 1 (je == kb + 1: column kb is their last; the two that change hands go to
+      // LDS at once - wave 0 is waiting for them), then the tiles with je == kb + 2: columns 0 .. kb in one chain on the
+      // accumulator, two columns per round on alternating operand registers, the next column's operands requested
+      // before the MFMAs of the current one.
+      auto column = [&](int s, int ra, int rb, int c, double (&a)[4], double (&b)[4]) {
+        (void)s;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          a[q] = S[ra + c * BS + 4 * q];
+          b[q] = S[rb + c * BS + 4 * q];
+        }
+      };
+#pragma unroll
+      for (int s = 0; s < E_SLOTS; ++s)
+        if (je[s] == kb + 1) {
+          const int i = ti[s], j = tj[s];
+          const int ra = sbase(j) + fr * spitch(j) + fk, rb = sbase(i) + fr * spitch(i) + fk;
+          double a[4], b[4];
+          column(s, ra, rb, kb, a, b);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[s], 0, 0, 1);
+          if (i - j <= 1) {
+            const int rs = sbase(i) + fr * spitch(i) + j * BS + fk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (i != j || fk + 4 * r <= fr) S[rs + 4 * r] = acc[s][r];
+            signal(&hand_cnt, 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+      for (int s = 0; s < E_SLOTS; ++s)
+        if (je[s] == kb + 2) {
+          const int i = ti[s], j = tj[s];
+          const int ra = sbase(j) + fr * spitch(j) + fk, rb = sbase(i) + fr * spitch(i) + fk;
+          double a0[4], b0[4], a1[4], b1[4];
+          column(s, ra, rb, 0, a0, b0);
+          for (int c = 0; c <= kb; c += 2) {
+            column(s, ra, rb, c + 1 <= kb ? c + 1 : c, a1, b1);  // (an odd last round re-reads its own column: no branch)
+            __builtin_amdgcn_sched_barrier(0);  // the requests above stay above the MFMAs below
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], acc[s], 0, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 > kb) break;
+            column(s, ra, rb, c + 2 <= kb ? c + 2 : c + 1, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], acc[s], 0, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      // The tiles first used at the next step but one.  Requested here, they arrive while the wave waits for the chain;
+      // this wave issues no other vector-memory instruction (the stores of what it computes are the inverse waves'
+      // job), so the s_waitcnt vmcnt(0) in front of a tile's first use waits for nothing else - in particular for no
+      // store acknowledgement.
+      fetch_tiles(kb + 2, false);
+      ev(kb, 4);
+    }
+  } else {
+    // ---------------------------------------------------------------------------------------------- the inverse
+    __builtin_amdgcn_s_setprio(0);
+    const int wb = wave - 5;
+    d4_t acc[D_SLOTS];  // slot s: the sum T[ti][tj]
+    int code[D_SLOTS], ti[D_SLOTS], tj[D_SLOTS];
+    slot_codes<true>(wb, code, std::make_integer_sequence<int, D_SLOTS>{});
+#pragma unroll
+    for (int s = 0; s < D_SLOTS; ++s) {
+      ti[s] = tj[s] = -1;
+      if (code[s] != 0xff) {
+        ti[s] = code[s] >> 4;
+        tj[s] = code[s] & 15;
+      }
+      acc[s] = d4_t{0.0, 0.0, 0.0, 0.0};
+    }
+    // (the strictly-upper 16-blocks of the inverse are zero since the buffer's allocation: api.hip, lane_alloc)
+#pragma nounroll
+    for (int kb = 0; kb < NBLK; ++kb) {
+      ev(kb, 0);
+      wait_for(&w_done, kb + 1);
+      ev(kb, 1);
+      const double* W = Xl[kb * (kb + 1) / 2 + kb];
+      // B: row block kb of the inverse, X[kb][jb] = -W T[kb][jb] (T in the D layout is the B operand)
+      double wv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wv[q] = W[fr * WP + fk + 4 * q];
+      int nx = 0;
+#pragma unroll
+      for (int s = 0; s < D_SLOTS; ++s)
+        if (ti[s] == kb) {
+          ++nx;
+          if (GPMI_DIAG_NOINV_SKIP) continue;
+          d4_t X = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) X = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q], acc[s][q], X, 0, 0, 1);  // -W T
+          double* Xt = Xl[kb * (kb + 1) / 2 + tj[s]];
+          double* dst = invD + (kb * BS + fk) * NB + tj[s] * BS + fr;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            Xt[(fk + 4 * r) * WP + fr] = X[r];
+            dst[4 * r * NB] = X[r];
+          }
+        }
+      if (nx) signal(&xrow_cnt, nx);
+      // the diagonal 16-blocks of L and of the inverse that the elimination of step kb left in LDS
+      if (wb == kb % DIAG_INVERSE) {
+        flush_diag(Es[kb % ES_BUFS], W, invD, A, ld, kb, lane);
+        signal(&flush_cnt, 1);
+      }
+      ev(kb, 2);
+      if (kb + 1 == NBLK) break;
+      wait_for(&xrow_cnt, xtiles_through(kb));
+      wait_for(&panel_cnt, panels_through(kb));
+      wait_for(&sub_ready, kb + 1);
+      ev(kb, 3);
+      // column kb of L is final in LDS: to global memory (these waves never load, so nothing of theirs ever waits for
+      // a store acknowledgement)
+      for (int i = kb + 1 + wb; i < NBLK; i += DIAG_INVERSE) {
+        const int rs = sbase(i) + fr * spitch(i) + kb * BS + fk;
+        double* dst = A + (int64_t)(i * BS + fr) * ld + kb * BS + fk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[4 * r] = S[rs + 4 * r];
+      }
+      // D: T[i][jb] += L[i][kb] X[kb][jb] for the row blocks i below, jb <= kb
+#pragma unroll
+      for (int s = 0; s < D_SLOTS; ++s)
+        if (tj[s] >= 0 && tj[s] <= kb && kb < ti[s] GPMI_DIAG_NOINV_COND) {
+          const double* X = Xl[kb * (kb + 1) / 2 + tj[s]];
+          const int ra = sbase(ti[s]) + fr * spitch(ti[s]) + kb * BS + fk;
+          double a[4], b[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            a[q] = S[ra + 4 * q];
+            b[q] = X[(fk + 4 * q) * WP + fr];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[s], 0, 0, 0);
+        }
+      ev(kb, 4);
+    }
   }
-  if (wave > 0) bulk(NBLK - 1);
+  ev(NBLK, 0);
   lap(3);
   if (dbg) {
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
+#ifdef GPMI_DIAG_TRACE
+    if (tracing)
+      for (int i = tid; i < 8 * (NBLK + 1) * DIAG_TRACE_EV; i += DIAG_THREADS - 64) dbg[24 + i] = (&trace_t[0][0][0])[i];
+#endif
     if (tid == 0) {
       for (int i = 0; i < 6; ++i) dbg[16 + i] = acc_t[i];
       dbg[8] = __builtin_amdgcn_s_memrealtime();

@@ -453,29 +453,39 @@ bool ensure_masked_pair(gpmi_ctx* c, Lane& L, int k);  // api.hip
 namespace {
 std::mutex g_flow_mu;
 hipEvent_t g_flow_ev[64] = {nullptr};
-bool g_flow_busy[64] = {false};
+// state of a device's gate: FREE, ENQUEUING (a caller is between flow_gate_try and flow_gate_leave: the event does not
+// describe its launch yet, so nobody may query it), RECORDED (the event marks the end of the launch in flight)
+enum FlowGate { GATE_FREE = 0, GATE_ENQUEUING, GATE_RECORDED };
+int g_flow_state[64] = {GATE_FREE};
 
 bool flow_gate_try(int device) {
   if (device < 0 || device >= 64) return false;
   std::lock_guard<std::mutex> lk(g_flow_mu);
-  if (g_flow_busy[device]) {
+  if (g_flow_state[device] == GATE_ENQUEUING) return false;
+  if (g_flow_state[device] == GATE_RECORDED) {
     if (hipEventQuery(g_flow_ev[device]) != hipSuccess) {
       (void)hipGetLastError();
       return false;
     }
-    g_flow_busy[device] = false;
+    g_flow_state[device] = GATE_FREE;
   }
   if (!g_flow_ev[device] && hipEventCreateWithFlags(&g_flow_ev[device], hipEventDisableTiming) != hipSuccess) {
     g_flow_ev[device] = nullptr;
     (void)hipGetLastError();
     return false;
   }
-  g_flow_busy[device] = true;  // until flow_gate_leave's event has completed
+  g_flow_state[device] = GATE_ENQUEUING;  // until flow_gate_leave has recorded the event behind the launch
   return true;
 }
-void flow_gate_leave(int device, hipStream_t s) {
+// `launched` = false: nothing was enqueued (set-up failed), the gate is free again
+void flow_gate_leave(int device, hipStream_t s, bool launched = true) {
   std::lock_guard<std::mutex> lk(g_flow_mu);
-  (void)hipEventRecord(g_flow_ev[device], s);
+  if (launched && hipEventRecord(g_flow_ev[device], s) == hipSuccess) {
+    g_flow_state[device] = GATE_RECORDED;
+  } else {
+    (void)hipGetLastError();
+    g_flow_state[device] = GATE_FREE;
+  }
 }
 }  // namespace
 
@@ -530,7 +540,7 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
         hipMemcpy(lane.flow_off, fl.off.data(), sizeof(int) * fl.off.size(), hipMemcpyHostToDevice) != hipSuccess) {
       (void)hipGetLastError();
       potrf_flow_free(lane);
-      flow_gate_leave(c->device, sf);
+      flow_gate_leave(c->device, sf, false);
       return false;
     }
     lane.flow_flops_update = fl.flops_update;

@@ -43,6 +43,7 @@ def _record(what, r, tol):
 
 
 ACHIEVED = []
+PT_SAMPLE_TOL = 1e-10  # sample paths of the teacher-forced chains (measured: see the achieved-error table)
 
 
 def check_each(a, b, tol=RTOL, what="", floor=1e-6, etol=1e-7):
@@ -427,7 +428,9 @@ def test_parallel_tempering_on_device_reproduces_reference_trace(golden, gp_mod)
 
     ch = make_chain(1.0, 100)
     ch.advance(60)
-    assert np.allclose(ch.get_sample(burn=0), g["single_samples"], rtol=0, atol=1e-8)
+    # accept / reject decisions are bit-determined; the sample VALUES inherit the device likelihood's last digits
+    # through the proposal-width adaptation (gibbs.py:132-148), so they are held to a tolerance, not to equality
+    check(np.asarray(ch.get_sample(burn=0)), g["single_samples"], PT_SAMPLE_TOL, "single chain samples")
     check(np.array(ch.probs), g["single_probs"], 1e-10)
 
     chains = [make_chain(t, 1000 + 10 * k) for k, t in enumerate(g["temps"])]
@@ -437,7 +440,7 @@ def test_parallel_tempering_on_device_reproduces_reference_trace(golden, gp_mod)
     random.seed(9)
     pt.advance(40, swap_interval=5)
     for k, c in enumerate(pt.return_chains()):
-        assert np.allclose(c.get_sample(burn=0), g[f"pt_samples_{k}"], rtol=0, atol=1e-8), k
+        check(np.asarray(c.get_sample(burn=0)), g[f"pt_samples_{k}"], PT_SAMPLE_TOL, f"tempered chain {k} samples")
         check(np.array(c.probs), g[f"pt_probs_{k}"], 1e-10)
     assert np.array_equal(pt.successful_swaps, g["pt_successful"])
     assert pt.posterior_evaluations >= 4 * 40 * 3
