@@ -32,7 +32,9 @@ Extra objects on the JSON line:
                 rocprofv3 --pmc runs cannot be part of this run); `kernels` lists the other kernels of a step
                 (K-build, the two triangular sweeps, the predict TRSM) from an extra, un-timed pass with events.
   cpu_baseline  the CPU oracle (NumPy/SciPy restatement of the reference, kind "port") timed on the
-                host cores on a bounded sample of the same workload (rank 0, N=1 only)
+                host cores on a bounded sample of the same workload (rank 0, N=1 only); `at_metric_size` (round 4):
+                ONE run of the same oracle at the metric's own N, d, M with K-build / potrf / solves / predict seconds
+                apart (--no-cpu-metric-size skips it: about a minute of host time)
 """
 import argparse
 import json
@@ -115,6 +117,49 @@ def cpu_baseline(n_cpu, d, m_cpu, runs=3):
         f"K-build as in the reference, numpy.linalg.cholesky, scipy.linalg.solve_triangular), warm-up + median of {runs} "
         f"runs: {dt:.1f} s each; {cpu}, {os.cpu_count()} logical CPUs, {blas} with {threads} threads, {versions}",
         "faithful": faithful,
+    }
+
+
+def cpu_at_metric_size(n, d, m):
+    """ONE memory-lean oracle run at the metric's own configuration, per phase: the
+    same NumPy / LAPACK calls as the reference path (regression.py:218-244, 188-216), K-build row-chunked as in
+    oracle/gp_oracle.py (the reference's N x N x d tensors need 52 GB at N = 16384, d = 8)."""
+    from oracle import gp_oracle as orc  # checker / baseline only
+    import workloads as wl
+    from numpy.linalg import cholesky
+    from scipy.linalg import solve_triangular
+
+    x, y, e = wl.synthetic_dataset(2, n, d)
+    theta = wl.timing_theta(wl.SE, y, d)
+    pts = wl.query_points(2, m, d)
+    t = [time.perf_counter()]
+
+    def lap():
+        t.append(time.perf_counter())
+        return t[-1] - t[-2]
+
+    K = orc.se_build(x, theta[1:])  # covariance.py:247-255
+    K[np.diag_indices(n)] += e**2   # regression.py:239 "+ self.sig"
+    t_build = lap()
+    L = cholesky(K)                 # regression.py:241
+    del K
+    t_potrf = lap()
+    alpha = solve_triangular(L.T, solve_triangular(L, y - theta[0], lower=True))  # regression.py:242-244
+    t_solve = lap()
+    K_qx = orc.se_cross(pts, x, theta[1:])                 # regression.py:209-210, batched over the query points
+    mu = K_qx @ alpha + theta[0]
+    v = solve_triangular(L, K_qx.T, lower=True)            # regression.py:213
+    sig = np.sqrt(np.abs(np.exp(theta[1]) ** 2 - (v**2).sum(axis=0)))
+    t_pred = lap()
+    total = t[-1] - t[0]
+    flops = n**3 / 3.0 + m * float(n) ** 2
+    return {
+        "value": flops / total / 1e9,
+        "unit": "GFLOP/s",
+        "seconds": {"k_build": t_build, "potrf": t_potrf, "alpha_solves": t_solve, "predict": t_pred, "total": total},
+        "potrf_gflops": n**3 / 3.0 / t_potrf / 1e9,
+        "sample": f"ONE run of the memory-lean oracle at the metric's own size, SE N={n} d={d} M={m} (no warm-up: a second "
+        f"run would double the {total:.0f} s); checksum mu[0]={float(mu[0]):.12g} sig[0]={float(sig[0]):.6g}",
     }
 
 
@@ -285,6 +330,8 @@ def main():
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--m", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-metric-size", action="store_true",
+                    help="skip the one CPU run at the metric's own size (about a minute of host time)")
     ap.add_argument("--no-sharded", action="store_true", help="skip the config 3 / config 5 runs behind the timed region")
     args = ap.parse_args()
 
@@ -512,6 +559,8 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
             line["roofline"]["kernels"] = kernel_rows(eng, step, _lib, N, M)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(4096, d, 256)  # ~10-15 s of host work in all
+            if not args.no_cpu_metric_size:
+                line["cpu_baseline"]["at_metric_size"] = cpu_at_metric_size(N, d, M)
         print(json.dumps(line), flush=True)
 
 

@@ -39,13 +39,17 @@ thread_local std::string g_create_err;
     }                          \
   } while (0)
 
-// a negative `info` is written by the flag-ordered kernels (triangular sweeps, potrf_flow.hip) when a poll timed out
-#define INFOCHK(ctx, inf)                                                              \
-  do {                                                                                 \
-    if ((inf) < 0) {                                                                   \
-      (ctx)->err = "internal error: a flag-ordered kernel timed out (triangular sweep / tile-task factorisation)"; \
-      return GPMI_ERR_INTERNAL;                                                        \
-    }                                                                                  \
+// a negative `info` is written by the flag-ordered kernels when a poll timed out: GPMI_INFO_FLOW_TIMEOUT by the tile-task
+// factorisation (potrf_flow.hip) - the one case the stream-ordered schedule (GPMI_OPT_NO_FLOW) cures, marked "[flow-tail]"
+// in the error text for the caller that wants to repeat the call -, GPMI_ERR_INTERNAL by the triangular sweeps
+#define INFOCHK(ctx, inf)                                                                                     \
+  do {                                                                                                        \
+    if ((inf) < 0) {                                                                                          \
+      (ctx)->err = (inf) == GPMI_INFO_FLOW_TIMEOUT                                                            \
+                       ? "internal error: the tile-task factorisation timed out [flow-tail]"                  \
+                       : "internal error: a flag-ordered triangular sweep timed out";                         \
+      return GPMI_ERR_INTERNAL;                                                                               \
+    }                                                                                                         \
   } while (0)
 
 constexpr int RED_SLOTS = 8192;  // per-lane result slots for batched evaluations
@@ -629,6 +633,8 @@ int gpmi_set_streams(gpmi_ctx* c, int n_streams) {
   if (!c) return GPMI_ERR_ARG;
   ARGCHK(c, c->n > 0, "gpmi_set_data has not been called");
   ARGCHK(c, n_streams >= 1 && n_streams <= 256, "n_streams out of range");
+  ARGCHK(c, c->bpend[0] == 0 && c->bpend[1] == 0,
+         "an asynchronous batch is pending on the lanes this call may release (gpmi_lml_batch_wait first)");
   if (int rc = set_device(c)) return rc;
   while ((int)c->lanes.size() > 1 + n_streams) {
     lane_free(c->lanes.back());
@@ -825,10 +831,11 @@ int gpmi_lml_batch_submit(gpmi_ctx* c, int kernel, int64_t T, const double* thet
   ARGCHK(c, c->bpend[slot] == 0, "this slot has a batch pending (gpmi_lml_batch_wait first)");
   if (int rc = set_device(c)) return rc;
   if (int rc = ensure_lanes(c, 3)) return rc;
-  // each slot owns half of the workspace: at least 2 T matrices - and room for 64 per slot from the start where the
-  // memory cap of ensure_batch_ws allows, because the workspace can only grow while nothing is pending
+  // each slot owns half of the workspace: at least 2 T matrices - and, because the workspace can only grow while nothing
+  // is pending, all that a slot may ever be asked for (128 evaluations) from the first submission on, as far as the
+  // memory cap of ensure_batch_ws allows: a later, larger group of chains then fits whatever the first one was
   if (c->bpend[1 - slot] == 0) {
-    if (int rc = ensure_batch_ws(c, (int)(2 * T > 128 ? 2 * T : 128))) return rc;  // (a no-op once it is that large)
+    if (int rc = ensure_batch_ws(c, 256)) return rc;  // (a no-op once it is that large)
     ARGCHK(c, c->bcap >= 2 * T, "not enough device memory for two batches of this size");
   } else {
     ARGCHK(c, c->bcap >= 2 * T,

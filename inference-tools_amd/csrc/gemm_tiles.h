@@ -529,7 +529,7 @@ __device__ __forceinline__ void flow_hook_enter(const FlowHook& h) {
         if ((++spins & 63) == 0 && flow_ld(h.abort)) break;
         if (spins > FLOW_SPIN_LIMIT) {
           __hip_atomic_store(h.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (h.info) atomicCAS(h.info, 0, GPMI_ERR_INTERNAL);
+          if (h.info) atomicCAS(h.info, 0, GPMI_INFO_FLOW_TIMEOUT);  // the chain launches of the tile-task factorisation
           break;
         }
       }

@@ -10,6 +10,7 @@
 
 constexpr int GPMI_NB = 128;     // tile / inner block size: every device matrix dimension is a multiple
 constexpr int GPMI_MAX_D = 64;   // max spatial dimensions handled by the covariance kernels
+constexpr int GPMI_INFO_FLOW_TIMEOUT = -6;  // `info` of a factorisation whose tile-task kernel gave up polling (api.hip: INFOCHK)
 constexpr int GPMI_NPAIRS = 1;   // CU-masked stream pairs of the look-ahead (32 | 224 CUs)
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -36,7 +37,7 @@ struct ProfSlot {
 // One independent evaluation lane: a stream with its own n x n scratch matrix and vectors.
 struct Lane {
   hipStream_t stream = nullptr;    // full-chip stream: covariance build, solves, small factorisations
-  bool owns_stream = true;         // false: one of the process-wide pooled streams (api.hip: pooled_stream)
+  bool owns_stream = true;         // false (lanes 2..): the stream is lane 0's or lane 1's (api.hip: lane_streams)
   // look-ahead pairs (CU-masked, disjoint; lanes 0 and 1 only, created with the lane): pair k factors the next panel on
   // gpmi_ctx::pair_cus[k] CUs (sp) while the trailing update runs on all the others (su)
   hipStream_t sp[GPMI_NPAIRS] = {nullptr};

@@ -39,7 +39,7 @@
 // and 256 VGPRs admit, but another process may hold those slots) is adopted after 50 us by a workgroup that is.
 // The only cross-launch dependency is between the chain stream and the task kernel, which run on disjoint CU masks.
 // Every poll is bounded: a time-out (a bug or a serialising profiler, never a wait) sets the abort word, every
-// poller gives up, and the host reports GPMI_ERR_INTERNAL through `info` instead of hanging the GPU.
+// poller gives up, and the host reports GPMI_ERR_INTERNAL (info = GPMI_INFO_FLOW_TIMEOUT) instead of hanging the GPU.
 // tools/sim/flow_sim.py holds the same task list as an executable model (NumPy replay in random admissible order
 // + a discrete-event timing model that chose the queue layout).
 #include <algorithm>
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void flow_task_kernel(FlowArgs a) {
         if (spins > FLOW_SPIN_LIMIT) {
           if (lane == 0) {
             __hip_atomic_store(fl + FL_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.info) atomicCAS(a.info, 0, GPMI_ERR_INTERNAL);
+            if (a.info) atomicCAS(a.info, 0, GPMI_INFO_FLOW_TIMEOUT);
           }
           got = -1;
           break;
@@ -500,7 +500,17 @@ bool potrf_flow_enabled(gpmi_ctx* c, Lane& lane, int m) {
     const char* e = std::getenv("GPMI_FLOW_MIN");
     return e ? std::atoi(e) : 8;
   }();
-  return on && !c->no_flow && m >= min_rows && m < 4096 && ensure_masked_pair(c, lane, 0);
+  // the task kernel keeps a 64 KiB operand ring + 4 KiB of list state in static LDS and counts on two workgroups per CU
+  // (gfx950: 160 KiB per CU); a part with less takes the stream-ordered schedule
+  static const bool lds_ok = [&] {
+    int per_block = 0;
+    if (hipDeviceGetAttribute(&per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    return per_block >= 72 * 1024;
+  }();
+  return on && lds_ok && !c->no_flow && m >= min_rows && m < 4096 && ensure_masked_pair(c, lane, 0);
 }
 
 void potrf_flow_free(Lane& lane) {
@@ -526,7 +536,8 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
     const int v = e ? std::atoi(e) : 2;
     return (v == 1 || v == 2) ? v : 2;
   }();
-  const int nwg = wgs_per_cu * ncu_u;
+  // (a lone resident workgroup must be able to adopt every list: never more lists than FLOW_MAX_LISTS)
+  const int nwg = wgs_per_cu * ncu_u < FLOW_MAX_LISTS ? wgs_per_cu * ncu_u : FLOW_MAX_LISTS;
   if (!flow_gate_try(c->device)) return false;
   if (lane.flow_m != m || lane.flow_nwg != nwg) {
     potrf_flow_free(lane);

@@ -104,17 +104,18 @@ class GpOptimiser:
         value = np.asarray(new_y)
         error = _optional_array(new_y_err)
 
-        # the record of how promising this point looked under the *previous* model
-        self.acquisition_max_history.append(self.acquisition(point))
-        self.convergence_metric_history.append(self.acquisition.convergence_metric(point))
-        self.iteration_history.append(self.y.size + 1)
-
         if self.y_err is not None and error is None:
             raise ValueError(msg.NEW_Y_ERR_REQUIRED)
+        # how promising this point looked under the *previous* model: evaluated now, recorded only once the model has
+        # accepted the point - a failed factor update (a duplicate proposal at fixed hyper-parameters: pivot <= 0,
+        # LinAlgError) leaves x / y AND the three histories as they were
+        acq_value = self.acquisition(point)
+        metric = self.acquisition.convergence_metric(point)
         if self.reuse_hyperpars:
-            # the model first: a point that makes the factor update fail (a duplicate proposal at fixed
-            # hyper-parameters: pivot <= 0, LinAlgError) must leave the optimiser's own record unchanged too
             self.gp.add_point(point, value, error)
+        self.acquisition_max_history.append(acq_value)
+        self.convergence_metric_history.append(metric)
+        self.iteration_history.append(self.y.size + 1)
         self.x = np.append(self.x, point, axis=0)
         self.y = np.append(self.y, value)
         if self.y_err is not None:

@@ -278,25 +278,35 @@ def advance_ladders(ladders, n: int, swap_interval=10, batch_posterior=None):
         ready = deque(range(len(groups)))  # groups with work, not in flight
         flying = deque()                   # (slot, group), oldest first
         free = [0, 1]
-        while ready or flying:
-            while ready and free:
-                g = ready.popleft()
-                for c in act[g]:
-                    prop[c][par[c]] = chains[c].params[par[c]].proposal()
-                slot = free.pop(0)
-                model.marginal_likelihood_batch_submit(array([prop[c] for c in act[g]]), slot)
-                flying.append((slot, g))
-            slot, g = flying.popleft()
-            vals = model.marginal_likelihood_batch_wait(slot)
-            free.append(slot)
-            evals += len(act[g])
-            still, finished = _settle(act[g], vals)
-            for k in finished:
-                still += _next_interval(k)
-            still.sort()
-            act[g] = still
-            if still:
-                ready.append(g)
+        try:
+            while ready or flying:
+                while ready and free:
+                    g = ready.popleft()
+                    for c in act[g]:
+                        prop[c][par[c]] = chains[c].params[par[c]].proposal()
+                    slot = free.pop(0)
+                    model.marginal_likelihood_batch_submit(array([prop[c] for c in act[g]]), slot)
+                    flying.append((slot, g))
+                slot, g = flying.popleft()
+                vals = model.marginal_likelihood_batch_wait(slot)
+                free.append(slot)
+                evals += len(act[g])
+                still, finished = _settle(act[g], vals)
+                for k in finished:
+                    still += _next_interval(k)
+                still.sort()
+                act[g] = still
+                if still:
+                    ready.append(g)
+        finally:
+            # an exception (a KeyboardInterrupt in a long run) between submit and wait must not leave a slot pending:
+            # every later batch call on this model would be refused
+            while flying:
+                slot, _ = flying.popleft()
+                try:
+                    model.marginal_likelihood_batch_wait(slot)
+                except Exception:
+                    pass
         return evals
     held = []
     while active or held:
