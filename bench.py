@@ -52,6 +52,9 @@ import numpy as np  # noqa: E402
 PEAK_FP64_MFMA_TFLOPS = 78.6  # 256 CU x 4 SIMD x 2048 FLOP / 64 clk x 2.4 GHz (tools/mfma_probe.hip)
 
 
+RCCL_INFO = {}  # rccl_ranks_seen, dataset_broadcast (multi-rank runs with a live communicator)
+
+
 def cpu_baseline(n_cpu, d, m_cpu, runs=3):
     """Oracle (port of the reference path: same NumPy / LAPACK calls) on the host cores: fit + batched predict at a
     bounded size, one warm-up at a quarter of the size, then the median of `runs` runs."""
@@ -409,6 +412,17 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
         # every rank must take the same path
         oks = rdv.allgather_obj(ok)
         gather = "rccl" if all(oks) else f"file-fallback ({'; '.join(str(o) for o in oks)}{'' if ok else ' ' + why})"
+        if gather == "rccl":
+            # the start-up distribution of SURVEY section 8(e) on the live communicator: rank 0's data set to every rank by
+            # ncclBroadcast, compared with the copy each rank generated itself; and the rank count RCCL itself reports
+            try:
+                RCCL_INFO["rccl_ranks_seen"] = eng.comm_count()
+                bx, by, be = sharding.broadcast_dataset(x, y, e, comm=eng) if rank == 0 else sharding.broadcast_dataset(comm=eng)
+                same = bool(np.array_equal(bx, x) and np.array_equal(by, y) and np.array_equal(be, e))
+                RCCL_INFO["dataset_broadcast"] = "ncclBroadcast from rank 0: " + (
+                    "identical to the locally generated copy" if same else "DIFFERS from the locally generated copy")
+            except Exception as err:
+                RCCL_INFO["dataset_broadcast"] = f"failed: {type(err).__name__}: {err}"
 
     def allgather(vec):
         if gather == "rccl":
@@ -496,6 +510,7 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                 "flop_per_step": flops_step,
                 "pct_fp64_mfma_peak_whole_step": 100.0 * value / world / 1e3 / PEAK_FP64_MFMA_TFLOPS,
                 "parallelism": f"{world} independent hyper-parameter evaluations (one per GPU), result all-gather: {gather}",
+                **RCCL_INFO,
             },
             "roofline": {
                 "kernel": "gemm_dma_kernel<1, 0> = <TILES_LOWER, OP_SUB>: 128x128 tiles, operands through an LDS-DMA ring (potrf trailing SYRK update, K=512; the full rounds of every launch with >= 384 tiles)",

@@ -286,10 +286,18 @@ int gpmi_linv_posterior_dense(gpmi_ctx* ctx, const double* K_host, const double*
  * (theta, log-prob) messages of the tempering processes (mcmc/parallel.py:195-201).  One process per
  * GPU.  Rank 0 calls gpmi_comm_unique_id (128 bytes), the caller distributes the id over any host
  * channel, every rank calls gpmi_comm_init, then gpmi_comm_allgather gathers `count` doubles per
- * rank (recv_host: world * count, in rank order).  librccl is loaded on first use. */
+ * rank (recv_host: world * count, in rank order).  librccl is loaded on first use.
+ * No data-path collective exists: the units (hyper-parameter vectors, optimiser starts, tempering ladders) are
+ * independent; the communicator carries the data set once at start-up and a few doubles per unit at the end. */
 int gpmi_comm_unique_id(char* id_out_128);
 int gpmi_comm_init(gpmi_ctx* ctx, int rank, int world, const char* id_128);
 int gpmi_comm_allgather(gpmi_ctx* ctx, const double* send_host, double* recv_host, int64_t count);
+/* Start-up distribution of the data set: `count` doubles of rank `root`'s buf_host to every rank's buf_host (one
+ * ncclBroadcast).  Replaces the pickling of the whole regressor into every worker process
+ * (regression.py:597-601, mcmc/parallel.py:127-136): x, y, y_err are all a rank needs to build its own. */
+int gpmi_comm_broadcast(gpmi_ctx* ctx, double* buf_host, int64_t count, int root);
+/* The number of ranks RCCL sees in the communicator (ncclCommCount). */
+int gpmi_comm_count(gpmi_ctx* ctx, int* ranks);
 int gpmi_comm_destroy(gpmi_ctx* ctx);
 
 /* Append ONE training point to the fitted model at unchanged hyper-parameters in O(n^2): the new row of the Cholesky

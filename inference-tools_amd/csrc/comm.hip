@@ -19,6 +19,8 @@ struct ncclUniqueIdLike {
 typedef int (*fn_get_unique_id)(ncclUniqueIdLike*);
 typedef int (*fn_comm_init_rank)(void**, int, ncclUniqueIdLike, int);
 typedef int (*fn_all_gather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*fn_broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_comm_count)(void*, int*);
 typedef int (*fn_comm_destroy)(void*);
 typedef const char* (*fn_get_error_string)(int);
 
@@ -27,6 +29,8 @@ struct Rccl {
   fn_get_unique_id get_unique_id = nullptr;
   fn_comm_init_rank comm_init_rank = nullptr;
   fn_all_gather all_gather = nullptr;
+  fn_broadcast broadcast = nullptr;   // optional symbols: absent ones make their entry points fail, not the library
+  fn_comm_count comm_count = nullptr;
   fn_comm_destroy comm_destroy = nullptr;
   fn_get_error_string get_error_string = nullptr;
 };
@@ -45,6 +49,8 @@ Rccl* rccl() {
       r.get_unique_id = (fn_get_unique_id)dlsym(r.lib, "ncclGetUniqueId");
       r.comm_init_rank = (fn_comm_init_rank)dlsym(r.lib, "ncclCommInitRank");
       r.all_gather = (fn_all_gather)dlsym(r.lib, "ncclAllGather");
+      r.broadcast = (fn_broadcast)dlsym(r.lib, "ncclBroadcast");
+      r.comm_count = (fn_comm_count)dlsym(r.lib, "ncclCommCount");
       r.comm_destroy = (fn_comm_destroy)dlsym(r.lib, "ncclCommDestroy");
       r.get_error_string = (fn_get_error_string)dlsym(r.lib, "ncclGetErrorString");
       if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy) r.lib = nullptr;
@@ -143,6 +149,64 @@ int gpmi_comm_allgather(gpmi_ctx* c, const double* send_host, double* recv_host,
       e != hipSuccess)
     return hip_fail(c, "gather download", e);
   if (hipError_t e = hipStreamSynchronize(s); e != hipSuccess) return hip_fail(c, "gather synchronise", e);
+  return GPMI_OK;
+}
+
+// Start-up distribution of the data set: rank `root`'s buffer to every rank, in place.  The
+// reference ships x, y, y_err to its workers by pickling the whole GpRegressor into them (regression.py:597-601,
+// mcmc/parallel.py:127-136); here it is one ncclBroadcast of a few hundred kilobytes over xGMI.
+int gpmi_comm_broadcast(gpmi_ctx* c, double* buf_host, int64_t count, int root) {
+  if (!c) return GPMI_ERR_ARG;
+  Rccl* r = rccl();
+  if (!r || !c->comm) {
+    c->err = "gpmi_comm_init has not been called";
+    return GPMI_ERR_ARG;
+  }
+  if (!r->broadcast) {
+    c->err = "this librccl has no ncclBroadcast";
+    return GPMI_ERR_NODEVICE;
+  }
+  if (!buf_host || count <= 0 || root < 0 || root >= c->comm_world) {
+    c->err = "bad buffer / count / root";
+    return GPMI_ERR_ARG;
+  }
+  if (hipError_t e = hipSetDevice(c->device); e != hipSuccess) return hip_fail(c, "hipSetDevice", e);
+  if (c->comm_buf_doubles < count) {
+    if (c->comm_buf) (void)hipFree(c->comm_buf);
+    c->comm_buf = nullptr;
+    c->comm_buf_doubles = 0;
+    if (hipMalloc(&c->comm_buf, sizeof(double) * count) != hipSuccess) {
+      c->err = "out of device memory for the broadcast buffer";
+      return GPMI_ERR_NOMEM;
+    }
+    c->comm_buf_doubles = count;
+  }
+  hipStream_t s = c->comm_stream;
+  if (c->comm_rank == root)
+    if (hipError_t e = hipMemcpyAsync(c->comm_buf, buf_host, sizeof(double) * count, hipMemcpyHostToDevice, s);
+        e != hipSuccess)
+      return hip_fail(c, "broadcast upload", e);
+  int rc = r->broadcast(c->comm_buf, c->comm_buf, (size_t)count, NCCL_DOUBLE, root, c->comm, s);
+  if (rc != 0) return fail(c, "ncclBroadcast", rc);
+  if (c->comm_rank != root)
+    if (hipError_t e = hipMemcpyAsync(buf_host, c->comm_buf, sizeof(double) * count, hipMemcpyDeviceToHost, s);
+        e != hipSuccess)
+      return hip_fail(c, "broadcast download", e);
+  if (hipError_t e = hipStreamSynchronize(s); e != hipSuccess) return hip_fail(c, "broadcast synchronise", e);
+  return GPMI_OK;
+}
+
+// The number of ranks RCCL itself sees in the communicator (ncclCommCount): what a scaling run prints beside the
+// launcher's WORLD_SIZE.
+int gpmi_comm_count(gpmi_ctx* c, int* ranks) {
+  if (!c || !ranks) return GPMI_ERR_ARG;
+  Rccl* r = rccl();
+  if (!r || !c->comm || !r->comm_count) {
+    c->err = "no communicator (gpmi_comm_init), or this librccl has no ncclCommCount";
+    return GPMI_ERR_ARG;
+  }
+  int rc = r->comm_count(c->comm, ranks);
+  if (rc != 0) return fail(c, "ncclCommCount", rc);
   return GPMI_OK;
 }
 

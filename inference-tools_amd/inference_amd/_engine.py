@@ -11,7 +11,78 @@ from inference_amd import _lib
 from inference_amd._lib import as_f64, dptr
 
 
-class GpEngine:
+class _DeviceCommMixin:
+    """The library's RCCL communicator on the handle `self.h` (gpmi_comm_*): the start-up broadcast of the data set
+    and the result gather of the sharded drivers (inference_amd.sharding)."""
+
+    comm_world = 0
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = _lib.load().gpmi_comm_unique_id(buf)
+        if rc != 0:
+            raise _lib.GpmiError(f"gpmi_comm_unique_id failed with status {rc} (librccl missing?)")
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        # RCCL prints a version banner on stdout from rank 0; keep stdout clean for callers that
+        # emit machine-readable output (bench.py prints one JSON line) by sending it to stderr
+        import os
+        import sys
+
+        libc = C.CDLL(None)
+        sys.stdout.flush()
+        libc.fflush(None)
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            self.h.call("gpmi_comm_init", int(rank), int(world), unique_id)
+        finally:
+            # the banner sits in C stdio's buffer when stdout is not a terminal: flush it while fd 1 still points
+            # at stderr, or it would come out after the caller's own output at process exit
+            libc.fflush(None)
+            os.dup2(saved, 1)
+            os.close(saved)
+        self.comm_world = world
+
+    def comm_allgather(self, values):
+        send = as_f64(values).ravel()
+        recv = np.empty(send.size * self.comm_world)
+        self.h.call("gpmi_comm_allgather", dptr(send), dptr(recv), send.size)
+        return recv.reshape(self.comm_world, send.size)
+
+    def comm_broadcast(self, values, root: int = 0):
+        """`values` of rank `root` on every rank (one ncclBroadcast); the other ranks pass an array of the same shape."""
+        buf = as_f64(values).copy()
+        self.h.call("gpmi_comm_broadcast", dptr(buf.ravel()), buf.size, int(root))
+        return buf
+
+    def comm_count(self) -> int:
+        """Ranks RCCL itself sees in the communicator (ncclCommCount)."""
+        n = C.c_int(0)
+        self.h.call("gpmi_comm_count", C.byref(n))
+        return n.value
+
+    def comm_destroy(self):
+        self.h.call("gpmi_comm_destroy")
+        self.comm_world = 0
+
+
+class DeviceComm(_DeviceCommMixin):
+    """A communicator on a handle of its own, for what happens before a rank has any data: rank 0 broadcasts x, y,
+    y_err (sharding.broadcast_dataset; the reference pickles the whole regressor into its worker processes,
+    regression.py:597-601, mcmc/parallel.py:127-136), every rank then builds its own regressor.  The same object can
+    serve the result gathers (`engine=` of the sharded drivers)."""
+
+    def __init__(self, device=None):
+        self.h = _lib.Handle(device)
+
+    def close(self):
+        self.h.close()
+
+
+class GpEngine(_DeviceCommMixin):
     def __init__(self, x, y, noise_var=None, y_cov=None, device=None, reserve=0):
         self.h = _lib.Handle(device)
         self.x = as_f64(x)
@@ -330,42 +401,6 @@ class GpEngine:
         G = np.empty((m, m)) if want_gram else None
         self.h.call("gpmi_solve_rows", dptr(Q), m, dptr(X), dptr(G))
         return X, G
-
-    # -- multi-GPU gather (RCCL) -----------------------------------------------------------
-    @staticmethod
-    def comm_unique_id() -> bytes:
-        buf = C.create_string_buffer(128)
-        rc = _lib.load().gpmi_comm_unique_id(buf)
-        if rc != 0:
-            raise _lib.GpmiError(f"gpmi_comm_unique_id failed with status {rc} (librccl missing?)")
-        return buf.raw
-
-    def comm_init(self, rank: int, world: int, unique_id: bytes):
-        # RCCL prints a version banner on stdout from rank 0; keep stdout clean for callers that
-        # emit machine-readable output (bench.py prints one JSON line) by sending it to stderr
-        import os
-        import sys
-
-        libc = C.CDLL(None)
-        sys.stdout.flush()
-        libc.fflush(None)
-        saved = os.dup(1)
-        try:
-            os.dup2(2, 1)
-            self.h.call("gpmi_comm_init", int(rank), int(world), unique_id)
-        finally:
-            # the banner sits in C stdio's buffer when stdout is not a terminal: flush it while fd 1 still points
-            # at stderr, or it would come out after the caller's own output at process exit
-            libc.fflush(None)
-            os.dup2(saved, 1)
-            os.close(saved)
-        self.comm_world = world
-
-    def comm_allgather(self, values):
-        send = as_f64(values).ravel()
-        recv = np.empty(send.size * self.comm_world)
-        self.h.call("gpmi_comm_allgather", dptr(send), dptr(recv), send.size)
-        return recv.reshape(self.comm_world, send.size)
 
     # -- instrumentation ----------------------------------------------------------------
     def timer_start(self):

@@ -93,6 +93,8 @@ SIGNATURES = {
     "gpmi_comm_unique_id": (C.c_int, [C.c_char_p]),
     "gpmi_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p]),
     "gpmi_comm_allgather": (C.c_int, [_vp, _dp, _dp, _i64]),
+    "gpmi_comm_broadcast": (C.c_int, [_vp, _dp, _i64, C.c_int]),
+    "gpmi_comm_count": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "gpmi_comm_destroy": (C.c_int, [_vp]),
     "gpmi_timer_start": (C.c_int, [_vp]),
     "gpmi_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),

@@ -11,7 +11,8 @@ process group (backend "gloo", CPU only — `import inference_amd` must come BEF
 `import torch` so that the process runs on the system ROCm runtime, see DESIGN.md
 section 6) or the torch-free `FileRendezvous` below (what bench.py uses).  Without a
 device communicator (CPU tests) the gather falls back to the bootstrap channel.
-There is no data-path collective: x, y are tiny and every rank builds them itself.
+There is no data-path collective.  The data set itself (x, y, y_err: a few hundred kilobytes) is either built by every
+rank from the same generator or handed out once at start-up by `broadcast_dataset` (one ncclBroadcast).
 
 Sharded units:
   * `marginal_likelihood_sweep`  config 3: a theta grid, contiguous blocks per rank;
@@ -80,6 +81,47 @@ def init_device_comm(engine):
         init_device_comm_files(engine, _default_rdv)
     else:
         engine.comm_init(0, 1, engine.comm_unique_id())
+
+
+def broadcast_dataset(x=None, y=None, y_err=None, comm=None, src: int = 0):
+    """(x, y, y_err) of rank `src` on every rank: the start-up distribution of SURVEY section 8(e).  Over RCCL (one
+    ncclBroadcast of n (d + 2) doubles, after a three-number header) when `comm` - a `DeviceComm` or an engine whose
+    communicator spans the job - is given, else over the bootstrap channel.  The other ranks pass nothing.  y_err may be
+    None on the source (it then is None everywhere)."""
+    rank, size = world()
+    if rank == src:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.ndim == 1:
+            x = x.reshape(-1, 1)
+        y = np.ascontiguousarray(y, dtype=np.float64).ravel()
+        err = None if y_err is None else np.ascontiguousarray(y_err, dtype=np.float64).ravel()
+        if y.size != x.shape[0] or (err is not None and err.size != y.size):
+            raise ValueError("broadcast_dataset: x, y, y_err disagree in length")
+    if size == 1:
+        return x, y, err
+    if comm is not None and getattr(comm, "comm_world", 0) == size:
+        head = np.array([x.shape[0], x.shape[1], 0.0 if err is None else 1.0]) if rank == src else np.zeros(3)
+        n, d, has_err = (int(v) for v in comm.comm_broadcast(head, src))
+        flat = np.zeros(n * (d + 1 + has_err))
+        if rank == src:
+            flat[: n * d] = x.ravel()
+            flat[n * d : n * (d + 1)] = y
+            if has_err:
+                flat[n * (d + 1) :] = err
+        flat = comm.comm_broadcast(flat, src)
+        return (flat[: n * d].reshape(n, d).copy(), flat[n * d : n * (d + 1)].copy(),
+                flat[n * (d + 1) :].copy() if has_err else None)
+    payload = (x, y, err) if rank == src else None
+    if _using_torch():
+        import torch.distributed as dist
+
+        box = [payload]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+    got = _default_rdv.broadcast_obj(payload, src)
+    xs, ys, es = got
+    return (np.asarray(xs, dtype=np.float64).reshape(len(ys), -1), np.asarray(ys, dtype=np.float64),
+            None if es is None else np.asarray(es, dtype=np.float64))
 
 
 def _using_torch():

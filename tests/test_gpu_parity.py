@@ -567,6 +567,30 @@ def test_rccl_gather_single_rank(gp_mod):
     assert vals.shape == (5, 1)
 
 
+def test_rccl_broadcast_and_count_single_rank():
+    """gpmi_comm_broadcast / gpmi_comm_count on a communicator of its own (DeviceComm: no data set needed - this is what
+    runs before a rank has any), world = 1: the one RCCL configuration of a 1-GPU box.  The N > 1 Python path is covered on
+    CPU (tests/test_sharding_cpu.py::test_broadcast_dataset_two_ranks_gloo)."""
+    from inference_amd import sharding
+    from inference_amd._engine import DeviceComm
+
+    comm = DeviceComm()
+    try:
+        comm.comm_init(0, 1, comm.comm_unique_id())
+        assert comm.comm_count() == 1
+        v = np.arange(7.0) * 0.5 - 1.0
+        assert np.array_equal(comm.comm_broadcast(v, 0), v)
+        assert np.array_equal(comm.comm_allgather(v)[0], v)
+        x, y, e = wl.synthetic_dataset(13, 64, 2)
+        gx, gy, ge = sharding.broadcast_dataset(x, y, e, comm=comm)
+        assert np.array_equal(gx, x) and np.array_equal(gy, y) and np.array_equal(ge, e)
+        with pytest.raises(Exception):
+            comm.comm_broadcast(v, 3)  # root outside the communicator
+    finally:
+        comm.comm_destroy()
+        comm.close()
+
+
 def test_two_ranks_on_one_device(tmp_path):
     """What the first multi-GPU run does first, on the hardware there is: two fresh processes on ONE device run
     `marginal_likelihood_sweep`, `multistart_sweep` and `tempering_run` on device engines through a FileRendezvous

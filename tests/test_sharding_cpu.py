@@ -68,6 +68,61 @@ def test_sharded_sweep_two_ranks_gloo(tmp_path, n_items):
         assert np.array_equal(got, serial)  # every rank holds the full, ordered result
 
 
+def _bcast_worker(rank, world, port, with_err, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "inference-tools_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    from inference_amd import sharding
+    from oracle import gp_oracle as orc
+    import workloads as wl
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # only the source rank holds the data (the reference pickles its regressor into the workers, regression.py:597-601)
+    if rank == 1:
+        x, y, e = wl.synthetic_dataset(3, 40, 3)
+        got = sharding.broadcast_dataset(x, y, e if with_err else None, src=1)
+    else:
+        got = sharding.broadcast_dataset(src=1)
+    x, y, e = got
+    # ... and every rank can build its own model from what it received
+    gp = orc.OracleGp(x, y, e if e is not None else np.full(y.size, 0.1), kernel=orc.SE)
+    lml = gp.marginal_likelihood(wl.timing_theta(wl.SE, y, 3))
+    np.savez(os.path.join(out_dir, f"b{rank}.npz"), x=x, y=y, e=np.zeros(0) if e is None else e, lml=lml)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("with_err", [True, False])
+def test_broadcast_dataset_two_ranks_gloo(tmp_path, with_err):
+    """Start-up distribution of SURVEY section 8(e) over the bootstrap channel (on the GPU ranks: one ncclBroadcast,
+    gpmi_comm_broadcast): x, y, y_err arrive bit for bit, y_err = None stays None."""
+    import workloads as wl
+
+    port = _free_port()
+    mp.spawn(_bcast_worker, args=(2, port, with_err, str(tmp_path)), nprocs=2, join=True)
+    x, y, e = wl.synthetic_dataset(3, 40, 3)
+    got = [np.load(tmp_path / f"b{r}.npz") for r in range(2)]
+    for g in got:
+        assert np.array_equal(g["x"], x) and np.array_equal(g["y"], y)
+        assert np.array_equal(g["e"], e) if with_err else g["e"].size == 0
+    assert float(got[0]["lml"]) == float(got[1]["lml"])
+
+
+def test_broadcast_dataset_single_process_and_validation():
+    from inference_amd import sharding
+    import workloads as wl
+
+    x, y, e = wl.synthetic_dataset(3, 12, 1)
+    gx, gy, ge = sharding.broadcast_dataset(x[:, 0], y, e)  # 1-D x becomes a column, as GpRegressor does
+    assert gx.shape == (12, 1) and np.array_equal(gy, y) and np.array_equal(ge, e)
+    with pytest.raises(ValueError):
+        sharding.broadcast_dataset(x, y[:-1], e)
+
+
 def test_shard_bounds_cover_everything():
     from inference_amd import sharding
 
