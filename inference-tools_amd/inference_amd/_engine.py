@@ -227,6 +227,10 @@ class GpEngine(_DeviceCommMixin):
         self.h.call("gpmi_lml_grad_qdiag", dptr(q))
         return q
 
+    def prepare_gradient(self, n_theta: int):
+        """gpmi_prepare_gradient: the gradient path's lazily allocated workspaces, now."""
+        self.h.call("gpmi_prepare_gradient", int(n_theta))
+
     def capacity(self):
         cap = C.c_int64(0)
         self.h.call("gpmi_capacity", C.byref(cap))

@@ -90,6 +90,7 @@ SIGNATURES = {
     "gpmi_loo_dense": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_predict_dense": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
     "gpmi_solve_rows": (C.c_int, [_vp, _dp, _i64, _dp, _dp]),
+    "gpmi_prepare_gradient": (C.c_int, [_vp, C.c_int]),
     "gpmi_comm_unique_id": (C.c_int, [C.c_char_p]),
     "gpmi_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p]),
     "gpmi_comm_allgather": (C.c_int, [_vp, _dp, _dp, _i64]),

@@ -797,6 +797,15 @@ class GpRegressor:
         y, grad_y = self.model_selector_gradient(theta)
         return -y, -grad_y
 
+    def prepare_gradient(self):
+        """(extension) Allocate the likelihood gradient's device workspaces now rather than inside the first
+        `marginal_likelihood_gradient` call (gpmi_prepare_gradient): at N = 16384 that first call otherwise costs twice a
+        later one.  Called by the gradient-based hyper-parameter search before its first evaluation; a no-op for covariance
+        functions that run through the dense path."""
+        if not self._generic and self._mix is None and self.n_points > 4096:
+            n_theta = np.arange(self.n_hyperpars)[self.cov_slice][self._stat_slice].size  # stationary-kernel parameters
+            self.engine.prepare_gradient(n_theta)
+
     def launch_bfgs(self, x0: ndarray):
         return fmin_l_bfgs_b(func=self.bfgs_cost_func, x0=x0, approx_grad=False, bounds=self.hp_bounds)
 
@@ -817,6 +826,7 @@ class GpRegressor:
             if sharding.world()[1] > 1:
                 thetas, fvals = sharding.multistart_sweep(self, array(starting_positions))
                 return thetas[int(np.argsort(fvals, kind="stable")[0])]
+        self.prepare_gradient()
         if self._lockstep_search():
             # every start advances in lockstep (gp/_lockstep.py: SciPy's own L-BFGS-B through its reverse-communication
             # interface, iterates identical to fmin_l_bfgs_b's): one batched device evaluation of the objective and
