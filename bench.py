@@ -171,7 +171,7 @@ def pmc_traffic():
     command (profiles/rNN_pmc.json, written by tools/pmc_bench.sh + tools/make_profiles.py: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
     coalesced reads on gfx950); (None, None) if absent."""
-    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)["kernels"]["update128"]["hbm_bytes_per_launch"], "profiles/" + name
@@ -185,7 +185,7 @@ def rocprof_duration_ratio():
     file): from the committed kernel-trace summary of this command (profiles/rNN_pmc.json `cross_check`).  rocprofv3
     times a launch from its dispatch to its completion signal - the end-of-kernel write-back included -, the stamps
     from the first workgroup's first instruction to the last workgroup's last acknowledged store."""
-    for name in ("r03_pmc.json", "r02_pmc.json"):
+    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 x = json.load(f)["cross_check"]
@@ -521,6 +521,12 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                 "peak": PEAK_FP64_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": ach / PEAK_FP64_MFMA_TFLOPS,
+                # ... and over EVERY launch of this kernel name (the slices on the panel stream's 32 CUs included: what a
+                # per-name kernel_stats row blends; profiles/rNN_bench_kernel_stats_by_queue.csv splits the row by queue)
+                "achieved_all_launches": ((prof["flops"] + prof_slice["flops"]) / ((prof["ms"] + prof_slice["ms"]) * 1e-3) / 1e12)
+                if prof["ms"] + prof_slice["ms"] > 0 else 0.0,
+                "frac_all_launches": ((prof["flops"] + prof_slice["flops"]) / ((prof["ms"] + prof_slice["ms"]) * 1e-3) / 1e12
+                                      / PEAK_FP64_MFMA_TFLOPS) if prof["ms"] + prof_slice["ms"] > 0 else 0.0,
                 "traffic": traffic,
                 "traffic_source": f"{traffic_src}: separate rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run; per launch, averaged over every launch of this kernel name (slices included: compare with same_kernel_name_all_launches.algorithmic_bytes_per_launch_avg)" if traffic_src else None,
                 "with_rocprofv3_durations": (lambda q: None if q[0] is None else {
@@ -551,6 +557,7 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                     "ms_per_step": all_ms / max(args.steps, 1),
                     "flop_per_step": all_fl / max(args.steps, 1),
                 },
+                "flow_tail_scope": "one flag-ordered tail per device at a time, process-wide: of several evaluation lanes factoring side by side (the config-3 sweep) only one gets it, the others take the stream-ordered schedule (same bits)",
                 "flow_tail": {
                     "what": "the chain-bound last tile rows of the factorisation (below 60 trailing tile rows) as ONE persistent tile-task launch on the update stream's 224 CUs beside the bare panel chain (csrc/potrf_flow.hip): FLOPs of its K = 128 / K = 512 update tasks over the launch's whole duration - the launch waits for the chain most of the time, so this is the overlap achieved, not a kernel rate; not part of all_trailing",
                     "achieved": (prof_flow["flops"] / (prof_flow["ms"] * 1e-3) / 1e12) if prof_flow["ms"] > 0 else 0.0,
