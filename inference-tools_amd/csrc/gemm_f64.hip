@@ -34,6 +34,8 @@ struct GemmArgs {
   int ntr, ntc, k;
   // 1 (TILES_LOWER): contraction starts at k = ti * BM (operands are zero before it);
   // 2: contraction ends at k = (tj + 1) * BN (B is lower triangular: B[j][k] = 0 for k > j)
+  // 3: one tile column of 128 = the whole contraction with a lower-triangular B (the panel TRSM as a product with the
+  //    inverse diagonal block): the zero part is skipped inside the tile (gemm_tiles::staged_tile, BTRI)
   int kskip;
   // optional wall-clock stamps of this launch (s_memrealtime, 100 MHz; 16 words, see the kernel): per-launch
   // durations for the roofline without HIP events in the stream (event records between the look-ahead
@@ -142,7 +144,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   const double* __restrict__ Bg = BKN ? g.B + bz * g.sB + (int64_t)kbeg * g.ldb + (int64_t)tj * BN
                                       : g.B + bz * g.sB + (int64_t)tj * BN * g.ldb + kbeg;
   double* Cg = g.C + bz * g.sC + (int64_t)ti * BM * g.ldc + (int64_t)tj * BN;
-  staged_tile<OP, BKN, BM, BN>(Ag, Bg, Cg, g.lda, g.ldb, g.ldc, (kend - kbeg) / BK, smem);
+  if constexpr (OP == OP_ASSIGN && BKN == 0 && BN == 128 && BM <= 64) {
+    if (g.kskip == 3) {
+      staged_tile<OP, BKN, BM, BN, CST_NT, LD_PLAIN, true>(Ag, Bg, Cg, g.lda, g.ldb, g.ldc, (kend - kbeg) / BK, smem);
+    } else {
+      staged_tile<OP, BKN, BM, BN>(Ag, Bg, Cg, g.lda, g.ldb, g.ldc, (kend - kbeg) / BK, smem);
+    }
+  } else {
+    staged_tile<OP, BKN, BM, BN>(Ag, Bg, Cg, g.lda, g.ldb, g.ldc, (kend - kbeg) / BK, smem);
+  }
 
   // End stamp (only the workgroups that can be the launch's last: dispatch is in order and tiles are uniform,
   // so the last one to finish is among the last two rounds of 512), taken behind the epilogue stores.
@@ -276,6 +286,8 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
       if (tiles == TILES_RECT && !b_kmajor && k > 128 && big * 4 * bt.count <= m32_max) bm = 32;
     }
   }
+  // the panel TRSM with the caller's word that B (the inverse of a diagonal block) is lower triangular
+  if (bt.b_lower_tri && kskip == 0 && bn == 128 && bm <= 64 && ntc == 1 && k == 128 && !b_kmajor && op == OP_ASSIGN) kskip = 3;
   GemmArgs g{C, A, B, ldc, lda, ldb, ntr * (128 / bm), ntc * (128 / bn), k, kskip, stamp,
              bt.sC, bt.sA, bt.sB, part == 2 ? 1 : 0, part >= 2 ? (int)nfull : 0, bt.hook};
   int64_t nwg;

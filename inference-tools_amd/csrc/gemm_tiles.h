@@ -97,9 +97,17 @@ constexpr int staged_lds_doubles() {
 // by the time of ONE tile rather than by throughput.
 // Ag: row 0 of the tile's A rows at the first k; Bg: row 0 of the tile's B rows at the first k (BKN: first k row, first
 // column of the tile); Cg: the tile's first element; nk: 16-deep slabs.
-template <int OP, int BKN, int BM, int BN, int CST = CST_NT, int LD = LD_PLAIN>
+// BTRI (round 4; BKN = 0, BN = 128 = the whole contraction, OP_ASSIGN): B is LOWER TRIANGULAR, B[j][k] = 0 for k > j - the
+// panel TRSM as a product with the inverse of the diagonal block (regression.py:241's dpotrf does a triangular solve
+// there).  Column block c (16 columns) of the result needs the slabs kt <= c only: the MFMAs of the others are skipped -
+// the very same sums, bit for bit (the skipped terms are products with exact zeros) - and a wave takes the column
+// blocks wc, wc + 2, wc + 4, wc + 6 instead of four neighbouring ones, so that its share of what is left (16 of 32
+// slab steps for wc = 0, 20 for wc = 1) is even: 44 % fewer MFMAs, 37 % less MFMA time per workgroup.
+template <int OP, int BKN, int BM, int BN, int CST = CST_NT, int LD = LD_PLAIN, bool BTRI = false>
 __device__ __forceinline__ void staged_tile(const double* __restrict__ Ag, const double* __restrict__ Bg, double* Cg,
                                             int64_t lda, int64_t ldb, int64_t ldc, int nk, double* smem) {
+  static_assert(!BTRI || (BKN == 0 && BN == 128 && OP == OP_ASSIGN), "BTRI: the in-place panel TRSM only");
+  constexpr int CSTEP = BTRI ? 32 : 16;  // columns between a wave's consecutive MFMA tiles
   constexpr int TM = BM / 32, TN = BN / 32;  // 16 x 16 MFMA tiles per wave (2 x 2 waves)
   constexpr int LDS_STRIDE_KN = BN + 16;
   constexpr int A_DOUBLES = BM * LDS_STRIDE;
@@ -155,11 +163,12 @@ __device__ __forceinline__ void staged_tile(const double* __restrict__ Ag, const
   };
 
   const int fr = lane & 15, fk = lane >> 4;
-  Cg += (int64_t)(wr * (BM / 2)) * ldc + wc * (BN / 2);
+  const int wcol = BTRI ? wc * 16 : wc * (BN / 2);  // first column of the wave's first MFMA tile
+  Cg += (int64_t)(wr * (BM / 2)) * ldc + wcol;
   const int sw = (fr >= 4 && fr < 12) ? 1 : 0;
   const int a_off = (wr * (BM / 2) + fr) * LDS_STRIDE + ((fk ^ sw) << 2);
   const int b_off = BKN ? 4 * fk * LDS_STRIDE_KN + wc * (BN / 2) + fr
-                        : (wc * (BN / 2) + fr) * LDS_STRIDE + ((fk ^ sw) << 2);
+                        : (wcol + fr) * LDS_STRIDE + ((fk ^ sw) << 2);
 
   // OP_SUB: the accumulators start from the C tile and the A operand is negated on its way into LDS,
   // so C - A B^T comes out of the MFMA chain itself and the epilogue is stores only.  The first operand slab is
@@ -184,7 +193,7 @@ __device__ __forceinline__ void staged_tile(const double* __restrict__ Ag, const
     for (int j = 0; j < TN; ++j) {
       if (OP == OP_SUB) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = c_load1<LD>(&Cg[(int64_t)(i * 16 + fk + 4 * r) * ldc + j * 16 + fr]);
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = c_load1<LD>(&Cg[(int64_t)(i * 16 + fk + 4 * r) * ldc + j * CSTEP + fr]);
       } else {
         acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
       }
@@ -220,15 +229,17 @@ __device__ __forceinline__ void staged_tile(const double* __restrict__ Ag, const
           b[t] = d2_t{sb[b_off + (2 * h) * LDS_STRIDE_KN + t * 16],
                       sb[b_off + (2 * h + 1) * LDS_STRIDE_KN + t * 16]};
         else
-          b[t] = *reinterpret_cast<const d2_t*>(sb + b_off + t * 16 * LDS_STRIDE + 2 * h);
+          b[t] = *reinterpret_cast<const d2_t*>(sb + b_off + t * CSTEP * LDS_STRIDE + 2 * h);
       }
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+      for (int j = 0; j < TN; ++j) {
+        if (BTRI && kt > 2 * j + wc) continue;  // column block 2 j + wc of a lower-triangular B: zero beyond slab 2 j + wc
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
+          for (int i = 0; i < TM; ++i)
             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+      }
     }
     // PF > 1: unconditional (the last step stages a repeat of the last slab, which nobody reads)
     if (PF > 1 || kt + 1 < nk) sstore(cur ^ 1, slot_next);
@@ -255,7 +266,7 @@ __device__ __forceinline__ void staged_tile(const double* __restrict__ Ag, const
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) c_store<CST>(acc[i][j][r], &Cg[(int64_t)(i * 16 + fk + 4 * r) * ldc + j * 16 + fr]);
+      for (int r = 0; r < 4; ++r) c_store<CST>(acc[i][j][r], &Cg[(int64_t)(i * 16 + fk + 4 * r) * ldc + j * CSTEP + fr]);
 }
 
 // ---- 128 x 128 tiles with K-contiguous operands: operand ring fed by LDS-DMA ---------------------------------------------------------------

@@ -232,6 +232,9 @@ struct GemmBatch {
   int64_t sC = 0, sA = 0, sB = 0;
   // CUs the launch's stream may use (0: the whole chip): the choice of 32-row tiles ("while CUs are idle") scales with it
   int ncu_hint = 0;
+  // B of a one-tile-column product with K = 128 is lower triangular (B[j][k] = 0 for k > j: the inverse of a diagonal
+  // block): the kernel skips the zero part
+  bool b_lower_tri = false;
   FlowHook hook;
 };
 struct BatchShape {

@@ -627,6 +627,7 @@ void factor_panel(gpmi_ctx* c, hipStream_t sp, double* A, int64_t ld, double* in
                   int J, int Je, int ncu = 0) {
   GemmBatch on;  // one problem; the CU count of a masked panel stream steers the tile height of the TRSM
   on.ncu_hint = ncu;
+  on.b_lower_tri = true;  // the panel TRSM's B is the inverse of the diagonal block
   // GPMI_CHAIN_TRACE=1 (tools/chain_trace.py, with the profile enabled): in-kernel wall-clock stamps of every launch
   // of the chain, printed by the next profile read
   static const bool trace = std::getenv("GPMI_CHAIN_TRACE") != nullptr;
@@ -724,7 +725,12 @@ int64_t slice_tiles(int rem, int64_t tiles_la, int64_t tiles_main, int kw, int n
   if (PCT <= 0 || kw != 4 * NB) return 0;
   const double tile_us = 64.4 * 2.0;  // one CU works on two tiles at a time
   const double per_main = tile_us / (2.0 * ncu_main), per_panel = tile_us / (2.0 * ncu_panel);
-  const double chain = 200.0 + 7.6 * rem;
+  // (200 us until round 4, whose potrf_diag takes 8 us less per column; GPMI_SLICE_CHAIN_US for A/B runs)
+  static const double CHAIN0 = [] {
+    const char* e = std::getenv("GPMI_SLICE_CHAIN_US");
+    return e ? std::atof(e) : 168.0;
+  }();
+  const double chain = CHAIN0 + 7.6 * rem;
   const double su = 20.0 + (double)(tiles_la + tiles_main) * per_main;
   double x = (su - chain) / (per_main + per_panel) * PCT / 100.0;
   const int64_t round = 2 * ncu_panel;
@@ -858,7 +864,8 @@ void potrf_lower_batched(gpmi_ctx* c, hipStream_t s, double* A, int64_t np, int6
     return v > 0 ? v : 1;
   }();
   const int nt = (int)(np / NB);
-  const GemmBatch inplace{bs.count, bs.sMat, bs.sMat, bs.sInv};
+  GemmBatch inplace{bs.count, bs.sMat, bs.sMat, bs.sInv};
+  inplace.b_lower_tri = true;
   const GemmBatch upd{bs.count, bs.sMat, bs.sMat, bs.sMat};
   for (int J = 0; J < nt; J += OBT) {
     const int Je = (J + OBT < nt) ? J + OBT : nt;

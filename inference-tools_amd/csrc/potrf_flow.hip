@@ -119,7 +119,7 @@ typedef __attribute__((address_space(1))) double glb_double_t;  // (generic poin
 template <int PROTO>
 __device__ __attribute__((noinline)) void flow_do_T(glb_double_t* C, const glb_double_t* invDk, int64_t ld,
                                                     lds_double_t* smem) {
-  staged_tile<OP_ASSIGN, 0, 32, 128, PROTO == 3 ? CST_NT : CST_SC1, PROTO == 2 ? LD_SC1 : LD_PLAIN>(
+  staged_tile<OP_ASSIGN, 0, 32, 128, PROTO == 3 ? CST_NT : CST_SC1, PROTO == 2 ? LD_SC1 : LD_PLAIN, true>(
       (const double*)C, (const double*)invDk, (double*)C, ld, NB, ld, NB / BK, (double*)smem);
 }
 template <int PROTO>
@@ -624,6 +624,7 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
         double* A21 = Akk + (int64_t)NB * ld;
         GemmBatch tc;
         tc.ncu_hint = c->pair_cus[0];
+        tc.b_lower_tri = true;
         tc.hook.pub = fl + FL_DDONE;
         tc.hook.pub_val = k + 1;
         tc.hook.wait = F + (k + 1) * m + k;

@@ -530,7 +530,8 @@ void trsm_identity_batched(hipStream_t s, const double* L, int64_t np, int64_t l
   const int nt = (int)(np / NB);
   const int OBT = 4;
   launch_set_identity(s, Q, ld, np, bs.count, bs.sMat);
-  const GemmBatch inplace{bs.count, bs.sMat, bs.sMat, bs.sInv};
+  GemmBatch inplace{bs.count, bs.sMat, bs.sMat, bs.sInv};
+  inplace.b_lower_tri = true;  // products with the inverses of the diagonal blocks
   const GemmBatch upd{bs.count, bs.sMat, bs.sMat, bs.sMat};
   for (int J = 0; J < nt; J += OBT) {
     const int Je = (J + OBT < nt) ? J + OBT : nt;
