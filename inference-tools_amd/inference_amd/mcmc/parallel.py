@@ -113,24 +113,36 @@ class ParallelTempering:
             chosen += [(min(a, b), max(a, b)) for a, b in zip(free[::2], free[1::2])]
         return chosen
 
-    def swap(self):
-        """Propose a position swap between randomly paired chains (parallel.py:190-231)."""
-        positions = [chain.get_last() for chain in self.chains]
-        probabilities = [chain.probs[-1] for chain in self.chains]
+    def draw_swap_plan(self):
+        """The random part of one `swap()`: the pairs and one uniform per pair, consumed from the ladder's generators in
+        swap()'s own order (pairing first, then one `rng.random()` per pair).  None of it depends on the chains' states,
+        so a driver may draw it ahead and apply the pairs one by one (`apply_pair`) as their chains become ready."""
         proposed_swaps = self.tight_pairs()
         for pair in proposed_swaps:
             self.attempted_swaps[pair] += 1
-        for i, j in proposed_swaps:
-            dt = self.inv_temps[i] - self.inv_temps[j]
-            pi = probabilities[i] / self.inv_temps[i]
-            pj = probabilities[j] / self.inv_temps[j]
-            dp = pi - pj
-            if self.rng.random() <= exp(-dt * dp):
-                self.chains[i].replace_last(positions[j])
-                self.chains[i].probs[-1] = pj * self.chains[i].inv_temp
-                self.chains[j].replace_last(positions[i])
-                self.chains[j].probs[-1] = pi * self.chains[j].inv_temp
-                self.successful_swaps[i, j] += 1
+        return proposed_swaps, [self.rng.random() for _ in proposed_swaps]
+
+    def apply_pair(self, i: int, j: int, u: float):
+        """Swap rule of parallel.py:207-231 for one pair, with the uniform `u` drawn for it."""
+        ci, cj = self.chains[i], self.chains[j]
+        dt = self.inv_temps[i] - self.inv_temps[j]
+        pi = ci.probs[-1] / self.inv_temps[i]
+        pj = cj.probs[-1] / self.inv_temps[j]
+        dp = pi - pj
+        if u <= exp(-dt * dp):
+            pos_i, pos_j = ci.get_last(), cj.get_last()
+            ci.replace_last(pos_j)
+            ci.probs[-1] = pj * ci.inv_temp
+            cj.replace_last(pos_i)
+            cj.probs[-1] = pi * cj.inv_temp
+            self.successful_swaps[i, j] += 1
+
+    def swap(self):
+        """Propose a position swap between randomly paired chains (parallel.py:190-231).  (The pairs are disjoint, so
+        applying them one after another on the chains' current states is the reference's snapshot-then-apply.)"""
+        pairs, uniforms = self.draw_swap_plan()
+        for (i, j), u in zip(pairs, uniforms):
+            self.apply_pair(i, j, u)
 
     def advance(self, n: int, swap_interval=10, display_progress=False):
         """Advance each chain by `n` steps with swap attempts every `swap_interval` steps."""
@@ -167,14 +179,19 @@ def advance_ladders(ladders, n: int, swap_interval=10, batch_posterior=None):
     device evaluation per proposal round), and every ladder performs its own swaps.  This is the per-GPU unit of
     config 5 (whole ladders per GPU, swaps GPU-local).
 
-    Ladders synchronise with THEMSELVES only: a ladder whose chains have all finished a swap interval swaps at once and
-    starts its next interval while other ladders are still in theirs.  (Round 2 stopped every ladder at every swap point:
-    the rounds before it shrank to the few chains still retrying - the slowest of 64 chains needs ~1.5x the average
-    number of proposals - and a batch of one costs what a batch of twenty costs.)  A chain draws from its own
-    generators, a ladder's swaps from the ladder's, so every trajectory and every swap decision is what it would be
-    with the ladder run alone: results do not depend on how ladders are grouped or sharded.  (Ladders that still pair
-    their chains with the module-level `random.choice` of parallel.py:172 share ONE stream; for those every swap point
-    stays a common one and the swaps are made in ladder order, as before.)
+    Nobody waits for more than ONE other chain (round 4).  A swap point pairs the chains of a ladder at random
+    (parallel.py:162-188) - and neither the pairing nor the uniform numbers of the accept tests depend on the chains'
+    states, so the ladder draws them when its first chain arrives (`ParallelTempering.draw_swap_plan`: the same numbers,
+    from the same generators, in the same order as `swap()` draws them) and every pair is swapped as soon as ITS two
+    chains have finished the interval; both then start the next interval while the rest of the ladder is still in
+    this one.  (Round 2 stopped every ladder at every swap point, round 3 every chain of a ladder until the ladder's
+    slowest - the retry-until-accept loop of gibbs.py:635-648 makes the slowest of eight chains need ~1.3x the average
+    number of proposals - had arrived: the batches thinned out towards every swap point.)  A chain draws from its own
+    generators, a ladder's swaps from the ladder's, and a pair's swap touches its two chains only: every trajectory and
+    every swap decision is what `ParallelTempering.advance` gives for the ladder run alone; results do not depend on how
+    ladders are grouped or sharded.  (Ladders that still pair their chains with the module-level `random.choice` of
+    parallel.py:172 share ONE stream; for those every swap point stays a common one and the swaps are made in ladder
+    order, as before.)
     Returns the number of posterior evaluations made."""
     bp = batch_posterior or ladders[0].batch_posterior
     if bp is None:
@@ -184,46 +201,78 @@ def advance_ladders(ladders, n: int, swap_interval=10, batch_posterior=None):
     chains = [c for lad in ladders for c in lad.chains]
     owner = [k for k, lad in enumerate(ladders) for _ in lad.chains]
     P = chains[0].n_parameters
-    # per ladder: steps of the current interval, steps left after it
-    def interval(done):
-        left = n - done
-        return swap_interval if left >= swap_interval else left
-    done = [0] * len(ladders)                 # completed steps (at interval boundaries)
-    goal = [interval(0) for _ in ladders]     # steps of the interval in progress
-    busy = [len(lad.chains) for lad in ladders]  # chains of the ladder still inside the interval
-    step = [0] * len(chains)
-    par = [0] * len(chains)
-    p_old = [c.probs[-1] for c in chains]
-    p_acc = list(p_old)
-    prop = [c.get_last() for c in chains]
-    active = list(range(len(chains)))
     first_of = []
     k0 = 0
     for lad in ladders:
         first_of.append(k0)
         k0 += len(lad.chains)
-    def _next_interval(k):
-        """Ladder k has finished an interval: swap, and hand back the chains that start its next one."""
-        lad = ladders[k]
-        done[k] += goal[k]
-        if goal[k] == swap_interval:  # (a trailing partial interval ends without a swap, as in `advance`)
-            lad.swap()
-        if done[k] >= n:
-            return []
-        goal[k] = interval(done[k])
-        busy[k] = len(lad.chains)
-        again = list(range(first_of[k], first_of[k] + len(lad.chains)))
-        for c in again:
-            step[c] = 0
-            par[c] = 0
-            p_old[c] = chains[c].probs[-1]
-            p_acc[c] = p_old[c]
-            prop[c] = chains[c].get_last()
-        return again
+    n_swaps = n // swap_interval                    # full intervals: each ends with a swap (as in `advance`)
+    n_intervals = n_swaps + (1 if n % swap_interval else 0)
+
+    def length(t):  # steps of interval t (a trailing partial interval ends without a swap)
+        return swap_interval if t < n_swaps else n - n_swaps * swap_interval
+
+    tc = [0] * len(chains)     # interval the chain is in
+    step = [0] * len(chains)   # steps taken inside it
+    par = [0] * len(chains)
+    p_old = [c.probs[-1] for c in chains]
+    p_acc = list(p_old)
+    prop = [c.get_last() for c in chains]
+    common = len(ladders) > 1 and any(lad.pair_choice is choice for lad in ladders)  # a shared random stream
+
+    def _restart(c):
+        """Chain c enters its next interval; False if it has none left."""
+        tc[c] += 1
+        if tc[c] >= n_intervals:
+            return False
+        step[c] = 0
+        par[c] = 0
+        p_old[c] = chains[c].probs[-1]
+        p_acc[c] = p_old[c]
+        prop[c] = chains[c].get_last()
+        return True
+
+    # swap plans, one per ladder and swap point, drawn in order when the first chain reaches the swap point
+    plans = [[] for _ in ladders]    # plans[k][t] = {local chain: (partner, pair, uniform)}
+    arrived = [dict() for _ in ladders]  # arrived[k][t] = set of local chains waiting for their partner
+
+    def _plan(k, t):
+        while len(plans[k]) <= t:
+            pairs, us = ladders[k].draw_swap_plan()
+            m = {}
+            for (i, j), u in zip(pairs, us):
+                m[int(i)] = (int(j), (int(i), int(j)), u)
+                m[int(j)] = (int(i), (int(i), int(j)), u)
+            plans[k].append(m)
+        return plans[k][t]
+
+    def _interval_done(c, still):
+        """Chain c has finished its interval: its pair swaps once both are there; whoever can goes on."""
+        k, t = owner[c], tc[c]
+        if t >= n_swaps:  # trailing partial interval: no swap, and nothing after it
+            _restart(c)
+            return
+        i = c - first_of[k]
+        entry = _plan(k, t).get(i)
+        if entry is None:  # odd ladder: this chain sits the swap out
+            if _restart(c):
+                still.append(c)
+            return
+        j, pair, u = entry
+        waiting = arrived[k].setdefault(t, set())
+        if j in waiting:
+            waiting.discard(j)
+            ladders[k].apply_pair(pair[0], pair[1], u)
+            for cc in (c, first_of[k] + j):
+                if _restart(cc):
+                    still.append(cc)
+        else:
+            waiting.add(i)
 
     def _settle(active, vals):
-        """The accept / reject bookkeeping of one round: returns (chains still inside their interval, ladders finished)."""
-        still, finished = [], []
+        """The accept / reject bookkeeping of one round: returns the chains that propose again (chains whose pair
+        is complete included), and - for the common-stream mode - the chains that finished their interval."""
+        still, ended = [], []
         for c, v in zip(active, vals):
             chain = chains[c]
             p_new = float(v) * chain.inv_temp
@@ -235,27 +284,48 @@ def advance_ladders(ladders, n: int, swap_interval=10, batch_posterior=None):
                     chain._commit(prop[c], p_acc[c])
                     step[c] += 1
                     par[c] = 0
-                    if step[c] < goal[owner[c]]:
+                    if step[c] < length(tc[c]):
                         p_old[c] = chain.probs[-1]
                         p_acc[c] = p_old[c]
                         prop[c] = chain.get_last()
-            if step[c] < goal[owner[c]]:
+            if step[c] < length(tc[c]):
                 still.append(c)
+            elif common:
+                ended.append(c)
             else:
-                busy[owner[c]] -= 1
-                if busy[owner[c]] == 0:
-                    finished.append(owner[c])
-        return still, finished
+                _interval_done(c, still)
+        return still, ended
 
     evals = 0
-    common = len(ladders) > 1 and any(lad.pair_choice is choice for lad in ladders)  # a shared random stream
+    active = list(range(len(chains)))
+    if common:
+        # one stream for every ladder's pairing: all chains meet at every swap point, the ladders swap in ladder order
+        held = []
+        while active or held:
+            if not active:
+                t = tc[held[0]]
+                if t < n_swaps:
+                    for lad in ladders:
+                        lad.swap()
+                active = sorted(c for c in held if _restart(c))
+                held = []
+                continue
+            for c in active:
+                prop[c][par[c]] = chains[c].params[par[c]].proposal()
+            vals = bp(array([prop[c] for c in active]))
+            evals += len(active)
+            active, ended = _settle(active, vals)
+            held += ended
+            active.sort()
+        return evals
     # Two (or more) groups of whole ladders, evaluated in turn through the model's two asynchronous slots: while the
     # device works on one group's proposals the host settles the other's - the bookkeeping above is ~10 us per chain
-    # and round, a sixth of the device time of a round of 64 chains.  Ladders never interact, generators are per chain
-    # and per ladder, and a value does not depend on its batch: the trajectories are those of the one-batch loop below.
+    # and round, a sixth of the device time of a round of 64 chains.  Ladders never interact (a chain's partner is in
+    # its own ladder, hence in its own group), generators are per chain and per ladder, and a value does not depend on
+    # its batch: the trajectories are those of the one-batch loop below.
     model = getattr(bp, "__self__", None)
     gmax = 0
-    if (not common and len(ladders) > 1 and getattr(bp, "__name__", "") == "marginal_likelihood_batch"
+    if (len(ladders) > 1 and getattr(bp, "__name__", "") == "marginal_likelihood_batch"
             and hasattr(model, "marginal_likelihood_batch_submit") and model.async_batches()):
         gmax = min(getattr(model.engine, "ASYNC_MAX", 128), model.engine.async_slot_capacity())
     if gmax >= max(len(lad.chains) for lad in ladders) and os.environ.get("GPMI_PT_ASYNC", "1") != "0":
@@ -291,9 +361,7 @@ def advance_ladders(ladders, n: int, swap_interval=10, batch_posterior=None):
                 vals = model.marginal_likelihood_batch_wait(slot)
                 free.append(slot)
                 evals += len(act[g])
-                still, finished = _settle(act[g], vals)
-                for k in finished:
-                    still += _next_interval(k)
+                still, _ = _settle(act[g], vals)
                 still.sort()
                 act[g] = still
                 if still:
@@ -308,25 +376,11 @@ def advance_ladders(ladders, n: int, swap_interval=10, batch_posterior=None):
                 except Exception:
                     pass
         return evals
-    held = []
-    while active or held:
-        if not active:  # common swap points: every ladder has arrived
-            finished, held = sorted(held), []
-            still = []
-            for k in finished:
-                still += _next_interval(k)
-            active = sorted(still)
-            continue
+    while active:
         for c in active:
             prop[c][par[c]] = chains[c].params[par[c]].proposal()
         vals = bp(array([prop[c] for c in active]))
         evals += len(active)
-        still, finished = _settle(active, vals)
-        if common:
-            held += finished
-        else:
-            for k in finished:  # the ladder's interval is complete: swap, then on to its next interval
-                still += _next_interval(k)
-        still.sort()  # a fixed order of the batch rows (values do not depend on it; the order of host work does)
-        active = still
+        active, _ = _settle(active, vals)
+        active.sort()  # a fixed order of the batch rows (values do not depend on it; the order of host work does)
     return evals

@@ -106,6 +106,43 @@ def test_lockstep_equals_sequential(golden, problem):
         assert np.array_equal(a.successful_swaps, b.successful_swaps)
 
 
+@pytest.mark.parametrize("temps,n,si", [([1.0, 2.0, 4.0, 8.0], 14, 4), ([1.0, 3.0, 9.0], 9, 3), ([1.0, 1.5, 2.5, 4.0, 7.0, 12.0], 10, 5)])
+def test_pairwise_swaps_equal_the_ladder_run_alone(golden, problem, temps, n, si):
+    """Ladders with generators of their own (the sharded / config-5 form): every PAIR swaps as soon as its two chains have
+    finished the interval and goes on, while the rest of the ladder is still in it (advance_ladders, round 4) - sample
+    paths, probabilities and swap counts must be those of `ParallelTempering.advance` on each ladder alone, trailing
+    partial interval and a chain that sits a swap out (odd ladder) included."""
+    g = golden("pt")
+    gp, start, widths = problem
+
+    def batch(thetas):
+        return np.array([gp.marginal_likelihood(t) for t in thetas])
+
+    def ladders():
+        out = []
+        for lad in range(3):
+            chains = [make_chain(gp.marginal_likelihood, start, widths, g["hp_bounds"], t, 9000 + 100 * lad + 10 * k)
+                      for k, t in enumerate(temps)]
+            pt = ParallelTempering(chains, batch_posterior=None)
+            pt.rng = default_rng(170 + lad)
+            pt.pair_choice = random.Random(300 + lad).choice
+            out.append(pt)
+        return out
+
+    alone = ladders()
+    for pt in alone:
+        pt.advance(n, swap_interval=si)
+    together = ladders()
+    advance_ladders(together, n, swap_interval=si, batch_posterior=batch)
+    for a, b in zip(alone, together):
+        for ca, cb in zip(a.chains, b.chains):
+            assert np.array_equal(ca.get_sample(burn=0), cb.get_sample(burn=0))
+            assert np.array_equal(np.array(ca.probs), np.array(cb.probs))
+        assert np.array_equal(a.successful_swaps, b.successful_swaps)
+        assert np.array_equal(a.attempted_swaps, b.attempted_swaps)
+        assert a.rng.random() == b.rng.random()  # the ladders' generators have been consumed identically
+
+
 def test_lockstep_on_analytic_posterior():
     def post(t):
         return float(-0.5 * np.sum((t - 1.0) ** 2 / np.array([0.5, 2.0]) ** 2))
