@@ -188,6 +188,13 @@ int gpmi_gradient(gpmi_ctx* ctx, const double* pts_host, int64_t m, double* gmu_
 int gpmi_loo_grad(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_theta, double extra_diag,
                   const double* mu_host, double* alpha_host, double* ikdiag_host, double* p_host,
                   double* grad_theta_host, double* trace_q_host, int* info);
+/* The same for T hyper-parameter vectors at once (thetas: T x n_theta, extra / mu_const: T values or mus: T x n; outputs
+ * T x n, T x n_theta, T): for n <= 4096 every launch carries the whole chunk (lockstep, like gpmi_lml_grad_batch); the
+ * multi-start search with the cross-validation objective (regression.py:159-164, 585-605) advances all its starts on it. */
+int gpmi_loo_grad_batch(gpmi_ctx* ctx, int kernel, int64_t T, const double* thetas_host, int n_theta,
+                        const double* extra_diag_host, const double* mus_host, const double* mu_const_host,
+                        double* alpha_host, double* ikdiag_host, double* p_host, double* grad_theta_host,
+                        double* trace_q_host, int* info);
 
 /* ---- covariance plugin surface -----------------------------------------------------
  * Replaces CovarianceFunction.build_covariance (covariance.py:247-255, 343-348): the n x n matrix

@@ -238,6 +238,13 @@ void free_data(gpmi_ctx* c) {
   fr(c->bVec);
   fr(c->bRed);
   fr(c->bMu);
+  fr(c->bB2);  // (the gradient batches' buffers were left behind here until round 4: a handle given a second data set of
+  fr(c->bGws);  //  another size kept using the first one's)
+  fr(c->bGout);
+  fr(c->bLoo);
+  if (c->h_bGout) (void)hipHostFree(c->h_bGout);
+  c->h_bGout = nullptr;
+  c->bgrad_cap = c->bgrad_ntheta = c->bLoo_cap = 0;
   if (c->bInfo) (void)hipFree(c->bInfo);
   c->bInfo = nullptr;
   if (c->bParams) (void)hipFree(c->bParams);
@@ -406,6 +413,8 @@ int ensure_batch_ws(gpmi_ctx* c, int want) {
   fr(c->bB2);
   fr(c->bGws);
   fr(c->bGout);
+  fr(c->bLoo);
+  c->bLoo_cap = 0;
   if (c->h_bGout) (void)hipHostFree(c->h_bGout);
   c->h_bGout = nullptr;
   c->bgrad_cap = c->bgrad_ntheta = 0;
@@ -1026,8 +1035,8 @@ int gpmi_lml_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas
     const GemmBatch syrk{B, bs.sMat, bs.sMat, bs.sMat};
     launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, 1, c->bA, c->ld, c->bB2, c->ld, c->bB2, c->ld, nt, nt, (int)c->np,
                 nullptr, syrk);
-    launch_lml_grad_batched(s, c->bParams, B, n_theta, c->x, c->n, c->np, c->bA, c->ld, bs.sMat, alpha_dev, bs.sVec,
-                            c->bGws, c->bGout);
+    launch_lml_grad_batched(s, c->bParams, B, n_theta, c->x, c->n, c->np, c->bA, c->ld, bs.sMat, alpha_dev, alpha_dev,
+                            bs.sVec, c->bGws, c->bGout);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_bRed, c->bRed, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(c->h_bGout, c->bGout, sizeof(double) * W * B, hipMemcpyDeviceToHost, s));
@@ -1041,6 +1050,113 @@ int gpmi_lml_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas
       INFOCHK(c, inf);
       lml[t0 + b] = -0.5 * c->h_bRed[2 * b] - c->h_bRed[2 * b + 1];
       for (int j = 0; j < n_theta; ++j) grad_theta[(t0 + b) * n_theta + j] = c->h_bGout[b * W + j];
+      if (trace_q) trace_q[t0 + b] = c->h_bGout[b * W + n_theta];
+      if (info) info[t0 + b] = inf;
+    }
+  }
+  return GPMI_OK;
+}
+
+// Leave-one-out log-likelihood terms and gradient (regression.py:489-526) for T hyper-parameter vectors in lockstep: the
+// batched form of gpmi_loo_grad - every launch carries the chunk in blockIdx.z.  What the reference's `multiprocessing.Pool`
+// farms out start by start (regression.py:597-601) when the model selector is the cross-validation objective.
+int gpmi_loo_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int n_theta, const double* extra,
+                        const double* mus, const double* mu_const, double* alpha_out, double* ikdiag_out, double* p_out,
+                        double* grad_theta, double* trace_q, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, T >= 1 && T <= RED_SLOTS, "T out of range");
+  ARGCHK(c, thetas && alpha_out && ikdiag_out && p_out && grad_theta, "NULL argument");
+  ARGCHK(c, mus || mu_const, "one of mus / mu_const is required");
+  if (int rc = set_device(c)) return rc;
+  const bool lockstep = (T >= 2 || c->lockstep_always) && c->np <= 4096 && !c->ycov;
+  if (!lockstep) {
+    std::vector<double> mu_row((size_t)c->n);
+    for (int64_t t = 0; t < T; ++t) {
+      const double* mu_t = mus ? mus + t * c->n : mu_row.data();
+      if (!mus) std::fill(mu_row.begin(), mu_row.end(), mu_const[t]);
+      int inf = 0;
+      const int rc = gpmi_loo_grad(c, kernel, thetas + t * n_theta, n_theta, extra ? extra[t] : 0.0, mu_t,
+                                   alpha_out + t * c->n, ikdiag_out + t * c->n, p_out + t * c->n,
+                                   grad_theta + t * n_theta, trace_q ? trace_q + t : nullptr, &inf);
+      if (info) info[t] = inf;
+      if (rc != GPMI_OK) return rc;
+    }
+    return GPMI_OK;
+  }
+  if (c->lanes.size() < 2)
+    if (int rc = ensure_lanes(c, 2)) return rc;
+  std::vector<KParams> ps((size_t)T);
+  for (int64_t t = 0; t < T; ++t)
+    if (int rc = make_params(c, kernel, thetas + t * n_theta, n_theta, extra ? extra[t] : 0.0, ps[(size_t)t])) return rc;
+  ARGCHK(c, c->bpend[0] == 0 && c->bpend[1] == 0,
+         "gpmi_loo_grad_batch: an asynchronous batch is pending on this handle (gpmi_lml_batch_wait first)");
+  if (int rc = ensure_batch_ws(c, (int)(T < 64 ? (T < 2 ? 2 : T) : 64))) return rc;
+  if (int rc = ensure_batch_grad_ws(c, c->bcap, n_theta)) return rc;
+  // four more vectors per problem: diag(K^-1), c1, sqrt(c2), p = K^-1 c1 (regression.py:505-513)
+  const int64_t sLoo = 4 * c->np;
+  if (c->bLoo_cap < c->bgrad_cap) {
+    if (c->bLoo) (void)hipFree(c->bLoo);
+    c->bLoo = nullptr;
+    c->bLoo_cap = 0;
+    HIPCHK(c, hipMalloc(&c->bLoo, sizeof(double) * sLoo * c->bgrad_cap));
+    c->bLoo_cap = c->bgrad_cap;
+  }
+  hipStream_t s = c->lanes[1].stream;
+  const int nt = (int)(c->np / GPMI_NB);
+  const BatchShape shape0{1, c->np * c->ld, (c->np / GPMI_NB) * GPMI_NB * GPMI_NB, 4 * c->np};
+  const int W = n_theta + 1;
+  for (int64_t t0 = 0; t0 < T; t0 += c->bgrad_cap) {
+    const int B = (int)((T - t0 < c->bgrad_cap) ? T - t0 : c->bgrad_cap);
+    BatchShape bs = shape0;
+    bs.count = B;
+    HIPCHK(c, hipMemcpyAsync(c->bParams, ps.data() + t0, sizeof(KParams) * B, hipMemcpyHostToDevice, s));
+    if (mus)
+      HIPCHK(c, hipMemcpyAsync(c->bMu, mus + t0 * c->n, sizeof(double) * B * c->n, hipMemcpyHostToDevice, s));
+    else
+      HIPCHK(c, hipMemcpyAsync(c->bMu, mu_const + t0, sizeof(double) * B, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(c->bInfo, 0, sizeof(int) * B, s));
+    launch_kbuild_square_batched(s, ps[0].kernel, c->bParams, B, c->x, c->n, c->np, c->noise, c->bA, c->ld, bs.sMat,
+                                 (int)c->d);
+    potrf_lower_batched(c, s, c->bA, c->np, c->ld, c->bInv, c->bInfo, bs);
+    launch_residual_batched(s, c->y, mus ? c->bMu : nullptr, mus ? nullptr : c->bMu, c->bVec + 2 * c->np, c->n, c->np,
+                            bs);
+    trsv_forward(c, s, c->bA, c->np, c->ld, c->bInv, c->bVec + 2 * c->np, c->bVec, c->bInfo, bs);
+    double* alpha_dev = c->bVec + c->np;  // slot 1 of every problem's four work vectors
+    trsv_backward(c, s, c->bA, c->np, c->ld, c->bInv, c->bVec, alpha_dev, c->bInfo, bs);
+    double* diag_dev = c->bLoo;
+    double* c1_dev = c->bLoo + c->np;
+    double* sc2_dev = c->bLoo + 2 * c->np;
+    double* p_dev = c->bLoo + 3 * c->np;
+    // L^-T, its row sums of squares = diag(K^-1), then K^-1 in full (both triangles)
+    trsm_identity_batched(s, c->bA, c->np, c->ld, c->bInv, c->bB2, bs);
+    launch_rows_sumsq(s, c->bB2, c->ld, c->np, c->np, 0.0, diag_dev, B, bs.sMat, sLoo, -1.0);
+    const GemmBatch syrk{B, bs.sMat, bs.sMat, bs.sMat};
+    launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, 1, c->bA, c->ld, c->bB2, c->ld, c->bB2, c->ld, nt, nt, (int)c->np,
+                nullptr, syrk);
+    launch_mirror_lower(s, c->bA, c->ld, c->np, B, bs.sMat);
+    launch_loo_vectors(s, alpha_dev, diag_dev, c1_dev, sc2_dev, c->n, c->np, B, bs.sVec, sLoo);
+    launch_rows_dot(s, c->bA, c->ld, c->np, c->np, c1_dev, p_dev, B, bs.sMat, sLoo);
+    // M = K^-1 diag(c2) K^-1 = G G^T with G = K^-1 diag(sqrt c2); lower tiles, overwriting K^-1
+    launch_scale_columns(s, c->bA, sc2_dev, c->bB2, c->ld, c->np, B, bs.sMat, sLoo);
+    launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, 0, c->bA, c->ld, c->bB2, c->ld, c->bB2, c->ld, nt, nt, (int)c->np,
+                nullptr, syrk);
+    launch_lml_grad_batched(s, c->bParams, B, n_theta, c->x, c->n, c->np, c->bA, c->ld, bs.sMat, p_dev, alpha_dev, sLoo,
+                            c->bGws, c->bGout);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_bGout, c->bGout, sizeof(double) * W * B, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_bInfo, c->bInfo, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpy2DAsync(alpha_out + t0 * c->n, sizeof(double) * c->n, alpha_dev, sizeof(double) * bs.sVec,
+                               sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpy2DAsync(ikdiag_out + t0 * c->n, sizeof(double) * c->n, diag_dev, sizeof(double) * sLoo,
+                               sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpy2DAsync(p_out + t0 * c->n, sizeof(double) * c->n, p_dev, sizeof(double) * sLoo,
+                               sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int b = 0; b < B; ++b) {
+      const int inf = c->h_bInfo[b];
+      INFOCHK(c, inf);
+      // the contraction returns 1/2 sum Q o dK; the LOO gradient has no 1/2 (regression.py:513)
+      for (int j = 0; j < n_theta; ++j) grad_theta[(t0 + b) * n_theta + j] = 2.0 * c->h_bGout[b * W + j];
       if (trace_q) trace_q[t0 + b] = c->h_bGout[b * W + n_theta];
       if (info) info[t0 + b] = inf;
     }

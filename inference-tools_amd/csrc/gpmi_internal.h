@@ -128,6 +128,8 @@ struct gpmi_ctx {
   double* bMu = nullptr;
   double* bB2 = nullptr;     // second matrix per problem (L^-T), gradient batches only
   double* bGws = nullptr;    // partial sums of the fused contraction
+  double* bLoo = nullptr;    // gpmi_loo_grad_batch: 4 vectors per problem (diag K^-1, c1, sqrt c2, p)
+  int bLoo_cap = 0;
   double* bGout = nullptr;   // (n_theta + 1) results per problem
   double* h_bGout = nullptr;
   int bgrad_cap = 0, bgrad_ntheta = 0;
@@ -205,13 +207,14 @@ void launch_lml_grad(hipStream_t s, const KParams& p, int n_theta, const double*
                      int64_t np, const double* iK, int64_t ld, const double* u, const double* v,
                      double* ws, double* out);
 void launch_lml_grad_batched(hipStream_t s, const KParams* pdev, int batch, int n_theta, const double* x, int64_t n,
-                             int64_t np, const double* iK, int64_t ld, int64_t sK, const double* alpha, int64_t sV,
-                             double* ws, double* out);
-void launch_mirror_lower(hipStream_t s, double* A, int64_t ld, int64_t np);
+                             int64_t np, const double* iK, int64_t ld, int64_t sK, const double* u, const double* v,
+                             int64_t sV, double* ws, double* out);
+void launch_mirror_lower(hipStream_t s, double* A, int64_t ld, int64_t np, int batch = 1, int64_t sMat = 0);
+// (batch > 1: problem z works on A / G + z sMat and on vectors sVec (sAlpha, sLoo) apart)
 void launch_scale_columns(hipStream_t s, const double* A, const double* sc, double* G, int64_t ld,
-                          int64_t np);
+                          int64_t np, int batch = 1, int64_t sMat = 0, int64_t sVec = 0);
 void launch_loo_vectors(hipStream_t s, const double* alpha, const double* ikdiag, double* c1,
-                        double* sc2, int64_t n, int64_t np);
+                        double* sc2, int64_t n, int64_t np, int batch = 1, int64_t sAlpha = 0, int64_t sLoo = 0);
 
 // flags a chain launch of the flag-ordered factorisation publishes / waits for at its start (potrf_flow.hip,
 // gemm_tiles.h: flow_hook_enter)
@@ -340,10 +343,10 @@ void launch_lml_reduce(hipStream_t s, const double* v, const double* L, int64_t 
                        double* red, const BatchShape& bs = BatchShape());
 // out[m] = sum_n Q[m][n] * a[n]
 void launch_rows_dot(hipStream_t s, const double* Q, int64_t ld, int64_t mp, int64_t np,
-                     const double* a, double* out);
-// out[m] = base - sum_n Q[m][n]^2
+                     const double* a, double* out, int batch = 1, int64_t sQ = 0, int64_t sVec = 0);
+// out[m] = sign (base - sum_n Q[m][n]^2)
 void launch_rows_sumsq(hipStream_t s, const double* Q, int64_t ld, int64_t mp, int64_t np,
-                       double base, double* out);
+                       double base, double* out, int batch = 1, int64_t sQ = 0, int64_t sVec = 0, double sign = 1.0);
 
 // Q (mp x np) <- Q L^-1   (backward solve of mp right-hand sides stored as rows)
 void trsm_rows_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,

@@ -49,10 +49,11 @@ __global__ __launch_bounds__(256) void lml_grad_kernel(KParams p, int n_theta,
 __global__ __launch_bounds__(256) void lml_grad_batched_kernel(const KParams* __restrict__ pdev, int n_theta,
                                                                const double* __restrict__ x, int64_t n,
                                                                const double* __restrict__ iK, int64_t ld,
-                                                               const double* __restrict__ uvec, double* __restrict__ ws,
+                                                               const double* __restrict__ uvec,
+                                                               const double* __restrict__ vvec, double* __restrict__ ws,
                                                                int64_t sK, int64_t sV, int64_t sW) {
   const int64_t z = blockIdx.z;
-  lml_grad_body(pdev[z], n_theta, x, n, iK + z * sK, ld, uvec + z * sV, uvec + z * sV, ws + z * sW);
+  lml_grad_body(pdev[z], n_theta, x, n, iK + z * sK, ld, uvec + z * sV, vvec + z * sV, ws + z * sW);
 }
 
 __device__ __forceinline__ void lml_grad_body(const KParams& p, int n_theta, const double* __restrict__ x, int64_t n,
@@ -164,8 +165,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restri
 }
 
 // A[j][i] = A[i][j] for j > i (tile-wise through LDS so that both sides are coalesced)
-__global__ __launch_bounds__(256) void mirror_lower_kernel(double* __restrict__ A, int64_t ld) {
+__global__ __launch_bounds__(256) void mirror_lower_kernel(double* __restrict__ A, int64_t ld, int64_t sA) {
   __shared__ double t[64][65];
+  A += (int64_t)blockIdx.z * sA;
   const int ti = blockIdx.y, tj = blockIdx.x;
   if (tj > ti) return;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -179,10 +181,13 @@ __global__ __launch_bounds__(256) void mirror_lower_kernel(double* __restrict__ 
 
 // G[b][a] = A[b][a] * s[a]
 __global__ void scale_columns_kernel(const double* __restrict__ A, const double* __restrict__ s,
-                                     double* __restrict__ G, int64_t ld, int64_t np) {
+                                     double* __restrict__ G, int64_t ld, int64_t np, int64_t sMat, int64_t sVec) {
   const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
   const int64_t i = blockIdx.y;
   if (j >= np) return;
+  A += (int64_t)blockIdx.z * sMat;
+  G += (int64_t)blockIdx.z * sMat;
+  s += (int64_t)blockIdx.z * sVec;
   const d2_t a = *reinterpret_cast<const d2_t*>(A + i * ld + j);
   *reinterpret_cast<d2_t*>(G + i * ld + j) = d2_t{a[0] * s[j], a[1] * s[j + 1]};
 }
@@ -191,9 +196,13 @@ __global__ void scale_columns_kernel(const double* __restrict__ A, const double*
 // sqrt(c2) with c2 = 1/2 var (1 + var alpha^2); zero in the padding
 __global__ void loo_vectors_kernel(const double* __restrict__ alpha, const double* __restrict__ ikdiag,
                                    double* __restrict__ c1, double* __restrict__ sc2, int64_t n,
-                                   int64_t np) {
+                                   int64_t np, int64_t sAlpha, int64_t sLoo) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= np) return;
+  alpha += (int64_t)blockIdx.z * sAlpha;
+  ikdiag += (int64_t)blockIdx.z * sLoo;
+  c1 += (int64_t)blockIdx.z * sLoo;
+  sc2 += (int64_t)blockIdx.z * sLoo;
   double a = 0.0, b = 0.0;
   if (i < n) {
     const double var = 1.0 / ikdiag[i];
@@ -206,21 +215,21 @@ __global__ void loo_vectors_kernel(const double* __restrict__ alpha, const doubl
 
 }  // namespace
 
-void launch_mirror_lower(hipStream_t s, double* A, int64_t ld, int64_t np) {
-  dim3 grid((unsigned)(np / 64), (unsigned)(np / 64));
-  hipLaunchKernelGGL(mirror_lower_kernel, grid, dim3(256), 0, s, A, ld);
+void launch_mirror_lower(hipStream_t s, double* A, int64_t ld, int64_t np, int batch, int64_t sMat) {
+  dim3 grid((unsigned)(np / 64), (unsigned)(np / 64), (unsigned)batch);
+  hipLaunchKernelGGL(mirror_lower_kernel, grid, dim3(256), 0, s, A, ld, sMat);
 }
 
 void launch_scale_columns(hipStream_t s, const double* A, const double* sc, double* G, int64_t ld,
-                          int64_t np) {
-  dim3 grid((unsigned)((np / 2 + 255) / 256), (unsigned)np);
-  hipLaunchKernelGGL(scale_columns_kernel, grid, dim3(256), 0, s, A, sc, G, ld, np);
+                          int64_t np, int batch, int64_t sMat, int64_t sVec) {
+  dim3 grid((unsigned)((np / 2 + 255) / 256), (unsigned)np, (unsigned)batch);
+  hipLaunchKernelGGL(scale_columns_kernel, grid, dim3(256), 0, s, A, sc, G, ld, np, sMat, sVec);
 }
 
 void launch_loo_vectors(hipStream_t s, const double* alpha, const double* ikdiag, double* c1,
-                        double* sc2, int64_t n, int64_t np) {
-  hipLaunchKernelGGL(loo_vectors_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, alpha,
-                     ikdiag, c1, sc2, n, np);
+                        double* sc2, int64_t n, int64_t np, int batch, int64_t sAlpha, int64_t sLoo) {
+  hipLaunchKernelGGL(loo_vectors_kernel, dim3((unsigned)((np + 255) / 256), 1, (unsigned)batch), dim3(256), 0, s, alpha,
+                     ikdiag, c1, sc2, n, np, sAlpha, sLoo);
 }
 
 int64_t grad_ws_doubles(int64_t np, int n_theta) {
@@ -238,14 +247,15 @@ void launch_lml_grad(hipStream_t s, const KParams& p, int n_theta, const double*
                      t * (t + 1) / 2, n_theta + 1, out, (int64_t)0);
 }
 
-// B lockstep evaluations: out[z * (n_theta + 1) ..] = gradient and trace of problem z (u = v = alpha_z)
+// B lockstep evaluations: out[z * (n_theta + 1) ..] = gradient and trace of problem z (likelihood gradient: u = v =
+// alpha_z; leave-one-out gradient: u = p_z, v = alpha_z, both with stride sV)
 void launch_lml_grad_batched(hipStream_t s, const KParams* pdev, int batch, int n_theta, const double* x, int64_t n,
-                             int64_t np, const double* iK, int64_t ld, int64_t sK, const double* alpha, int64_t sV,
-                             double* ws, double* out) {
+                             int64_t np, const double* iK, int64_t ld, int64_t sK, const double* u, const double* v,
+                             int64_t sV, double* ws, double* out) {
   const int64_t t = np / KT;
   const int64_t sW = grad_ws_doubles(np, n_theta);
   dim3 grid((unsigned)t, (unsigned)t, (unsigned)batch);
-  hipLaunchKernelGGL(lml_grad_batched_kernel, grid, dim3(256), 0, s, pdev, n_theta, x, n, iK, ld, alpha, ws, sK, sV, sW);
+  hipLaunchKernelGGL(lml_grad_batched_kernel, grid, dim3(256), 0, s, pdev, n_theta, x, n, iK, ld, u, v, ws, sK, sV, sW);
   hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(n_theta + 1), 1, (unsigned)batch), dim3(256), 0, s, ws,
                      t * (t + 1) / 2, n_theta + 1, out, sW);
 }

@@ -333,11 +333,13 @@ __global__ __launch_bounds__(1024) void lml_reduce_kernel(const double* __restri
 __global__ __launch_bounds__(256) void rows_dot_kernel(const double* __restrict__ Q, int64_t ld,
                                                        int64_t mp, int64_t np,
                                                        const double* __restrict__ a,
-                                                       double* __restrict__ out) {
+                                                       double* __restrict__ out, int64_t sQ, int64_t sVec) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= mp) return;
-  const double* q = Q + row * ld;
+  a += (int64_t)blockIdx.z * sVec;    // batch: problem z, vectors sVec apart
+  out += (int64_t)blockIdx.z * sVec;
+  const double* q = Q + (int64_t)blockIdx.z * sQ + row * ld;
   double s = 0.0;
   for (int64_t j = lane * 2; j < np; j += 128) {
     const d2_t qv = *reinterpret_cast<const d2_t*>(q + j);
@@ -351,11 +353,13 @@ __global__ __launch_bounds__(256) void rows_dot_kernel(const double* __restrict_
 
 __global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restrict__ Q, int64_t ld,
                                                          int64_t mp, int64_t np, double base,
-                                                         double* __restrict__ out) {
+                                                         double* __restrict__ out, int64_t sQ, int64_t sVec,
+                                                         double sign) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= mp) return;
-  const double* q = Q + row * ld;
+  out += (int64_t)blockIdx.z * sVec;
+  const double* q = Q + (int64_t)blockIdx.z * sQ + row * ld;
   double s = 0.0;
   for (int64_t j = lane * 2; j < np; j += 128) {
     const d2_t qv = *reinterpret_cast<const d2_t*>(q + j);
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restric
     s = fma(qv[1], qv[1], s);
   }
   s = wave_sum(s);
-  if (lane == 0) out[row] = base - s;
+  if (lane == 0) out[row] = sign * (base - s);
 }
 
 }  // namespace
@@ -576,13 +580,13 @@ void launch_residual_batched(hipStream_t s, const double* y, const double* mus, 
 }
 
 void launch_rows_dot(hipStream_t s, const double* Q, int64_t ld, int64_t mp, int64_t np,
-                     const double* a, double* out) {
-  hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)((mp + 3) / 4)), dim3(256), 0, s, Q, ld, mp, np,
-                     a, out);
+                     const double* a, double* out, int batch, int64_t sQ, int64_t sVec) {
+  hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)((mp + 3) / 4), 1, (unsigned)batch), dim3(256), 0, s, Q, ld, mp, np,
+                     a, out, sQ, sVec);
 }
 
 void launch_rows_sumsq(hipStream_t s, const double* Q, int64_t ld, int64_t mp, int64_t np,
-                       double base, double* out) {
-  hipLaunchKernelGGL(rows_sumsq_kernel, dim3((unsigned)((mp + 3) / 4)), dim3(256), 0, s, Q, ld, mp,
-                     np, base, out);
+                       double base, double* out, int batch, int64_t sQ, int64_t sVec, double sign) {
+  hipLaunchKernelGGL(rows_sumsq_kernel, dim3((unsigned)((mp + 3) / 4), 1, (unsigned)batch), dim3(256), 0, s, Q, ld, mp,
+                     np, base, out, sQ, sVec, sign);
 }

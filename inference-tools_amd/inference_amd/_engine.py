@@ -365,6 +365,21 @@ class GpEngine(_DeviceCommMixin):
                     dptr(alpha), dptr(ikdiag), dptr(pvec), dptr(grad), C.byref(trq), C.byref(info))
         return alpha, ikdiag, pvec, grad, trq.value, info.value
 
+    def loo_grad_batch(self, kernel, thetas_cov, extra_diag, mus=None, mu_const=None):
+        """T evaluations of `loo_grad` in one call (gpmi_loo_grad_batch: lockstep for padded N <= 4096):
+        (alpha (T, n), ikdiag (T, n), pvec (T, n), grad (T, n_theta), trace_q (T,), info (T,))."""
+        th = as_f64(np.atleast_2d(thetas_cov))
+        T, nth = th.shape
+        ex = as_f64(np.broadcast_to(np.asarray(extra_diag, dtype=float), (T,)))
+        alpha, ikdiag, pvec = np.empty((T, self.n)), np.empty((T, self.n)), np.empty((T, self.n))
+        grad, trq = np.empty((T, nth)), np.empty(T)
+        info = np.zeros(T, dtype=np.int32)
+        mus_p = dptr(as_f64(mus)) if mus is not None else None
+        muc_p = dptr(as_f64(np.broadcast_to(np.asarray(mu_const, dtype=float), (T,)))) if mus is None else None
+        self.h.call("gpmi_loo_grad_batch", kernel, T, dptr(th), nth, dptr(ex), mus_p, muc_p, dptr(alpha), dptr(ikdiag),
+                    dptr(pvec), dptr(grad), dptr(trq), info.ctypes.data_as(C.POINTER(C.c_int)))
+        return alpha, ikdiag, pvec, grad, trq, info
+
     # -- dense entry points (covariance functions that only implement the plugin ABC) ------------------
     def fit_dense(self, K, mu):
         K, mu = as_f64(K), as_f64(mu)

@@ -68,6 +68,7 @@ SIGNATURES = {
     "gpmi_loo_diag": (C.c_int, [_vp, _dp]),
     "gpmi_loo_terms": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _ip]),
     "gpmi_loo_grad": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_loo_grad_batch": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_fit_mix": (C.c_int, [_vp, C.c_int, _ip, _dp, _ip, _dp, C.c_double, _dp, _dp, _dp, _ip]),
     "gpmi_lml_mix": (C.c_int, [_vp, C.c_int, _ip, _dp, _ip, _dp, C.c_double, _dp, _dp, _ip]),
     "gpmi_lml_grad_mix": (C.c_int, [_vp, C.c_int, _ip, _dp, _ip, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp, _ip]),

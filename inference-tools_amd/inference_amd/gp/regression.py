@@ -476,6 +476,39 @@ class GpRegressor:
         grad[self.cov_slice] = g_cov
         return LOO, grad
 
+    def loo_likelihood_gradient_batch(self, thetas: ndarray):
+        """(extension) `loo_likelihood_gradient` for T hyper-parameter vectors in one device call (gpmi_loo_grad_batch:
+        for N <= 4096 the evaluations advance in lockstep): returns (LOO (T,), grad (T, P)).  What the lockstep
+        multi-start search evaluates per round when the model selector is the cross-validation objective
+        (regression.py:159-164)."""
+        thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
+        if self._generic or self._het_slice is not None or self._mix is not None:
+            res = [self.loo_likelihood_gradient(t) for t in thetas]
+            return np.array([r[0] for r in res]), np.array([r[1] for r in res])
+        split = [self._split_cov_theta(t[self.cov_slice]) for t in thetas]
+        th = np.array([s_[0] for s_ in split])
+        ex = np.array([s_[1] for s_ in split])
+        means = [self.mean.mean_and_gradients(t[self.mean_slice]) for t in thetas]
+        if isinstance(self.mean, ConstantMean):
+            out = self.engine.loo_grad_batch(self._kernel_id, th, ex, mu_const=thetas[:, 0])
+        else:
+            out = self.engine.loo_grad_batch(self._kernel_id, th, ex, mus=np.array([m[0] for m in means]))
+        alpha, ikdiag, pvec, g_stat, trace_q, info = out
+        if (info != 0).any():
+            raise LinAlgError("Matrix is not positive definite")  # regression.py:501 has no guard
+        values = np.empty(len(thetas))
+        grads = zeros((len(thetas), self.n_hyperpars))
+        for t in range(len(thetas)):
+            var = 1.0 / ikdiag[t]
+            values[t] = float(-0.5 * (var * alpha[t] ** 2 + np.log(var)).sum())
+            grads[t, self.mean_slice] = array([(pvec[t] * dmu).sum() for dmu in means[t][1]])
+            g_cov = zeros(self.cov.n_params)
+            g_cov[self._stat_slice] = g_stat[t]
+            if self._wn_index is not None:
+                g_cov[self._wn_index] = 2.0 * ex[t] * trace_q[t]  # dK = 2 sigma^2 I (covariance.py:171-175)
+            grads[t, self.cov_slice] = g_cov
+        return values, grads
+
     def marginal_likelihood(self, theta: ndarray) -> float:
         """Log-marginal likelihood, R&W eq. 5.8 without the 2 pi constant (regression.py:528-542)."""
         theta = np.asarray(theta, dtype=float)
@@ -833,8 +866,11 @@ class GpRegressor:
             # its gradient per round instead of one latency-bound call per start and iteration
             from ._lockstep import lockstep_lbfgsb
 
+            batch = (self.loo_likelihood_gradient_batch if self.model_selector_gradient == self.loo_likelihood_gradient
+                     else self.marginal_likelihood_gradient_batch)
+
             def neg_batch(X):
-                f, g = self.marginal_likelihood_gradient_batch(X)
+                f, g = batch(X)
                 return -f, -g
 
             results = lockstep_lbfgsb(neg_batch, array(starting_positions), self.hp_bounds)
@@ -845,11 +881,14 @@ class GpRegressor:
         return sorted(results, key=lambda r: r[1])[0][0]
 
     def _lockstep_search(self):
-        """The multi-start search runs in lockstep when its objective is the marginal likelihood of a kernel with a
-        fused device gradient and the problem is small enough for batched (lockstep) device evaluations; the values of
-        a start are then those of `launch_bfgs` evaluated through the same batched kernels (`batch_independent_values`)."""
-        return (self.model_selector_gradient == self.marginal_likelihood_gradient and not self._generic
-                and self._mix is None and self._het_slice is None and self._y_cov is None
+        """The multi-start search runs in lockstep when its objective is the marginal likelihood or (round 4) the
+        leave-one-out likelihood of a kernel with a fused device gradient and the problem is small enough for batched
+        (lockstep) device evaluations; the values of a start are then those of `launch_bfgs` evaluated through the same
+        batched kernels (`batch_independent_values`).  ChangePoint mixtures and HeteroscedasticNoise carry per-point terms
+        (window weights, one variance per point and hyper-parameter vector) the batched kernels do not take: their
+        starts run one after another."""
+        return (self.model_selector_gradient in (self.marginal_likelihood_gradient, self.loo_likelihood_gradient)
+                and not self._generic and self._mix is None and self._het_slice is None and self._y_cov is None
                 and self.engine.capacity() <= 4096)
 
     def __str__(self):

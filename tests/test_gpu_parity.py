@@ -552,6 +552,42 @@ def test_batched_gradient_equals_single_evaluations(gp_mod, kid, wn, mean):
         check(a.hyperpars, serial[0], 1e-6, "theta*: lockstep vs serial search")
 
 
+@pytest.mark.parametrize("kid,wn,mean", [(wl.SE, False, "const"), (wl.RQ, True, "const"), (wl.SE, True, "linear")])
+def test_batched_loo_gradient_equals_single_evaluations(gp_mod, kid, wn, mean):
+    """gpmi_loo_grad_batch (lockstep: K-build, factorisation, sweeps, L^-T, diag(K^-1), the two SYRKs, the LOO vectors, the
+    fused contraction all with the batch in blockIdx.z) against one-at-a-time `loo_likelihood_gradient` calls
+    (regression.py:489-526): value and every gradient component, ragged batch sizes."""
+    n, d = 600, 3
+    x, y, e = wl.synthetic_dataset(23, n, d)
+    cov = kernel_cls(gp_mod, kid)()
+    if wn:
+        cov = cov + gp_mod.WhiteNoise()
+    kw = dict(kernel=cov)
+    if mean == "linear":
+        kw["mean"] = gp_mod.LinearMean
+    thetas = wl.theta_set(kid, y, d, 7)
+    if wn:
+        thetas = np.hstack([thetas, np.linspace(-3.0, -1.0, len(thetas))[:, None]])
+    if mean == "linear":
+        rng = np.random.default_rng(4)
+        thetas = np.hstack([thetas[:, :1], 0.2 * rng.standard_normal((len(thetas), d)), thetas[:, 1:]])
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=thetas[0], cross_val=True, **kw)
+    single = [gp.loo_likelihood_gradient(t) for t in thetas]
+    for b in (7, 3, 1):
+        f, g = gp.loo_likelihood_gradient_batch(thetas[:b])
+        check(f, [r[0] for r in single[:b]], 1e-11, f"LOO likelihood, batch of {b}")
+        for k in range(b):
+            check_each(g[k], single[k][1], 1e-10, what=f"LOO gradient, batch of {b}", etol=1e-6)
+    if kid == wl.SE and not wn:
+        # the cross-validation search in lockstep ends where the start-by-start search ends
+        np.random.seed(5)
+        a = gp_mod.GpRegressor(x, y, y_err=e, cross_val=True, n_starts=3, **kw)
+        assert a._lockstep_search()
+        starts = [l[0] for l in a.search_log]
+        serial = sorted((a.launch_bfgs(s0) for s0 in starts), key=lambda r: r[1])[0]
+        check(a.loo_likelihood(a.hyperpars), -serial[1], 1e-8, "LOO at the optimum: lockstep vs serial search")
+
+
 def test_rccl_gather_single_rank(gp_mod):
     """gpmi_comm_* with world = 1 (the only RCCL configuration a 1-GPU box offers): unique id,
     communicator, all-gather through the library's own stream."""
@@ -1027,7 +1063,10 @@ def test_multistart_bfgs_reproduces_reference_search(golden, gp_mod, tag, kw):
         kw["kernel"] = gp_mod.RationalQuadratic
     np.random.seed(3)
     gp = gp_mod.GpRegressor(x, y, y_err=e, optimizer="bfgs", n_starts=4, **kw)
-    log = gp.search_log  # (start, optimum, objective) per run; the LML search advances its runs in lockstep (round 3)
+    # (start, optimum, objective) per run; the runs advance in lockstep: off gpmi_lml_grad_batch (round 3) and, for the
+    # cross-validation objective, off gpmi_loo_grad_batch (round 4)
+    log = gp.search_log
+    assert gp._lockstep_search()
     check(np.array(gp.hp_bounds, dtype=float), g[f"ms_{tag}_bounds"], 1e-12, "bounds")
     # same random numbers in the same order; the bounds they scale come from the O(N log N) identity (1e-15 apart)
     check(np.array([l[0] for l in log]), g[f"ms_{tag}_starts"], 1e-13, "start positions")

@@ -17,7 +17,7 @@ for sub in ("bench", "cfg2", "cfg3", "cfg4", "cfg5", "lmlgrad", "pt"):
     st = stats_of(sub)
     if st:
         shutil.copy(st, os.path.join(pr, f"{tag}_{sub}_kernel_stats.csv"))
-for name in ("cfg2.txt", "cfg3.txt", "cfg4.txt", "cfg5.txt", "lmlgrad.txt", "pt.json", "pt16.json", "pt_traced.json", "propose.json", "bench_timeline.txt"):
+for name in ("cfg2.txt", "cfg3.txt", "cfg4.txt", "cfg5.txt", "lmlgrad.txt", "pt.json", "pt16.json", "pt_traced.json", "propose.json", "search.json", "bench_timeline.txt"):
     src = os.path.join(go, name)
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(pr, f"{tag}_{name}"))

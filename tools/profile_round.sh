@@ -23,6 +23,7 @@ timeout 300 python3 tools/config5_bench.py 50 > $out/pt.json 2> $out/pt_plain.er
 timeout 300 python3 tools/config5_bench.py 20 16 > $out/pt16.json 2>> $out/pt_plain.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/pt -- python3 tools/config5_bench.py 10 > $out/pt_traced.json 2> $out/pt.err
 timeout 300 python3 tools/propose_bench.py 4096 32 > $out/propose.json 2> $out/propose.err
+timeout 300 python3 tools/search_time.py > $out/search.json 2> $out/search.err
 # keep the stats, drop the bulky traces (gpurun_out is capped at 64 MiB)
 find $out -name "*kernel_trace.csv" -delete
 find $out -name "*agent_info.csv" -delete

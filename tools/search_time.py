@@ -1,5 +1,7 @@
 """Constructor-with-search time (multi-start L-BFGS-B over the hyper-parameters, regression.py:585-605) for BASELINE
-configs 1 and 4, lockstep (one batched gradient evaluation per round for all starts) against one start after another.
+configs 1 and 4, lockstep (one batched gradient evaluation per round for all starts) against one start after another;
+for the marginal likelihood and (round 4: gpmi_loo_grad_batch) the cross-validation objective (cross_val=True,
+regression.py:159-164).
 usage: python tools/search_time.py"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,5 +25,16 @@ for cfg, n, d in ((1, 512, 2), (5, 2048, 4), (4, 4096, 4)):
         row[mode + "_seconds"] = time.perf_counter() - t0
         row[mode + "_lml"] = float(gp.marginal_likelihood(gp.hyperpars))
         row["starts"] = int(2 * np.sqrt(len(gp.hp_bounds))) + 1
+    for mode in ("serial", "lockstep"):
+        np.random.seed(3)
+        GpRegressor._lockstep_search = (lambda self: False) if mode == "serial" else keep
+        if mode == "serial":  # warm-up of the cross-validation path
+            GpRegressor(x, y, y_err=e, hyperpars=wl.timing_theta(wl.SE, y, d), cross_val=True).loo_likelihood_gradient_batch(
+                np.array([wl.timing_theta(wl.SE, y, d)] * 5))
+        t0 = time.perf_counter()
+        gp = GpRegressor(x, y, y_err=e, cross_val=True)
+        row["cross_val_" + mode + "_seconds"] = time.perf_counter() - t0
+        row["cross_val_" + mode + "_loo"] = float(gp.loo_likelihood(gp.hyperpars))
+    GpRegressor._lockstep_search = keep
     out.append(row)
 print(json.dumps(out, indent=1))
