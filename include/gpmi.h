@@ -188,6 +188,15 @@ int gpmi_gradient(gpmi_ctx* ctx, const double* pts_host, int64_t m, double* gmu_
 int gpmi_loo_grad(gpmi_ctx* ctx, int kernel, const double* theta_host, int n_theta, double extra_diag,
                   const double* mu_host, double* alpha_host, double* ikdiag_host, double* p_host,
                   double* grad_theta_host, double* trace_q_host, int* info);
+/* gpmi_lml_grad_batch with noise variances of their own for every evaluation (noise_var_host: T x n) and the diagonal of
+ * alpha alpha^T - K^-1 back (qdiag_host: T x n): what HeteroscedasticNoise (covariance.py:608-690: one variance per point IS
+ * a hyper-parameter, its gradient is exp(2 theta_i) qdiag_i, :683-689) needs from a batch - the single-evaluation form is
+ * gpmi_set_noise + gpmi_lml_grad + gpmi_lml_grad_qdiag. */
+int gpmi_lml_grad_batch_noise(gpmi_ctx* ctx, int kernel, int64_t T, const double* thetas_host, int n_theta,
+                              const double* extra_diag_host, const double* mus_host, const double* mu_const_host,
+                              const double* noise_var_host, double* lml_host, double* grad_theta_host,
+                              double* trace_q_host, double* alpha_host, double* qdiag_host, int* info);
+
 /* The same for T hyper-parameter vectors at once (thetas: T x n_theta, extra / mu_const: T values or mus: T x n; outputs
  * T x n, T x n_theta, T): for n <= 4096 every launch carries the whole chunk (lockstep, like gpmi_lml_grad_batch); the
  * multi-start search with the cross-validation objective (regression.py:159-164, 585-605) advances all its starts on it. */

@@ -242,9 +242,10 @@ void free_data(gpmi_ctx* c) {
   fr(c->bGws);  //  another size kept using the first one's)
   fr(c->bGout);
   fr(c->bLoo);
+  fr(c->bNoise);
   if (c->h_bGout) (void)hipHostFree(c->h_bGout);
   c->h_bGout = nullptr;
-  c->bgrad_cap = c->bgrad_ntheta = c->bLoo_cap = 0;
+  c->bgrad_cap = c->bgrad_ntheta = c->bLoo_cap = c->bNoise_cap = 0;
   if (c->bInfo) (void)hipFree(c->bInfo);
   c->bInfo = nullptr;
   if (c->bParams) (void)hipFree(c->bParams);
@@ -414,7 +415,8 @@ int ensure_batch_ws(gpmi_ctx* c, int want) {
   fr(c->bGws);
   fr(c->bGout);
   fr(c->bLoo);
-  c->bLoo_cap = 0;
+  fr(c->bNoise);
+  c->bLoo_cap = c->bNoise_cap = 0;
   if (c->h_bGout) (void)hipHostFree(c->h_bGout);
   c->h_bGout = nullptr;
   c->bgrad_cap = c->bgrad_ntheta = 0;
@@ -489,6 +491,12 @@ int ensure_query_ws(gpmi_ctx* c, int64_t mp) {
 
 // ---- instrumentation ----------------------------------------------------------------
 namespace {
+__global__ void qdiag_batched_kernel(const double* __restrict__ iK, int64_t ld, const double* __restrict__ alpha,
+                                     double* __restrict__ out, int64_t n, int64_t sMat, int64_t sVec, int64_t sOut) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, z = blockIdx.z;
+  if (i < n) out[z * sOut + i] = alpha[z * sVec + i] * alpha[z * sVec + i] - iK[z * sMat + i * ld + i];
+}
+
 __global__ void negate_kernel(double* v, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] = -v[i];
@@ -973,9 +981,12 @@ int gpmi_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
   return GPMI_OK;
 }
 
-int gpmi_lml_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int n_theta, const double* extra,
-                        const double* mus, const double* mu_const, double* lml, double* grad_theta, double* trace_q,
-                        double* alpha_out, int* info) {
+// noise_batch (T x n, host) / qdiag_out (T x n, host): the per-problem noise variances of HeteroscedasticNoise
+// (covariance.py:608-690: they are hyper-parameters) and the diagonal of Q = alpha alpha^T - K^-1 their gradient needs;
+// both NULL for the plain form
+static int lml_grad_batch_impl(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int n_theta, const double* extra,
+                               const double* mus, const double* mu_const, const double* noise_batch, double* lml,
+                               double* grad_theta, double* trace_q, double* alpha_out, double* qdiag_out, int* info) {
   if (!c) return GPMI_ERR_ARG;
   ARGCHK(c, T >= 1 && T <= RED_SLOTS, "T out of range");
   ARGCHK(c, thetas && lml && grad_theta, "thetas / lml / grad_theta is NULL");
@@ -989,11 +1000,15 @@ int gpmi_lml_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas
       const double* mu_t = mus ? mus + t * c->n : mu_row.data();
       if (!mus) std::fill(mu_row.begin(), mu_row.end(), mu_const[t]);
       int inf = 0;
+      if (noise_batch)
+        if (int rc = gpmi_set_noise(c, noise_batch + t * c->n)) return rc;
       const int rc = gpmi_lml_grad(c, kernel, thetas + t * n_theta, n_theta, extra ? extra[t] : 0.0, mu_t, lml + t,
                                    grad_theta + t * n_theta, trace_q ? trace_q + t : nullptr,
                                    alpha_out ? alpha_out + t * c->n : nullptr, &inf);
       if (info) info[t] = inf;
       if (rc != GPMI_OK) return rc;
+      if (qdiag_out)
+        if (int rc2 = gpmi_lml_grad_qdiag(c, qdiag_out + t * c->n)) return rc2;
     }
     return GPMI_OK;
   }
@@ -1008,6 +1023,13 @@ int gpmi_lml_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas
          "gpmi_lml_grad_batch: an asynchronous batch is pending on this handle (gpmi_lml_batch_wait first)");
   if (int rc = ensure_batch_ws(c, (int)(T < 64 ? (T < 2 ? 2 : T) : 64))) return rc;
   if (int rc = ensure_batch_grad_ws(c, c->bcap, n_theta)) return rc;
+  if ((noise_batch || qdiag_out) && c->bNoise_cap < c->bgrad_cap) {
+    if (c->bNoise) (void)hipFree(c->bNoise);
+    c->bNoise = nullptr;
+    c->bNoise_cap = 0;
+    HIPCHK(c, hipMalloc(&c->bNoise, sizeof(double) * c->np * c->bgrad_cap));
+    c->bNoise_cap = c->bgrad_cap;
+  }
   hipStream_t s = c->lanes[1].stream;
   const int nt = (int)(c->np / GPMI_NB);
   const BatchShape shape0{1, c->np * c->ld, (c->np / GPMI_NB) * GPMI_NB * GPMI_NB, 4 * c->np};
@@ -1022,8 +1044,11 @@ int gpmi_lml_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas
     else
       HIPCHK(c, hipMemcpyAsync(c->bMu, mu_const + t0, sizeof(double) * B, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemsetAsync(c->bInfo, 0, sizeof(int) * B, s));
-    launch_kbuild_square_batched(s, ps[0].kernel, c->bParams, B, c->x, c->n, c->np, c->noise, c->bA, c->ld, bs.sMat,
-                                 (int)c->d);
+    if (noise_batch)
+      HIPCHK(c, hipMemcpy2DAsync(c->bNoise, sizeof(double) * c->np, noise_batch + t0 * c->n, sizeof(double) * c->n,
+                                 sizeof(double) * c->n, B, hipMemcpyHostToDevice, s));
+    launch_kbuild_square_batched(s, ps[0].kernel, c->bParams, B, c->x, c->n, c->np, noise_batch ? c->bNoise : c->noise,
+                                 c->bA, c->ld, bs.sMat, (int)c->d, noise_batch ? c->np : 0);
     potrf_lower_batched(c, s, c->bA, c->np, c->ld, c->bInv, c->bInfo, bs);
     launch_residual_batched(s, c->y, mus ? c->bMu : nullptr, mus ? nullptr : c->bMu, c->bVec + 2 * c->np, c->n, c->np,
                             bs);
@@ -1037,6 +1062,12 @@ int gpmi_lml_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas
                 nullptr, syrk);
     launch_lml_grad_batched(s, c->bParams, B, n_theta, c->x, c->n, c->np, c->bA, c->ld, bs.sMat, alpha_dev, alpha_dev,
                             bs.sVec, c->bGws, c->bGout);
+    if (qdiag_out) {  // diag(alpha alpha^T - K^-1) per problem, into the noise buffer (consumed by the build above)
+      hipLaunchKernelGGL(qdiag_batched_kernel, dim3((unsigned)((c->n + 255) / 256), 1, (unsigned)B), dim3(256), 0, s, c->bA,
+                         c->ld, alpha_dev, c->bNoise, c->n, bs.sMat, bs.sVec, c->np);
+      HIPCHK(c, hipMemcpy2DAsync(qdiag_out + t0 * c->n, sizeof(double) * c->n, c->bNoise, sizeof(double) * c->np,
+                                 sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_bRed, c->bRed, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(c->h_bGout, c->bGout, sizeof(double) * W * B, hipMemcpyDeviceToHost, s));
@@ -1055,6 +1086,23 @@ int gpmi_lml_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas
     }
   }
   return GPMI_OK;
+}
+
+int gpmi_lml_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int n_theta, const double* extra,
+                        const double* mus, const double* mu_const, double* lml, double* grad_theta, double* trace_q,
+                        double* alpha_out, int* info) {
+  return lml_grad_batch_impl(c, kernel, T, thetas, n_theta, extra, mus, mu_const, nullptr, lml, grad_theta, trace_q,
+                             alpha_out, nullptr, info);
+}
+
+int gpmi_lml_grad_batch_noise(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int n_theta, const double* extra,
+                              const double* mus, const double* mu_const, const double* noise_var, double* lml,
+                              double* grad_theta, double* trace_q, double* alpha_out, double* qdiag_out, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, noise_var && qdiag_out, "noise_var / qdiag is NULL");
+  ARGCHK(c, !c->ycov, "per-point noise hyper-parameters need diagonal data errors");
+  return lml_grad_batch_impl(c, kernel, T, thetas, n_theta, extra, mus, mu_const, noise_var, lml, grad_theta, trace_q,
+                             alpha_out, qdiag_out, info);
 }
 
 // Leave-one-out log-likelihood terms and gradient (regression.py:489-526) for T hyper-parameter vectors in lockstep: the

@@ -128,6 +128,8 @@ struct gpmi_ctx {
   double* bMu = nullptr;
   double* bB2 = nullptr;     // second matrix per problem (L^-T), gradient batches only
   double* bGws = nullptr;    // partial sums of the fused contraction
+  double* bNoise = nullptr;  // gpmi_lml_grad_batch_noise: one noise-variance vector per problem
+  int bNoise_cap = 0;
   double* bLoo = nullptr;    // gpmi_loo_grad_batch: 4 vectors per problem (diag K^-1, c1, sqrt c2, p)
   int bLoo_cap = 0;
   double* bGout = nullptr;   // (n_theta + 1) results per problem
@@ -293,7 +295,7 @@ void potrf_lower_batched(gpmi_ctx* c, hipStream_t s, double* A, int64_t np, int6
                          int* info, const BatchShape& bs);
 void launch_kbuild_square_batched(hipStream_t s, int kernel, const KParams* pdev, int batch, const double* x,
                                   int64_t n, int64_t np, const double* noise, double* A, int64_t ld,
-                                  int64_t stride, int d);
+                                  int64_t stride, int d, int64_t noise_stride = 0);
 // blocked right-looking Cholesky, in place, lower; invD receives the inverses of the diagonal blocks
 // allow_lookahead = false keeps everything on the lane's full-chip stream (several lanes running
 // concurrently already fill the chip, and their masked stream pairs would only fight for HW queues)

@@ -56,8 +56,10 @@ __global__ __launch_bounds__(256) void kbuild_batched_kernel(const KParams* __re
                                                              const double* __restrict__ x, int64_t n,
                                                              const double* __restrict__ noise,
                                                              double* __restrict__ out, int64_t ld,
-                                                             int64_t stride) {
-  kbuild_body<true, KERNEL>(pdev[blockIdx.z], x, n, x, n, noise, out + (int64_t)blockIdx.z * stride, ld, 2);
+                                                             int64_t stride, int64_t noise_stride) {
+  // noise_stride > 0: every problem has noise variances of its own (HeteroscedasticNoise: they are hyper-parameters)
+  kbuild_body<true, KERNEL>(pdev[blockIdx.z], x, n, x, n, noise + (int64_t)blockIdx.z * noise_stride,
+                            out + (int64_t)blockIdx.z * stride, ld, 2);
 }
 
 template <bool SQUARE, int KERNEL>
@@ -205,15 +207,15 @@ void launch_kbuild_square_part(hipStream_t s, const KParams& p, const double* x,
 
 void launch_kbuild_square_batched(hipStream_t s, int kernel, const KParams* pdev, int batch, const double* x,
                                   int64_t n, int64_t np, const double* noise, double* A, int64_t ld,
-                                  int64_t stride, int d) {
+                                  int64_t stride, int d, int64_t noise_stride) {
   const unsigned nt = (unsigned)(np / KT);
   dim3 grid(nt * (nt + 1) / 2, 1, (unsigned)batch);  // lower tiles only, one-dimensional (kbuild_body, mode 2)
   if (kernel == GPMI_KERNEL_SE)
     hipLaunchKernelGGL(kbuild_batched_kernel<GPMI_KERNEL_SE>, grid, dim3(256), kb_lds_bytes(d), s, pdev, x, n, noise, A,
-                       ld, stride);
+                       ld, stride, noise_stride);
   else
     hipLaunchKernelGGL(kbuild_batched_kernel<GPMI_KERNEL_RQ>, grid, dim3(256), kb_lds_bytes(d), s, pdev, x, n, noise, A,
-                       ld, stride);
+                       ld, stride, noise_stride);
 }
 
 void launch_kbuild_cross(hipStream_t s, const KParams& p, const double* U, int64_t mu, int64_t mp,

@@ -282,6 +282,22 @@ class GpEngine(_DeviceCommMixin):
                     dptr(trq), dptr(alpha), info.ctypes.data_as(C.POINTER(C.c_int)))
         return lml, grad, trq, alpha, info
 
+    def lml_grad_batch_noise(self, kernel, thetas_cov, extra_diag, noise_vars, mus=None, mu_const=None):
+        """`lml_grad_batch` with noise variances of their own for every evaluation (gpmi_lml_grad_batch_noise):
+        (lml, grad, trace_q, alpha, qdiag (T, n), info)."""
+        th = as_f64(np.atleast_2d(thetas_cov))
+        T, nth = th.shape
+        ex = as_f64(np.broadcast_to(np.asarray(extra_diag, dtype=float), (T,)))
+        nv = as_f64(np.atleast_2d(noise_vars))
+        lml, trq = np.empty(T), np.empty(T)
+        grad, alpha, qdiag = np.empty((T, nth)), np.empty((T, self.n)), np.empty((T, self.n))
+        info = np.zeros(T, dtype=np.int32)
+        mus_p = dptr(as_f64(mus)) if mus is not None else None
+        muc_p = dptr(as_f64(np.broadcast_to(np.asarray(mu_const, dtype=float), (T,)))) if mus is None else None
+        self.h.call("gpmi_lml_grad_batch_noise", kernel, T, dptr(th), nth, dptr(ex), mus_p, muc_p, dptr(nv), dptr(lml),
+                    dptr(grad), dptr(trq), dptr(alpha), dptr(qdiag), info.ctypes.data_as(C.POINTER(C.c_int)))
+        return lml, grad, trq, alpha, qdiag, info
+
     # -- prediction -------------------------------------------------------------------
     def predict(self, pts, want_var=True):
         p = as_f64(pts)

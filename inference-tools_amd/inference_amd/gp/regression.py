@@ -622,18 +622,23 @@ class GpRegressor:
         (gpmi_lml_grad_batch: for N <= 4096 the evaluations advance in lockstep, every launch carrying all of them):
         returns (lml (T,), grad (T, P)).  What the lockstep multi-start search evaluates per round."""
         thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
-        if self._generic or self._het_slice is not None or self._mix is not None:  # per-point terms: one at a time
+        if self._generic or self._mix is not None:  # the mixture's window weights are per point AND per evaluation
             res = [self.marginal_likelihood_gradient(t) for t in thetas]
             return np.array([r[0] for r in res]), np.array([r[1] for r in res])
-        split = [self._split_cov_theta(t[self.cov_slice]) for t in thetas]
-        th = np.array([s_[0] for s_ in split])
-        ex = np.array([s_[1] for s_ in split])
+        th = np.array([np.ascontiguousarray(t[self.cov_slice][self._stat_slice]) for t in thetas])
+        ex = np.array([float(np.exp(2 * t[self.cov_slice][self._wn_index])) if self._wn_index is not None else 0.0
+                       for t in thetas])
         means = [self.mean.mean_and_gradients(t[self.mean_slice]) for t in thetas]
-        if isinstance(self.mean, ConstantMean):
-            lml, g_stat, trace_q, alpha, info = self.engine.lml_grad_batch(self._kernel_id, th, ex, mu_const=thetas[:, 0])
+        mean_kw = (dict(mu_const=thetas[:, 0]) if isinstance(self.mean, ConstantMean)
+                   else dict(mus=np.array([m[0] for m in means])))
+        qdiag = None
+        if self._het_slice is not None:
+            # HeteroscedasticNoise: every evaluation has noise variances of its own (round 4: gpmi_lml_grad_batch_noise)
+            noise = np.array([self._noise_total(t[self.cov_slice]) for t in thetas])
+            lml, g_stat, trace_q, alpha, qdiag, info = self.engine.lml_grad_batch_noise(self._kernel_id, th, ex, noise,
+                                                                                        **mean_kw)
         else:
-            lml, g_stat, trace_q, alpha, info = self.engine.lml_grad_batch(self._kernel_id, th, ex,
-                                                                            mus=np.array([m[0] for m in means]))
+            lml, g_stat, trace_q, alpha, info = self.engine.lml_grad_batch(self._kernel_id, th, ex, **mean_kw)
         if (info != 0).any():
             raise LinAlgError("Matrix is not positive definite")  # regression.py:555 has no guard
         grads = zeros((len(thetas), self.n_hyperpars))
@@ -643,6 +648,8 @@ class GpRegressor:
             g_cov[self._stat_slice] = g_stat[t]
             if self._wn_index is not None:
                 g_cov[self._wn_index] = ex[t] * trace_q[t]
+            if qdiag is not None:  # dK/d ln sigma_i = 2 sigma_i^2 e_i e_i^T (covariance.py:682-686)
+                g_cov[self._het_slice] = np.exp(2 * thetas[t][self.cov_slice][self._het_slice]) * qdiag[t]
             grads[t, self.cov_slice] = g_cov
         return lml, grads
 
@@ -884,12 +891,14 @@ class GpRegressor:
         """The multi-start search runs in lockstep when its objective is the marginal likelihood or (round 4) the
         leave-one-out likelihood of a kernel with a fused device gradient and the problem is small enough for batched
         (lockstep) device evaluations; the values of a start are then those of `launch_bfgs` evaluated through the same
-        batched kernels (`batch_independent_values`).  ChangePoint mixtures and HeteroscedasticNoise carry per-point terms
-        (window weights, one variance per point and hyper-parameter vector) the batched kernels do not take: their
+        batched kernels (`batch_independent_values`).  HeteroscedasticNoise - one variance per point and evaluation - rides
+        along for the marginal likelihood (gpmi_lml_grad_batch_noise); its leave-one-out gradient and the ChangePoint
+        mixtures (window weights per point and evaluation, several sub-kernel builds) have no batched kernels: their
         starts run one after another."""
-        return (self.model_selector_gradient in (self.marginal_likelihood_gradient, self.loo_likelihood_gradient)
-                and not self._generic and self._mix is None and self._het_slice is None and self._y_cov is None
-                and self.engine.capacity() <= 4096)
+        lml = self.model_selector_gradient == self.marginal_likelihood_gradient
+        loo = self.model_selector_gradient == self.loo_likelihood_gradient
+        return ((lml or (loo and self._het_slice is None)) and not self._generic and self._mix is None
+                and self._y_cov is None and self.engine.capacity() <= 4096)
 
     def __str__(self):
         pad = max(len(label) for label in self.hyperpar_labels) + 2

@@ -881,6 +881,13 @@ def test_heteroscedastic_noise_vs_reference(golden, gp_mod, tag, with_err):
     check([r[0] for r in res], g[f"{tag}_lml2"], what="lml (gradient call)")
     for r, ref in zip(res, g[f"{tag}_grad"]):
         check_each(r[1], ref, what="gradient")
+    # the same through the lockstep batch (gpmi_lml_grad_batch_noise: every evaluation carries noise variances of its own):
+    # against the reference's values, and the multi-start search may now run its starts together
+    fb, gb = gp.marginal_likelihood_gradient_batch(th)
+    check(fb, g[f"{tag}_lml2"], what="lml (batched gradient call)")
+    for row, ref in zip(gb, g[f"{tag}_grad"]):
+        check_each(row, ref, what="gradient (batched)")
+    assert gp._lockstep_search()
     check(gp.K_xx, g[f"{tag}_K_xx"], 1e-13, "K_xx after evaluations at other thetas")
     mu, sig = gp(wl.query_points(77, 40, d))
     check(mu, g[f"{tag}_mu"], what="mu")
