@@ -1,0 +1,86 @@
+// Shared by the translation units of the C-ABI (api.hip: handle, lanes, workspaces, lifecycle, instrumentation;
+// api_regression.hip: the GpRegressor entry points; api_mix.hip: ChangePoint mixtures and per-point noise; api_linv.hip:
+// GpLinearInverter; api_dense.hip: plugin covariance functions and the rank-one append): error macros and the helpers
+// every entry point is built from.  Internal - the public interface is include/gpmi.h.
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "gpmi_internal.h"
+
+#define HIPCHK(ctx, expr)                                                                   \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                      \
+      return (e__ == hipErrorOutOfMemory) ? GPMI_ERR_NOMEM : GPMI_ERR_HIP;                  \
+    }                                                                                       \
+  } while (0)
+
+#define ARGCHK(ctx, cond, msg) \
+  do {                         \
+    if (!(cond)) {             \
+      (ctx)->err = (msg);      \
+      return GPMI_ERR_ARG;     \
+    }                          \
+  } while (0)
+
+// a negative `info` is written by the flag-ordered kernels when a poll timed out: GPMI_INFO_FLOW_TIMEOUT by the tile-task
+// factorisation (potrf_flow.hip) - the one case the stream-ordered schedule (GPMI_OPT_NO_FLOW) cures, marked "[flow-tail]"
+// in the error text for the caller that wants to repeat the call -, GPMI_ERR_INTERNAL by the triangular sweeps
+#define INFOCHK(ctx, inf)                                                                                     \
+  do {                                                                                                        \
+    if ((inf) < 0) {                                                                                          \
+      (ctx)->err = (inf) == GPMI_INFO_FLOW_TIMEOUT                                                            \
+                       ? "internal error: the tile-task factorisation timed out [flow-tail]"                  \
+                       : "internal error: a flag-ordered triangular sweep timed out";                         \
+      return GPMI_ERR_INTERNAL;                                                                               \
+    }                                                                                                         \
+  } while (0)
+
+constexpr int RED_SLOTS = 8192;  // per-lane result slots for batched evaluations
+
+// one evaluation of the mixture covariance K = sum_m diag(g_m) K_m diag(g_m) + extra I (+ data errors)
+struct MixEval {
+  int nk;
+  const KParams* p;   // nk sub-kernels (their extra_diag is ignored)
+  const double* g;    // nk x np device weights (row m: g_m; padding 1 for m = 0, else 0)
+  double extra;       // WhiteNoise variance
+  double* scratch;    // np x ld
+  const double* zero; // np zeros
+};
+
+extern thread_local std::string g_create_err;
+
+// api.hip
+int lane_streams(gpmi_ctx* c, Lane& L);
+bool ensure_masked_pair(gpmi_ctx* c, Lane& L, int k);
+int lane_masked_streams(gpmi_ctx* c, Lane& L);
+int lane_alloc(gpmi_ctx* c, Lane& L);
+void lane_free(Lane& L);
+int ensure_lanes(gpmi_ctx* c, size_t count);
+void free_data(gpmi_ctx* c);
+int make_params(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double extra, KParams& p);
+int set_device(gpmi_ctx* c);
+void build_mix_square(gpmi_ctx* c, hipStream_t s, const MixEval& mx, double* dst, bool lower_only);
+int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const double* mu_dev, double mu_const, int slot, bool allow_lookahead = true,
+                               const MixEval* mix = nullptr);
+int ensure_second_matrix(gpmi_ctx* c, Lane& L);
+int ensure_inv2(gpmi_ctx* c, Lane& F, hipStream_t s);
+int ensure_trsm_panel(gpmi_ctx* c, int64_t rows);
+int enqueue_inverse_factor(gpmi_ctx* c, Lane& L, Lane& F);
+int ensure_batch_ws(gpmi_ctx* c, int want);
+int ensure_batch_grad_ws(gpmi_ctx* c, int want, int n_theta);
+int ensure_query_ws(gpmi_ctx* c, int64_t mp);
+void linv_free(LinvState& S);  // api_linv.hip
+// v <- -v;  out_i = alpha_i^2 - iK_ii (one problem / problem z of a batch)
+void launch_negate(hipStream_t s, double* v, int64_t n);
+void launch_qdiag(hipStream_t s, const double* iK, int64_t ld, const double* alpha, double* out, int64_t n);
+void launch_qdiag_batched(hipStream_t s, int batch, const double* iK, int64_t ld, const double* alpha, double* out, int64_t n,
+                          int64_t sMat, int64_t sVec, int64_t sOut);

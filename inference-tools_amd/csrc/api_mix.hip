@@ -1,0 +1,342 @@
+// C-ABI of libgpmi (include/gpmi.h): mixture covariance (ChangePoint) and per-point noise hyper-parameters (HeteroscedasticNoise).
+// (split from api.hip in round 4; the handle, the lanes and the helpers these entry points are built from: api.hip,
+// api_internal.h)
+#include "api_internal.h"
+
+// ---- mixture covariance (ChangePoint) -------------------------------------------------------------------
+namespace {
+
+// parse the sub-kernels, upload the weights: fills ps[nk] and the device buffers of the context
+int mix_prepare(gpmi_ctx* c, int nk, const int* kernels, const double* thetas, const int* n_thetas,
+                const double* g_host, KParams* ps) {
+  ARGCHK(c, c->n > 0, "gpmi_set_data has not been called");
+  ARGCHK(c, nk >= 1 && nk <= GPMI_MAX_MIX, "number of sub-kernels out of range (1..4)");
+  ARGCHK(c, kernels && thetas && n_thetas && g_host, "NULL argument");
+  int off = 0;
+  for (int m = 0; m < nk; ++m) {
+    if (int rc = make_params(c, kernels[m], thetas + off, n_thetas[m], 0.0, ps[m])) return rc;
+    off += n_thetas[m];
+  }
+  if (int rc = set_device(c)) return rc;
+  if (!c->mix_g) HIPCHK(c, hipMalloc(&c->mix_g, sizeof(double) * GPMI_MAX_MIX * c->np));
+  if (!c->mix_scratch) HIPCHK(c, hipMalloc(&c->mix_scratch, sizeof(double) * c->np * c->ld));
+  if (!c->mix_zero) {
+    HIPCHK(c, hipMalloc(&c->mix_zero, sizeof(double) * c->np));
+    HIPCHK(c, hipMemset(c->mix_zero, 0, sizeof(double) * c->np));
+  }
+  if (int rc = gpmi_sync(c)) return rc;  // nothing may still be reading the previous weights
+  std::vector<double> g((size_t)nk * c->np);
+  for (int m = 0; m < nk; ++m)
+    for (int64_t i = 0; i < c->np; ++i)
+      g[(size_t)m * c->np + i] = i < c->n ? g_host[(size_t)m * c->n + i] : (m == 0 ? 1.0 : 0.0);
+  HIPCHK(c, hipMemcpy(c->mix_g, g.data(), sizeof(double) * nk * c->np, hipMemcpyHostToDevice));
+  return GPMI_OK;
+}
+
+int ensure_q3(gpmi_ctx* c) {
+  if (c->q3_cap >= c->mq_cap && c->Q3) return GPMI_OK;
+  if (c->Q3) (void)hipFree(c->Q3);
+  c->Q3 = nullptr;
+  HIPCHK(c, hipMalloc(&c->Q3, sizeof(double) * c->mq_cap * c->ld));
+  c->q3_cap = c->mq_cap;
+  return GPMI_OK;
+}
+
+// c->Q (mp x ld) = sum_m diag(gq_m) K_m(pts, x) diag(g_m); gq_dev: nk x mp device weights of the query points
+void build_mix_cross(gpmi_ctx* c, hipStream_t s, const double* gq_dev, int64_t mc, int64_t mp) {
+  for (int m = 0; m < c->mix_nk; ++m) {
+    launch_kbuild_cross(s, c->mix_p[m], c->pts, mc, mp, c->x, c->n, c->np, c->Q3, c->ld);
+    launch_scale_add(s, c->Q, c->ld, c->Q3, c->ld, gq_dev + (int64_t)m * mp, c->mix_g + (int64_t)m * c->np, mp,
+                     c->np, m > 0);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpmi_fit_mix(gpmi_ctx* c, int nk, const int* kernels, const double* thetas, const int* n_thetas,
+                 const double* g_host, double extra_diag, const double* mu, double* alpha_out,
+                 double* logdet_out, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  KParams ps[GPMI_MAX_MIX];
+  if (int rc = mix_prepare(c, nk, kernels, thetas, n_thetas, g_host, ps)) return rc;
+  ARGCHK(c, mu != nullptr, "mu is NULL");
+  Lane& L = c->lanes[0];
+  hipStream_t s = L.stream;
+  double* mu_dev = L.vec + 3 * c->np;
+  const MixEval mx{nk, ps, c->mix_g, extra_diag, c->mix_scratch, c->mix_zero};
+  HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
+  if (int rc = enqueue_factor_and_forward(c, L, ps[0], mu_dev, 0.0, 0, true, &mx)) return rc;
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, c->alpha, L.info);
+  HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (alpha_out)
+    HIPCHK(c, hipMemcpyAsync(alpha_out, c->alpha, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  if (logdet_out) *logdet_out = L.h_red[1];
+  INFOCHK(c, L.h_info[0]);
+  if (info) *info = L.h_info[0];
+  c->mix_nk = nk;
+  for (int m = 0; m < nk; ++m) c->mix_p[m] = ps[m];
+  c->fit_params = ps[0];
+  c->fitted = (L.h_info[0] == 0);
+  return GPMI_OK;
+}
+
+int gpmi_lml_mix(gpmi_ctx* c, int nk, const int* kernels, const double* thetas, const int* n_thetas,
+                 const double* g_host, double extra_diag, const double* mu, double* lml, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  KParams ps[GPMI_MAX_MIX];
+  if (int rc = ensure_lanes(c, 2)) return rc;
+  // the weights of a fitted mixture live in the same device buffer: an evaluation at other hyper-parameters
+  // invalidates them for gpmi_predict_mix until the next gpmi_fit_mix (the host wrapper re-fits lazily)
+  if (int rc = mix_prepare(c, nk, kernels, thetas, n_thetas, g_host, ps)) return rc;
+  ARGCHK(c, mu && lml, "mu / lml is NULL");
+  c->fitted = false;
+  Lane& L = c->lanes[1];
+  hipStream_t s = L.stream;
+  double* mu_dev = L.vec + 3 * c->np;
+  const MixEval mx{nk, ps, c->mix_g, extra_diag, c->mix_scratch, c->mix_zero};
+  HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
+  if (int rc = enqueue_factor_and_forward(c, L, ps[0], mu_dev, 0.0, 0, true, &mx)) return rc;
+  HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  INFOCHK(c, L.h_info[0]);
+  if (info) *info = L.h_info[0];
+  *lml = (L.h_info[0] == 0) ? (-0.5 * L.h_red[0] - L.h_red[1]) : -1e50;
+  return GPMI_OK;
+}
+
+int gpmi_lml_grad_mix(gpmi_ctx* c, int nk, const int* kernels, const double* thetas, const int* n_thetas,
+                      const double* g_host, double extra_diag, const double* mu, double* lml,
+                      double* grad_thetas, double* hrows, double* alpha_out, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  KParams ps[GPMI_MAX_MIX];
+  if (int rc = ensure_lanes(c, 2)) return rc;
+  if (int rc = mix_prepare(c, nk, kernels, thetas, n_thetas, g_host, ps)) return rc;
+  ARGCHK(c, mu && lml && grad_thetas && hrows, "mu / lml / grad_thetas / hrows is NULL");
+  c->fitted = false;
+  Lane& L = c->lanes[1];
+  if (int rc = ensure_second_matrix(c, L)) return rc;
+  int max_nt = 0, tot_nt = 0;
+  for (int m = 0; m < nk; ++m) {
+    max_nt = n_thetas[m] > max_nt ? n_thetas[m] : max_nt;
+    tot_nt += n_thetas[m];
+  }
+  const int64_t need = grad_ws_doubles(c->np, max_nt);
+  if (L.gws_doubles < need) {
+    if (L.gws) (void)hipFree(L.gws);
+    L.gws = nullptr;
+    L.gws_doubles = 0;
+    HIPCHK(c, hipMalloc(&L.gws, sizeof(double) * need));
+    L.gws_doubles = need;
+  }
+  hipStream_t s = L.stream;
+  double* mu_dev = L.vec + 3 * c->np;
+  double* alpha_dev = L.vec + c->np;
+  double* ua = L.vec + 2 * c->np;  // g_m o alpha
+  double* gout = L.red + 16;       // (n_theta_m + 1) values per sub-kernel, consecutive
+  double* hdev = c->mix_scratch;   // nk x np row sums: the scratch matrix is free once K is factorised
+  const MixEval mx{nk, ps, c->mix_g, extra_diag, c->mix_scratch, c->mix_zero};
+  HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
+  if (int rc = enqueue_factor_and_forward(c, L, ps[0], mu_dev, 0.0, 0, true, &mx)) return rc;
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, alpha_dev, L.info);
+  // K^-1 = L^-T L^-1, lower tiles over L, then both triangles (it is read row-wise below)
+  if (int rc = enqueue_inverse_factor(c, L, L)) return rc;
+  launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, 1, L.A, c->ld, L.B2, c->ld, L.B2, c->ld,
+              (int)(c->np / GPMI_NB), (int)(c->np / GPMI_NB), (int)c->np);
+  launch_mirror_lower(s, L.A, c->ld, c->np);
+  int goff = 0;
+  for (int m = 0; m < nk; ++m) {
+    const double* gm = c->mix_g + (int64_t)m * c->np;
+    // sub-kernel parameters: 1/2 sum Q o (D_m dK_m D_m) = 1/2 sum (D_m Q D_m) o dK_m, the fused contraction on
+    // the scaled inverse with u = v = g_m o alpha
+    launch_scale_add(s, L.B2, c->ld, L.A, c->ld, gm, gm, c->np, c->np, false);
+    launch_vec_mul(s, gm, alpha_dev, ua, c->np);
+    launch_lml_grad(s, ps[m], n_thetas[m], c->x, c->n, c->np, L.B2, c->ld, ua, ua, L.gws, gout + goff);
+    goff += n_thetas[m] + 1;
+    // window parameters: h_m(i) = sum_j Q_ij K_m,ij g_m(j)  (the host contracts it with d g_m / d phi)
+    KParams pm = ps[m];
+    pm.extra_diag = 0.0;
+    launch_kbuild_square(s, pm, c->x, c->n, c->np, c->mix_zero, L.B2, c->ld, false);
+    launch_mix_rowsum(s, L.A, L.B2, c->ld, alpha_dev, gm, hdev + (int64_t)m * c->np, c->n);
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(L.h_red + 16, gout, sizeof(double) * goff, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
+  for (int m = 0; m < nk; ++m)
+    HIPCHK(c, hipMemcpyAsync(hrows + (int64_t)m * c->n, hdev + (int64_t)m * c->np, sizeof(double) * c->n,
+                             hipMemcpyDeviceToHost, s));
+  if (alpha_out) HIPCHK(c, hipMemcpyAsync(alpha_out, alpha_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  *lml = -0.5 * L.h_red[0] - L.h_red[1];
+  goff = 0;
+  int o = 0;
+  for (int m = 0; m < nk; ++m) {
+    for (int j = 0; j < n_thetas[m]; ++j) grad_thetas[o++] = L.h_red[16 + goff + j];
+    goff += n_thetas[m] + 1;
+  }
+  (void)tot_nt;
+  INFOCHK(c, L.h_info[0]);
+  if (info) *info = L.h_info[0];
+  return GPMI_OK;
+}
+
+int gpmi_loo_terms_mix(gpmi_ctx* c, int nk, const int* kernels, const double* thetas, const int* n_thetas,
+                       const double* g_host, double extra_diag, const double* mu, double* alpha_out,
+                       double* ikdiag, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  KParams ps[GPMI_MAX_MIX];
+  if (int rc = ensure_lanes(c, 2)) return rc;
+  if (int rc = mix_prepare(c, nk, kernels, thetas, n_thetas, g_host, ps)) return rc;
+  ARGCHK(c, mu && alpha_out && ikdiag, "mu / alpha / ikdiag is NULL");
+  c->fitted = false;
+  Lane& L = c->lanes[1];
+  if (int rc = ensure_second_matrix(c, L)) return rc;
+  hipStream_t s = L.stream;
+  double* mu_dev = L.vec + 3 * c->np;
+  double* alpha_dev = L.vec + c->np;
+  double* diag_dev = L.vec + 2 * c->np;
+  const MixEval mx{nk, ps, c->mix_g, extra_diag, c->mix_scratch, c->mix_zero};
+  HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
+  if (int rc = enqueue_factor_and_forward(c, L, ps[0], mu_dev, 0.0, 0, true, &mx)) return rc;
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, alpha_dev, L.info);
+  if (int rc = enqueue_inverse_factor(c, L, L)) return rc;
+  launch_rows_sumsq(s, L.B2, c->ld, c->np, c->np, 0.0, diag_dev);  // -diag(K^-1): squared row norms of L^-T
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(alpha_out, alpha_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(ikdiag, diag_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  for (int64_t i = 0; i < c->n; ++i) ikdiag[i] = -ikdiag[i];
+  INFOCHK(c, L.h_info[0]);
+  if (info) *info = L.h_info[0];
+  return GPMI_OK;
+}
+
+int gpmi_predict_mix(gpmi_ctx* c, const double* pts, int64_t m, const double* gq_host, double* mu_out,
+                     double* negsumsq_out) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->fitted && c->mix_nk > 0, "gpmi_predict_mix needs a successful gpmi_fit_mix");
+  ARGCHK(c, pts && gq_host && m > 0, "NULL argument or m <= 0");
+  if (int rc = set_device(c)) return rc;
+  Lane& L = c->lanes[0];
+  hipStream_t s = L.stream;
+  const int64_t chunk = 2048;
+  const int nk = c->mix_nk;
+  for (int64_t m0 = 0; m0 < m; m0 += chunk) {
+    const int64_t mc = (m - m0 < chunk) ? m - m0 : chunk;
+    const int64_t mp = round_up(mc, GPMI_NB);
+    if (int rc = ensure_query_ws(c, mp)) return rc;
+    if (int rc = ensure_q3(c)) return rc;
+    double* gq_dev = c->pvec + 2 * mp;  // nk x mp  (pvec holds mp (2 + 2 d + d^2 + 4) doubles)
+    HIPCHK(c, hipMemsetAsync(gq_dev, 0, sizeof(double) * nk * mp, s));
+    HIPCHK(c, hipMemcpyAsync(c->pts, pts + m0 * c->d, sizeof(double) * mc * c->d, hipMemcpyHostToDevice, s));
+    for (int k = 0; k < nk; ++k)
+      HIPCHK(c, hipMemcpyAsync(gq_dev + (int64_t)k * mp, gq_host + (int64_t)k * m + m0, sizeof(double) * mc,
+                               hipMemcpyHostToDevice, s));
+    build_mix_cross(c, s, gq_dev, mc, mp);
+    double* mu_dev = c->pvec;
+    double* var_dev = c->pvec + mp;
+    if (mu_out) launch_rows_dot(s, c->Q, c->ld, mp, c->np, c->alpha, mu_dev);
+    if (negsumsq_out) {
+      if (int rc = ensure_inv2(c, L, s)) return rc;
+      trsm_rows_forward(c, s, L.A, c->np, c->ld, L.inv2, c->Q, mp, false, c->Q2, nullptr);
+      launch_rows_sumsq(s, c->Q2, c->ld, mp, c->np, 0.0, var_dev);  // -|L^-1 k|^2; the host adds K_qq[0, 0]
+    }
+    HIPCHK(c, hipGetLastError());
+    if (mu_out) HIPCHK(c, hipMemcpyAsync(mu_out + m0, mu_dev, sizeof(double) * mc, hipMemcpyDeviceToHost, s));
+    if (negsumsq_out)
+      HIPCHK(c, hipMemcpyAsync(negsumsq_out + m0, var_dev, sizeof(double) * mc, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+  }
+  return GPMI_OK;
+}
+
+int gpmi_posterior_mix(gpmi_ctx* c, const double* pts, int64_t m, const double* gq_host, double* mu_out,
+                       double* cov_out) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->fitted && c->mix_nk > 0, "gpmi_posterior_mix needs a successful gpmi_fit_mix");
+  ARGCHK(c, pts && gq_host && m > 0, "NULL argument or m <= 0");
+  if (int rc = set_device(c)) return rc;
+  Lane& L = c->lanes[0];
+  hipStream_t s = L.stream;
+  const int nk = c->mix_nk;
+  const int64_t mp = round_up(m, GPMI_NB);
+  if (int rc = ensure_query_ws(c, mp)) return rc;
+  if (int rc = ensure_q3(c)) return rc;
+  double* gq_dev = c->pvec + 2 * mp;
+  HIPCHK(c, hipMemsetAsync(gq_dev, 0, sizeof(double) * nk * mp, s));
+  HIPCHK(c, hipMemcpyAsync(c->pts, pts, sizeof(double) * m * c->d, hipMemcpyHostToDevice, s));
+  for (int k = 0; k < nk; ++k)
+    HIPCHK(c, hipMemcpyAsync(gq_dev + (int64_t)k * mp, gq_host + (int64_t)k * m, sizeof(double) * m,
+                             hipMemcpyHostToDevice, s));
+  build_mix_cross(c, s, gq_dev, m, mp);
+  double* mu_dev = c->pvec;
+  launch_rows_dot(s, c->Q, c->ld, mp, c->np, c->alpha, mu_dev);
+  if (mu_out) HIPCHK(c, hipMemcpyAsync(mu_out, mu_dev, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+  if (cov_out) {
+    const int64_t ldq = mp + 32;
+    double *Kqq = nullptr, *tmp = nullptr;
+    HIPCHK(c, hipMalloc(&Kqq, sizeof(double) * mp * ldq));
+    hipError_t e = hipMalloc(&tmp, sizeof(double) * mp * ldq);
+    if (e == hipSuccess) {
+      if (int rc = ensure_inv2(c, L, s)) {
+        (void)hipFree(Kqq);
+        (void)hipFree(tmp);
+        return rc;
+      }
+      trsm_rows_forward(c, s, L.A, c->np, c->ld, L.inv2, c->Q, mp, false, c->Q2, nullptr);
+      // K_qq = sum_m diag(gq_m) K_m(pts, pts) diag(gq_m): no jitter, no noise (covariance.py:529-544)
+      for (int k = 0; k < nk; ++k) {
+        launch_kbuild_cross(s, c->mix_p[k], c->pts, m, mp, c->pts, m, mp, tmp, ldq);
+        launch_scale_add(s, Kqq, ldq, tmp, ldq, gq_dev + (int64_t)k * mp, gq_dev + (int64_t)k * mp, mp, mp, k > 0);
+      }
+      launch_gemm_nt(s, TILES_RECT, OP_SUB, Kqq, ldq, c->Q2, c->ld, c->Q2, c->ld, (int)(mp / GPMI_NB),
+                     (int)(mp / GPMI_NB), (int)c->np);
+      e = hipMemcpy2DAsync(cov_out, sizeof(double) * m, Kqq, sizeof(double) * ldq, sizeof(double) * m, m,
+                           hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    (void)hipFree(Kqq);
+    if (tmp) (void)hipFree(tmp);
+    HIPCHK(c, e);
+  }
+  HIPCHK(c, hipStreamSynchronize(s));
+  return GPMI_OK;
+}
+
+}  // extern "C"
+
+// ---- per-point noise hyper-parameters ----------------------------------------------------------------
+extern "C" {
+
+int gpmi_set_noise(gpmi_ctx* c, const double* noise_var) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->n > 0, "gpmi_set_data has not been called");
+  ARGCHK(c, noise_var != nullptr, "noise_var is NULL");
+  if (int rc = set_device(c)) return rc;
+  if (int rc = gpmi_sync(c)) return rc;  // nothing may still be reading the old values
+  HIPCHK(c, hipMemcpy(c->noise, noise_var, sizeof(double) * c->n, hipMemcpyHostToDevice));
+  return GPMI_OK;
+}
+
+int gpmi_lml_grad_qdiag(gpmi_ctx* c, double* qdiag) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, qdiag != nullptr, "qdiag is NULL");
+  ARGCHK(c, c->lanes.size() >= 2 && c->lanes[1].B2, "gpmi_lml_grad has not been called");
+  if (int rc = set_device(c)) return rc;
+  Lane& L = c->lanes[1];  // after gpmi_lml_grad: L.A = K^-1 (lower tiles), vec + np = alpha
+  double* out = L.vec + 2 * c->np;
+  launch_qdiag(L.stream, L.A, c->ld, L.vec + c->np, out, c->n);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(qdiag, out, sizeof(double) * c->n, hipMemcpyDeviceToHost, L.stream));
+  HIPCHK(c, hipStreamSynchronize(L.stream));
+  return GPMI_OK;
+}
+
+}  // extern "C"
+
