@@ -162,7 +162,7 @@ __device__ inline void flush_diag(const ElimScratch& sc, const double* Wl, doubl
 // one CU is a third of the kernel, so who computes what, when, decides the kernel as much as the chain does.
 //
 // Round 4 - three roles, ordered by six LDS counters (data flow; the one barrier is at the very start):
-//   wave 0 (SIMD 0, alone: wave 4 leaves at once) - the chain: factor16(kb) -> W_kb published | sub-diagonal tile
+//   wave 0 (SIMD 0) - the chain: factor16(kb) -> W_kb published | sub-diagonal tile
 //       (kb+1, kb) = A W^T and the trailing product of tile (kb+1, kb+1), in registers -> factor16(kb+1) ...
 //   waves 1-3 (one per SIMD 1-3, priority 2) - the factor: every other tile (i, j) of the matrix has ONE owner for the
 //       whole kernel (dealt round-robin in column-major order: any step's active tiles are a contiguous range of that
@@ -174,9 +174,11 @@ __device__ inline void flush_diag(const ElimScratch& sc, const double* Wl, doubl
 //       memory); E - tile -= P_i,c P_j,c^T, lazily: a tile next used at step je receives the columns 0 .. je - 2 in one
 //       chain of MFMAs at step je - 2 and column je - 1 at step je - 1 (13 - 17 products per step instead of 33, 25,
 //       18, ...).  A tile leaves the registers once: after A, or - the two tiles wave 0 takes over next - after E.
-//   waves 5-7 (the same SIMDs, priority 0) - the inverse, right-looking, tiles owned the same way: B - row block kb,
+//   waves 4-7 (one per SIMD, priority 0) - the inverse, right-looking, tiles owned the same way: B - row block kb,
 //       X[kb][jb] = -W T[kb][jb]; D - T[i][jb] += L[i][kb] X[kb][jb] for the rows below.  More than half of the kernel's
-//       MFMAs and on nobody's critical path until the last row.
+//       MFMAs and on nobody's critical path until the last row.  (Wave 4 shares SIMD 0 with the chain: at the lowest
+//       priority its MFMAs cost the chain's vector instructions little, and a quarter of the inverse leaves the three
+//       SIMDs the factor waves need - 21.2 -> 18.5 us against wave 4 idle, GPMI_DIAG_INVERSE=3.)
 // A product's operands are requested while the MFMAs of the product before it run (the sequence of products of a
 // step is generated on the fly by scalar code; the accumulator is picked by a scalar switch over the slot, since
 // registers cannot be indexed): ~300 cycles per product against 1000 for the straightforward loop over slots, whose
@@ -193,7 +195,10 @@ __device__ inline void flush_diag(const ElimScratch& sc, const double* Wl, doubl
 #define GPMI_DIAG_NOINV_SKIP false
 #endif
 constexpr int DIAG_THREADS = 512;
-constexpr int DIAG_FACTOR = 3, DIAG_INVERSE = 3;     // owner waves of the matrix tiles / of the inverse's tiles
+#ifndef GPMI_DIAG_INVERSE
+#define GPMI_DIAG_INVERSE 4  // 4: wave 4 (the chain's SIMD mate) is a fourth owner of the inverse's tiles; 3: it leaves at once (A/B builds)
+#endif
+constexpr int DIAG_FACTOR = 3, DIAG_INVERSE = GPMI_DIAG_INVERSE;  // owner waves of the matrix tiles / of the inverse's tiles
 constexpr int NE_TILES = NBLK * (NBLK + 1) / 2 - 3;  // tiles (i, j), j <= i, without (0,0), (1,0), (1,1): wave 0's from the start
 constexpr int ND_TILES = NBLK * (NBLK - 1) / 2;      // tiles of the inverse below the diagonal
 constexpr int E_SLOTS = (NE_TILES + DIAG_FACTOR - 1) / DIAG_FACTOR;
@@ -220,14 +225,23 @@ constexpr int tile_code(int n, bool inverse) {
 template <int S, bool INV>
 __device__ __forceinline__ int slot_code(int wb) {
   // the inverse's tiles are dealt from the other end (evens out the slot counts of a SIMD's two waves)
-  constexpr int c0 = tile_code((INV ? 2 : 0) + 3 * S, INV), c1 = tile_code(1 + 3 * S, INV), c2 = tile_code((INV ? 0 : 2) + 3 * S, INV);
-  return wb == 0 ? c0 : (wb == 1 ? c1 : c2);
+  constexpr int NW = INV ? DIAG_INVERSE : DIAG_FACTOR;
+  constexpr int c0 = tile_code((INV ? NW - 1 : 0) + NW * S, INV), c1 = tile_code((INV ? NW - 2 : 1) + NW * S, INV),
+                c2 = tile_code((INV ? NW - 3 : 2) + NW * S, INV);
+  // (no fourth alternative unless there is a fourth owner: with an "empty" code among a slot's possible values the
+  // compiler stops specialising the slot loops - 256 VGPRs, spills, 28 instead of 21 us)
+  if constexpr (NW == 3) {
+    return wb == 0 ? c0 : (wb == 1 ? c1 : c2);
+  } else {
+    constexpr int c3 = tile_code((INV ? NW - 4 : 3) + NW * S, INV);
+    return wb == 0 ? c0 : (wb == 1 ? c1 : (wb == 2 ? c2 : c3));
+  }
 }
 template <bool INV, int... S>
 __device__ __forceinline__ void slot_codes(int wb, int* code, std::integer_sequence<int, S...>) {
   ((code[S] = slot_code<S, INV>(wb)), ...);
 }
-static_assert(DIAG_FACTOR == 3 && DIAG_INVERSE == 3, "slot_code deals to three owners");
+static_assert(DIAG_FACTOR == 3 && (DIAG_INVERSE == 3 || DIAG_INVERSE == 4), "slot_code deals to three or four owners");
 // panel tiles (rows >= c + 2) of the columns 0 .. kb; tiles of the inverse's row blocks 0 .. kb
 __device__ inline int panels_through(int kb) { return (kb + 1) * (NBLK - 2) - kb * (kb + 1) / 2; }
 __device__ inline int xtiles_through(int kb) { return kb * (kb + 1) / 2; }
@@ -292,7 +306,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
     flush_cnt = 0;
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the counters are zero for everybody
-  if (wave == 4) return;  // the chain has SIMD 0 to itself
+  if (DIAG_INVERSE == 3 && wave == 4) return;  // the chain has SIMD 0 to itself
 
   // (every wave of the workgroup is resident, so a counter always arrives; the bound - ~0.1 s - only keeps a bug from
   // hanging the GPU: the factorisation is then wrong and says so through info)
@@ -500,7 +514,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
   } else {
     // ---------------------------------------------------------------------------------------------- the inverse
     __builtin_amdgcn_s_setprio(0);
-    const int wb = wave - 5;
+    const int wb = wave == 4 ? 3 : wave - 5;
     d4_t acc[D_SLOTS];  // slot s: the sum T[ti][tj]
     int code[D_SLOTS], ti[D_SLOTS], tj[D_SLOTS];
     slot_codes<true>(wb, code, std::make_integer_sequence<int, D_SLOTS>{});
