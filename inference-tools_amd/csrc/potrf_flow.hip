@@ -128,6 +128,84 @@ __device__ __attribute__((noinline)) void flow_do_U(const glb_double_t* Ai, cons
   dma64_tile<OP_SUB, PROTO == 3 ? CST_NT : CST_SC1, PROTO == 2 ? LD_SC1 : LD_PLAIN>(
       (const double*)Ai, (const double*)Bj, (double*)C, ld, ld, ld, NB / DMA_BK, (double*)smem);
 }
+// ---- the chain's two products per column, on tiles of 16 rows (round 4) ----------------------------------------------
+// Tc(k): tile (k+1, k) <- tile * invD(k)^T and Uc(k): tile (k+1, k+1) -= X X^T are 128 x 128 x 128 products on the
+// critical path.  The tile bodies of the throughput kernels put one wave on 4 - 8 MFMA tiles (a 32 x 128 TRSM slab: 8 per
+// wave, 4.2 us of MFMA time on its SIMD; a 64 x 64 update tile: 4 per wave over K = 128, the same) - right when the
+// launch has hundreds of workgroups, slow when it has four.  Here every wave owns ONE 16 x 16 tile of the result, takes
+// its operands straight from L2 into registers (all requests in flight at once, no LDS, no barrier in the loop) and runs
+// its 4 .. 32 MFMAs as one chain: 6.2 -> ~3 us and 6.7 -> ~3 us per column.
+// The sums are those of the throughput bodies BIT FOR BIT, because a flow-ordered factorisation must equal the stream-
+// ordered one, which runs these tiles inside launches of the generic kernels: the register-staged TRSM body
+// (gemm_tiles::staged_tile, BTRI) feeds k = 16 s + 4 fk + q to MFMA step q of slab s and skips the slabs beyond the
+// column block; the ring body of the update (gemm_tiles::dma64_tile) feeds k = 8 st + 2 fk to the first and
+// 8 st + 2 fk + 1 to the second MFMA of stage st and negates A through the MFMA's BLGP field.  Same operands, same order.
+struct ChainArgs {
+  double* T;         // tile (k+1, k): 128 x 128, Tc's input and output, Uc's operand
+  double* C;         // tile (k+1, k+1): Uc's target
+  const double* invD;  // inverse of diagonal block k (row-major 128 x 128, lower triangular)
+  int64_t ld;
+  FlowHook hook;
+};
+
+// 8 workgroups x 8 waves: workgroup b owns the rows 16 b .. 16 b + 15 (in place: nobody else reads or writes them), wave c
+// the column block c.
+__global__ __launch_bounds__(512) void chain_trsm_kernel(ChainArgs g) {
+  flow_hook_enter(g.hook);
+  const int lane = threadIdx.x & 63, c = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int fr = lane & 15, fk = lane >> 4;
+  const double* arow = g.T + (int64_t)(16 * blockIdx.x + fr) * g.ld + 4 * fk;
+  const double* brow = g.invD + (int64_t)(16 * c + fr) * NB + 4 * fk;
+  d4_t a[NB / 16], b[NB / 16];
+#pragma unroll
+  for (int s = 0; s < NB / 16; ++s)
+    if (s <= c) {  // column block c of a lower-triangular B: zero beyond slab c
+      a[s] = *reinterpret_cast<const d4_t*>(arow + 16 * s);
+      b[s] = *reinterpret_cast<const d4_t*>(brow + 16 * s);
+    }
+  d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < NB / 16; ++s)
+    if (s <= c) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][q], b[s][q], acc, 0, 0, 0);
+    }
+  // every wave of the workgroup has its operands (the MFMAs above waited for them) before anybody overwrites the rows
+  __syncthreads();
+  double* out = g.T + (int64_t)(16 * blockIdx.x + fk) * g.ld + 16 * c + fr;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[(int64_t)4 * r * g.ld] = acc[r];
+}
+
+// 9 workgroups x 4 waves: the 36 tiles (i, j), j <= i, of 16 x 16 of the target's lower triangle (diagonal tiles in full)
+__global__ __launch_bounds__(256) void chain_syrk_kernel(ChainArgs g) {
+  flow_hook_enter(g.hook);
+  const int lane = threadIdx.x & 63;
+  const int t = __builtin_amdgcn_readfirstlane((int)(4 * blockIdx.x + (threadIdx.x >> 6)));
+  int i = 0;
+  while ((i + 1) * (i + 2) / 2 <= t) ++i;
+  const int j = t - i * (i + 1) / 2;
+  const int fr = lane & 15, fk = lane >> 4;
+  const double* arow = g.T + (int64_t)(16 * i + fr) * g.ld + 2 * fk;
+  const double* brow = g.T + (int64_t)(16 * j + fr) * g.ld + 2 * fk;
+  double* cp = g.C + (int64_t)(16 * i + fk) * g.ld + 16 * j + fr;
+  d4_t acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = cp[(int64_t)4 * r * g.ld];
+  d2_t a[NB / 8], b[NB / 8];
+#pragma unroll
+  for (int st = 0; st < NB / 8; ++st) {
+    a[st] = *reinterpret_cast<const d2_t*>(arow + 8 * st);
+    b[st] = *reinterpret_cast<const d2_t*>(brow + 8 * st);
+  }
+#pragma unroll
+  for (int st = 0; st < NB / 8; ++st)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[st][h], b[st][h], acc, 0, 0, 1);  // C - A B^T
+#pragma unroll
+  for (int r = 0; r < 4; ++r) cp[(int64_t)4 * r * g.ld] = acc[r];
+}
+
 template <int PROTO>
 __global__ __launch_bounds__(256, 2) void flow_task_kernel(FlowArgs a) {
   __shared__ double smem[DMA128_LDS_DOUBLES];
@@ -622,6 +700,8 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
       launch_potrf_diag(sp, Akk, ld, invDk, info, (t0 + k) * NB, ck);
       if (k + 1 < m) {
         double* A21 = Akk + (int64_t)NB * ld;
+        // GPMI_CHAIN_TILES=0: the generic kernels (32-row TRSM slabs, 64 x 64 update tiles) as until round 3 - same bits
+        static const bool chain_tiles = env_int("GPMI_CHAIN_TILES", 1) != 0;
         GemmBatch tc;
         tc.ncu_hint = c->pair_cus[0];
         tc.b_lower_tri = true;
@@ -633,7 +713,6 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
         tc.hook.info = info;
         tc.hook.wait_ticks = stats ? stats + 4 : nullptr;
         tc.hook.trace = ck ? ck + GPMI_STAMP_WORDS : nullptr;
-        launch_gemm_nt(sp, TILES_RECT, OP_ASSIGN, A21, ld, A21, ld, invDk, NB, 1, 1, NB, nullptr, tc);
         GemmBatch uc;
         uc.hook.pub = Lcnt + k + 1;
         uc.hook.pub_val = 4 * (k + 1);
@@ -643,7 +722,15 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
         uc.hook.info = info;
         uc.hook.wait_ticks = stats ? stats + 5 : nullptr;
         uc.hook.trace = ck ? ck + GPMI_STAMP_WORDS + 2 : nullptr;
-        launch_gemm_nt(sp, TILES_LOWER, OP_SUB, A21 + NB, ld, A21, ld, A21, ld, 1, 1, NB, nullptr, uc);
+        if (chain_tiles) {
+          ChainArgs ta{A21, A21 + NB, invDk, ld, tc.hook};
+          hipLaunchKernelGGL(chain_trsm_kernel, dim3(NB / 16), dim3(512), 0, sp, ta);
+          ChainArgs ua{A21, A21 + NB, invDk, ld, uc.hook};
+          hipLaunchKernelGGL(chain_syrk_kernel, dim3(9), dim3(256), 0, sp, ua);
+        } else {
+          launch_gemm_nt(sp, TILES_RECT, OP_ASSIGN, A21, ld, A21, ld, invDk, NB, 1, 1, NB, nullptr, tc);
+          launch_gemm_nt(sp, TILES_LOWER, OP_SUB, A21 + NB, ld, A21, ld, A21, ld, 1, 1, NB, nullptr, uc);
+        }
       }
     }
   }
