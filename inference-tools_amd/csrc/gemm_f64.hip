@@ -208,6 +208,37 @@ __global__ __launch_bounds__(256, GPMI_DMA_WGS) void gemm_dma_kernel(GemmArgs g)
                                      ((__builtin_amdgcn_s_memrealtime() - r_start) & 0xffffffffull);
 }
 
+// 256 x 128 tiles (gemm_tiles::dma256_tile), experiment GPMI_GEMM_256=1: whole products with even tile counts only
+template <int TILES, int OP>
+__global__ __launch_bounds__(512, 1) void gemm_dma256_kernel(GemmArgs g) {
+  __shared__ double smem[DMA256_LDS_DOUBLES];
+  int ti, tj;  // ti: 256-row tile, tj: 128-column tile
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int nr2 = g.ntr >> 1;
+  if (TILES == TILES_RECT) {
+    ti = id / g.ntc;
+    tj = id - ti * g.ntc;
+  } else {
+    const int h = g.ntc >> 1, tri = h * (h + 1);
+    if (id < tri) {
+      int r = (int)((sqrtf(4.0f * id + 1.0f) - 1.0f) * 0.5f);
+      while (r * (r + 1) > id) --r;
+      while ((r + 1) * (r + 2) <= id) ++r;
+      ti = r;
+      tj = id - r * (r + 1);
+    } else {
+      ti = h + (id - tri) / g.ntc;
+      tj = (id - tri) % g.ntc;
+    }
+  }
+  (void)nr2;
+  const int64_t bz = blockIdx.z;
+  const double* __restrict__ Ag = g.A + bz * g.sA + (int64_t)ti * 256 * g.lda;
+  const double* __restrict__ Bg = g.B + bz * g.sB + (int64_t)tj * 128 * g.ldb;
+  double* Cg = g.C + bz * g.sC + (int64_t)ti * 256 * g.ldc + (int64_t)tj * 128;
+  dma256_tile<OP>(Ag, Bg, Cg, g.lda, g.ldb, g.ldc, g.k / DMA_BK, smem, TILES == TILES_LOWER && tj == 2 * ti + 1);
+}
+
 template <int TILES, int OP>
 __global__ __launch_bounds__(256, 4) void gemm_dma64_kernel(GemmArgs g) {
   __shared__ double smem[DMA64_LDS_DOUBLES];
@@ -308,6 +339,20 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
   // consistent because BOTH tile sizes of their C -= A B^T launches are ring kernels (this one and gemm_dma64_kernel)
   // and their in-place TRSM is register-staged at either tile height.
   static const bool no_dma = std::getenv("GPMI_GEMM_NO_DMA") != nullptr;
+  static const bool tall = std::getenv("GPMI_GEMM_256") != nullptr;
+  if (tall && bm == 128 && bn == 128 && !b_kmajor && part == 0 && kskip == 0 && k % 128 == 0 && ntr % 2 == 0 && ntc % 2 == 0 && !stamp) {
+    const int h = ntc / 2;
+    const int64_t n256 = tiles == TILES_RECT ? (int64_t)(ntr / 2) * ntc : (int64_t)h * (h + 1) + (int64_t)(ntr / 2 - h) * ntc;
+    dim3 grid2((unsigned)n256, 1, (unsigned)bt.count), block2(512);
+    if (tiles == TILES_RECT) {
+      if (op == OP_SUB) hipLaunchKernelGGL((gemm_dma256_kernel<TILES_RECT, OP_SUB>), grid2, block2, 0, s, g);
+      else hipLaunchKernelGGL((gemm_dma256_kernel<TILES_RECT, OP_ASSIGN>), grid2, block2, 0, s, g);
+    } else {
+      if (op == OP_SUB) hipLaunchKernelGGL((gemm_dma256_kernel<TILES_LOWER, OP_SUB>), grid2, block2, 0, s, g);
+      else hipLaunchKernelGGL((gemm_dma256_kernel<TILES_LOWER, OP_ASSIGN>), grid2, block2, 0, s, g);
+    }
+    return;
+  }
   if (!no_dma && bm == 128 && bn == 128 && !b_kmajor && part != 2 && k % 128 == 0) {
     if (tiles == TILES_RECT) {
       if (op == OP_SUB) hipLaunchKernelGGL((gemm_dma_kernel<TILES_RECT, OP_SUB>), grid, block, 0, s, g);

@@ -414,6 +414,113 @@ __device__ __forceinline__ void dma128_tile(const double* __restrict__ Ag, const
                      reinterpret_cast<d2_t*>(&Cg[(int64_t)(i * 16 + fk + 4 * r) * ldc + jp * 32 + 2 * fr]));
 }
 
+// ---- 256 x 128 tiles on the same ring: 8 waves (4 x 2 of 64 x 64), one workgroup per CU -----------------------------------------------
+// The tile VERDICT r03 asked to be tried: the B slab of a stage is shared by four wave rows instead of two (operand
+// bytes per flop x 0.75), at the price of one barrier domain per CU (the two 128 x 128 workgroups of a CU run their
+// stages in anti-phase, one's barrier under the other's MFMAs).  Three 16-byte pieces per thread and stage (two of A's
+// 256 rows, one of B's 128), 24 KiB per stage.  skip_top: the wave rows 0-1 (the upper 128 rows of the tile) take part
+// in the ring but neither compute nor store (the tile on the diagonal of a lower-triangular product).
+constexpr int DMA256_STAGE_DOUBLES = 3 * DMA_OP_DOUBLES;
+constexpr int DMA256_LDS_DOUBLES = DMA_STAGES * DMA256_STAGE_DOUBLES;
+
+template <int OP, int CST = CST_NT, int LD = LD_PLAIN>
+__device__ __forceinline__ void dma256_tile(const double* __restrict__ Ag, const double* __restrict__ Bg, double* Cg,
+                                            int64_t lda, int64_t ldb, int64_t ldc, int nk, double* smem, bool skip_top) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int row0 = tid >> 2, slot = tid & 3;                   // 0 .. 127
+  const int q0 = (slot - 2 * ((row0 >> 2) & 3)) & 3;
+  const double* a_src0 = Ag + (int64_t)row0 * lda + 2 * q0;
+  const double* a_src1 = a_src0 + (int64_t)128 * lda;
+  auto bperm = [](int R) {
+    const int t = (R >> 4) & 3, f = R & 15;
+    return (R & 64) + ((t & 2) << 4) + 2 * f + (t & 1);
+  };
+  const double* b_src0 = Bg + (int64_t)bperm(row0) * ldb + 2 * q0;
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const unsigned wave_off = (unsigned)__builtin_amdgcn_readfirstlane(wave * 64 * 16);
+  auto issue = [&](int st, int k0) {
+    const unsigned base = lds0 + (unsigned)st * (DMA256_STAGE_DOUBLES * 8) + wave_off;
+    const double* p0 = a_src0 + k0;
+    const double* p1 = a_src1 + k0;
+    const double* p2 = b_src0 + k0;
+    asm volatile(
+        "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off"
+        :
+        : "v"(p0), "v"(p1), "v"(p2), "s"(base), "s"(base + DMA_OP_DOUBLES * 8), "s"(base + 2 * DMA_OP_DOUBLES * 8)
+        : "memory");
+  };
+  for (int st = 0; st < DMA_STAGES - 1 && st < nk; ++st) issue(st, st * DMA_BK);
+
+  const bool idle = skip_top && wr < 2;  // wave-uniform
+  Cg += (int64_t)(wr * 64) * ldc + wc * 64;
+  d4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d2_t cv = d2_t{0.0, 0.0};
+        if (OP == OP_SUB && !idle)
+          cv = c_load2<LD>(reinterpret_cast<const d2_t*>(&Cg[(int64_t)(i * 16 + fk + 4 * r) * ldc + jp * 32 + 2 * fr]));
+        acc[i][2 * jp][r] = cv[0];
+        acc[i][2 * jp + 1][r] = cv[1];
+      }
+
+  const int rslot = (fk + 2 * (fr >> 2)) & 3;
+  const int a_off = ((wr * 64 + fr) * 4 + rslot) * 2;
+  const int b_off = 2 * DMA_OP_DOUBLES + ((wc * 64 + fr) * 4 + rslot) * 2;
+  auto wait3 = [](int newer) {
+    if (newer >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (newer >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto stage = [&](int kt) {
+    const int ahead = nk - 1 - kt;
+    wait3(3 * (ahead < DMA_STAGES - 2 ? ahead : DMA_STAGES - 2));
+    __syncthreads();
+    const double* sa = smem + (kt % DMA_STAGES) * DMA256_STAGE_DOUBLES;
+    d2_t a[4], b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const d2_t*>(sa + a_off + t * 16 * 4 * 2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const d2_t*>(sa + b_off + t * 16 * 4 * 2);
+    if (kt + DMA_STAGES - 1 < nk) issue((kt + DMA_STAGES - 1) % DMA_STAGES, (kt + DMA_STAGES - 1) * DMA_BK);
+    if (!idle) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][h], b[j][h], acc[i][j], 0, 0, OP == OP_SUB ? 1 : 0);
+    }
+  };
+  stage(0);
+  int kt = 1;
+  for (; kt + 3 < nk; kt += 4) {
+    stage(kt);
+    stage(kt + 1);
+    stage(kt + 2);
+    stage(kt + 3);
+  }
+  for (; kt < nk; ++kt) stage(kt);
+  if (idle) return;
+  c_store_begin<CST>();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        c_store<CST>((d2_t{acc[i][2 * jp][r], acc[i][2 * jp + 1][r]}),
+                     reinterpret_cast<d2_t*>(&Cg[(int64_t)(i * 16 + fk + 4 * r) * ldc + jp * 32 + 2 * fr]));
+}
+
 // ---- 64 x 64 tiles on the same ring ---------------------------------------------------------------------------------
 // The remainders of split launches, the narrow look-ahead updates (fewer than 384 tiles) and the tail's outer updates
 // run 64 x 64 tiles; with the register-staged kernel they reached 40-47 TFLOP/s at K = 512.  Same scheme as
