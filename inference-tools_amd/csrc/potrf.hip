@@ -179,10 +179,12 @@ __device__ inline void flush_diag(const ElimScratch& sc, const double* Wl, doubl
 //       MFMAs and on nobody's critical path until the last row.  (Wave 4 shares SIMD 0 with the chain: at the lowest
 //       priority its MFMAs cost the chain's vector instructions little, and a quarter of the inverse leaves the three
 //       SIMDs the factor waves need - 21.2 -> 18.5 us against wave 4 idle, GPMI_DIAG_INVERSE=3.)
-// A product's operands are requested while the MFMAs of the product before it run (the sequence of products of a
-// step is generated on the fly by scalar code; the accumulator is picked by a scalar switch over the slot, since
-// registers cannot be indexed): ~300 cycles per product against 1000 for the straightforward loop over slots, whose
-// LDS reads the compiler placed right in front of their MFMAs.
+// The slot loops are unrolled over compile-time tile codes (tile_code / slot_code below: a slot's accumulator is a named
+// register, which tile it holds one of three or four constants picked by the wave's index), and a product's operands
+// are read from LDS while the MFMAs of the product before it run (two operand sets in turn, pinned with
+// sched_barrier: left alone, the compiler put every product's LDS reads right in front of its MFMAs, ~1000 cycles per
+// product against ~300).  (A sequence of products generated on the fly by scalar code, the accumulator picked by a
+// scalar switch over the slot, was built first: PHI webs over all slots, 256 VGPRs with spills, 73 us.)
 // Counters (monotonic, LDS atomics behind the writer's own LDS traffic; nothing written to global memory is read
 // again in this kernel, so no fence ever waits for a store acknowledgement): w_done (W_kb published), sub_ready (wave
 // 0's tile (kb+1, kb)), panel_cnt (panel tiles, cumulative over the columns), hand_cnt (tiles handed to wave 0),
