@@ -19,8 +19,13 @@ for b in range(nl):
 idx = {}
 for n in range(ntasks):
     t = tasks[n]
-    idx.setdefault((int(t["type"]), int(t["i"]), int(t["j"]) if t["type"] else 0, int(t["k"])), []).append(n)
-lazyp = lambda i, j: max((j // 4 - 1) if i < 4 * (j // 4) + 8 else j // 4, 0)
+    idx.setdefault((int(t["type"]), int(t["i"]), int(t["j"]) if t["type"] in (1, 2) else 0, int(t["k"])), []).append(n)
+DEPTH = int(__import__("os").environ.get("GPMI_FLOW_NEAR_DEPTH", "1"))
+lazyp = lambda i, j: max((j // 4 - DEPTH) if i < 4 * (j // 4) + 8 else j // 4, 0)
+
+
+R_FROM = 12
+rrow = lambda i, k: (3, i, 0, k // 4) in idx
 
 
 def producers_of_tile(i, j, upto):
@@ -29,8 +34,12 @@ def producers_of_tile(i, j, upto):
     for q in range(lazyp(i, j)):
         out += idx.get((2, i, j, q), [])
     for k in range(4 * lazyp(i, j), upto):
-        out += idx.get((1, i, j, k), [])
+        out += idx.get((3, i, 0, k // 4), []) if rrow(i, k) else idx.get((1, i, j, k), [])
     return out
+
+
+def t_tasks(i, k):
+    return idx.get((3, i, 0, k // 4), []) if rrow(i, k) else idx.get((0, i, 0, k), [])
 
 
 def inputs(n):
@@ -39,14 +48,16 @@ def inputs(n):
     if ty == 0:
         return producers_of_tile(i, k, k), ("D", k)
     if ty == 1:
-        return idx.get((0, i, 0, k), []) + idx.get((0, j, 0, k), []) + producers_of_tile(i, j, k), None
+        return t_tasks(i, k) + t_tasks(j, k) + producers_of_tile(i, j, k), None
+    if ty == 3:
+        return [x for c in range(4) for q in range(k) for x in idx.get((2, i, 4 * k + c, q), [])], ("D", 4 * k + 3)
     cols = range(4 * k, 4 * k + 4)
-    return [x for c in cols for x in idx.get((0, i, 0, c), []) + idx.get((0, j, 0, c), [])] + idx.get((2, i, j, k - 1), []), None
+    return [x for c in cols for x in t_tasks(i, c) + t_tasks(j, c)] + idx.get((2, i, j, k - 1), []), None
 
 
 def describe(n):
     t = tasks[n]
-    return f"{'TUZ'[t['type']]}({t['i']},{t['j'] if t['type'] else t['k']},{t['k']}) s={t['s']} list {owner[n]}: polled {us(tt[n,0]):.0f} ready {us(tt[n,1]):.0f} done {us(tt[n,2]):.0f} pub {us(tt[n,3]):.0f}"
+    return f"{'TUZR'[t['type']]}({t['i']},{t['j'] if t['type'] in (1, 2) else t['k']},{t['k']}) s={t['s']} list {owner[n]}: polled {us(tt[n,0]):.0f} ready {us(tt[n,1]):.0f} done {us(tt[n,2]):.0f} pub {us(tt[n,3]):.0f}"
 
 
 print(f"step {K}: D {us(ct[K,0]):.0f}..{us(ct[K,8]):.0f}; Tc enters {us(ct[K,24]):.0f} waits until {us(ct[K,25]):.0f}; Uc enters {us(ct[K,26]):.0f} until {us(ct[K,27]):.0f}")

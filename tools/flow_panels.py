@@ -27,7 +27,9 @@ for n in range(ntasks):
         if hi > lo: bins[i] += hi - lo
 nwg = 448
 print("busy fraction per 25us:", " ".join(f"{x/25/nwg:.2f}" for x in bins))
-for ty in range(3):
+for ty in range(4):
     sel = tasks['type'] == ty
+    if not sel.any():
+        continue
     d = (tt[sel, 2] - tt[sel, 1]) * 0.01
-    print("TUZ"[ty], "body median", np.median(d), "mean", d.mean(), "sum/wg", d.sum() / nwg)
+    print("TUZR"[ty], "body median", np.median(d), "mean", d.mean(), "sum/wg", d.sum() / nwg)

@@ -21,11 +21,13 @@ for b in range(nwg):
     owner[off[b]:off[b + 1]] = b
 t0 = ct[0, 0]
 us = lambda x: (x - t0) * 0.01
-names = "TUZ"
+names = "TUZR"
 print(f"m={m} workgroups={nwg} tasks={ntasks}; whole chain {us(ct[m-1, 8]):.0f} us")
 dur = (tt[:, 2] - tt[:, 1]) * 0.01
-for ty in range(3):
+for ty in range(4):
     sel = tasks["type"] == ty
+    if not sel.any():
+        continue
     print(f"  {names[ty]} tasks: {sel.sum()}  body {np.median(dur[sel]):.1f} us median, {dur[sel].mean():.1f} mean, {np.percentile(dur[sel], 95):.1f} p95;"
           f" publish {np.median((tt[sel, 3] - tt[sel, 2]) * 0.01):.2f} us")
 for k in range(k0, min(k0 + nk, m - 1)):
