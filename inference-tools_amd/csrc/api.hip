@@ -269,7 +269,7 @@ void build_mix_square(gpmi_ctx* c, hipStream_t s, const MixEval& mx, double* dst
 // info[slot].  `mu_dev` may be null (then mu_const is used).  `mix` != nullptr: mixture covariance.
 int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const double* mu_dev,
                                double mu_const, int slot, bool allow_lookahead,
-                               const MixEval* mix) {
+                               const MixEval* mix, bool prebuild_inv2) {
   hipStream_t s = L.stream;
   L.inv2_valid = false;
   HIPCHK(c, hipMemsetAsync(L.info + slot, 0, sizeof(int), s));
@@ -296,9 +296,26 @@ int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const dou
   }
   if (c->ycov) launch_add_full(s, L.A, c->ld, c->ycov, c->n);
   potrf_lower(c, L, L.A, c->np, c->ld, L.invD, L.info + slot, allow_lookahead);
+  if (prebuild_inv2 && L.su[0] && c->np >= 4 * GPMI_OB) {
+    // the fit's caller predicts next: the inverses of the 512 x 512 diagonal blocks (six small batched launches, 0.2 ms
+    // on a stream of their own) are built on the lane's update stream beside the two triangular sweeps, which are
+    // chain-latency bound and leave most of the chip idle; the caller orders its stream behind ev_main
+    HIPCHK(c, hipEventRecord(L.ev_join, s));
+    HIPCHK(c, hipStreamWaitEvent(L.su[0], L.ev_join, 0));
+    if (int rc = ensure_inv2(c, L, L.su[0])) return rc;
+    HIPCHK(c, hipEventRecord(L.ev_main, L.su[0]));
+  }
   launch_residual(s, c->y, mu_dev, mu_const, L.vec + 2 * c->np, c->n, c->np);
   trsv_forward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, L.vec, L.info + slot);
-  launch_lml_reduce(s, L.vec, L.A, c->ld, c->np, L.red + 2 * slot);
+  if (prebuild_inv2 && L.inv2_valid && L.su[0]) {
+    // (same caller: v . v and sum ln L_ii - one workgroup, 42 us - beside the backward sweep instead of in front of it)
+    HIPCHK(c, hipEventRecord(L.ev_la, s));
+    HIPCHK(c, hipStreamWaitEvent(L.su[0], L.ev_la, 0));
+    launch_lml_reduce(L.su[0], L.vec, L.A, c->ld, c->np, L.red + 2 * slot);
+    HIPCHK(c, hipEventRecord(L.ev_main, L.su[0]));
+  } else {
+    launch_lml_reduce(s, L.vec, L.A, c->ld, c->np, L.red + 2 * slot);
+  }
   HIPCHK(c, hipGetLastError());
   return GPMI_OK;
 }
