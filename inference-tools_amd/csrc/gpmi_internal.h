@@ -289,7 +289,8 @@ void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, int k
 // potrf.hip
 hipStream_t potrf_first_update_stream(gpmi_ctx* c, Lane& lane, int64_t np, bool allow_lookahead);
 void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0,
-                       unsigned long long* dbg = nullptr, const BatchShape& bs = BatchShape());
+                       unsigned long long* dbg = nullptr, const BatchShape& bs = BatchShape(), int* pub = nullptr,
+                       int pub_val = 0);
 // batched, in-order factorisation of bs.count matrices (small problems: no look-ahead)
 void potrf_lower_batched(gpmi_ctx* c, hipStream_t s, double* A, int64_t np, int64_t ld, double* invD,
                          int* info, const BatchShape& bs);

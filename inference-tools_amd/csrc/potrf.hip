@@ -255,7 +255,10 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
                                                          double* __restrict__ invD,
                                                          int* __restrict__ info, int col0,
                                                          unsigned long long* __restrict__ dbg,
-                                                         int64_t strideA, int64_t strideInv) {
+                                                         int64_t strideA, int64_t strideInv, int* pub, int pub_val) {
+  // (flag-ordered tail, potrf_flow.hip: this launch publishes what the chain launch before it produced)
+  if (pub && threadIdx.x == 0 && blockIdx.z == 0)
+    __hip_atomic_store(pub, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   A += (int64_t)blockIdx.z * strideA;
   invD += (int64_t)blockIdx.z * strideInv;
   info += blockIdx.z;
@@ -623,9 +626,9 @@ __global__ void fault_scale_kernel(double* A, int64_t ld, double f, int64_t stri
 }  // namespace
 
 void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0,
-                       unsigned long long* dbg, const BatchShape& bs) {
+                       unsigned long long* dbg, const BatchShape& bs, int* pub, int pub_val) {
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, 1, (unsigned)bs.count), dim3(DIAG_THREADS), 0, s, Ablk, ld, invD,
-                     info, col0, dbg, bs.sMat, bs.sInv);
+                     info, col0, dbg, bs.sMat, bs.sInv, pub, pub_val);
   // GPMI_FAULT_DIAG_EPS=<eps>: fault injection for the test suite's own sensitivity check, never set otherwise
   static const double fault = [] {
     const char* e = std::getenv("GPMI_FAULT_DIAG_EPS");

@@ -74,7 +74,7 @@ struct FlowTask {
 static_assert(sizeof(FlowTask) == 12, "FlowTask layout");
 
 // hot words on lines of their own
-constexpr int FL_DDONE = 0, FL_ABORT = 32, FL_T0 = 48, FL_STATS = 64, FL_LCNT = 128;
+constexpr int FL_DDONE = 0, FL_ABORT = 32, FL_T0 = 48, FL_STATS = 64, FL_ROWCNT = 96, FL_LCNT = 128;  // FL_ROWCNT: 8 words (chain_fused_kernel)
 __host__ __device__ inline int flow_f_off(int m) { return FL_LCNT + ((m + 31) / 32) * 32; }
 __host__ __device__ inline int flow_owner_off(int m) { return flow_f_off(m) + ((m * m + 31) / 32) * 32; }  // one word per list
 inline int flow_flag_ints(int m, int nwg) { return flow_owner_off(m) + nwg; }
@@ -204,6 +204,167 @@ __global__ __launch_bounds__(256) void chain_syrk_kernel(ChainArgs g) {
     for (int h = 0; h < 2; ++h) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[st][h], b[st][h], acc, 0, 0, 1);  // C - A B^T
 #pragma unroll
   for (int r = 0; r < 4; ++r) cp[(int64_t)4 * r * g.ld] = acc[r];
+}
+
+// Tc(k) and Uc(k) in ONE launch (GPMI_CHAIN_TILES=2, the default): the update tile (i, j) of 16 x 16 needs the rows i and j of
+// X = T invD^T - two 16 x 128 strips, 64 MFMAs for the eight waves of a workgroup - so every workgroup computes the strips
+// of ITS tile itself instead of waiting a kernel boundary (2.3 us) and an L2 round trip for somebody else's: workgroups
+// 0 .. 27 the off-diagonal tiles (two strips each), 28 .. 31 two diagonal tiles each (two strips as well): 32 equal
+// workgroups, one per CU of the panel stream.  Strips and update take their k in exactly the groups of
+// chain_trsm_kernel / chain_syrk_kernel (bit-identical).  X replaces T in place: the diagonal-pair workgroup of a strip
+// stores it once all eight workgroups that read the strip's rows of T have them in registers (a counter per strip,
+// monotonic over the columns; only those four workgroups ever wait, so the others always finish and free their CUs).
+struct ChainFusedArgs {
+  double* T;
+  double* C;
+  const double* invD;
+  int64_t ld;
+  int* rowcnt;       // 8 counters: workgroups that have loaded strip r of T, summed over the columns so far
+  int rowcnt_target; // 8 x (columns so far, this one included)
+  const int* wait2;  // second flag: tile (k+1, k+1) has taken the columns before k
+  int wait2_val;
+  FlowHook hook;
+};
+constexpr int CF_PITCH = NB + 2;   // X strips, row-major (update operands: 16-byte reads at (row fr, 8 st + 2 fk))
+constexpr int CF_APITCH = NB + 4;  // T strips, row-major (TRSM operands: 32-byte reads at (row fr, 16 s + 4 fk))
+
+__global__ __launch_bounds__(512) void chain_fused_kernel(ChainFusedArgs g) {
+  __shared__ __attribute__((aligned(16))) double Ts[2][16 * CF_APITCH];
+  __shared__ __attribute__((aligned(16))) double Xs[2][16 * CF_PITCH];
+  // the hook of a chain launch (gemm_tiles.h: flow_hook_enter) with BOTH flags in one poll: tile (k+1, k) and tile
+  // (k+1, k+1) have taken the columns before k (normally long set; one L2 round trip for the two)
+  {
+    const FlowHook& h = g.hook;
+    if (h.trace && blockIdx.x == 0 && threadIdx.x == 0) h.trace[0] = __builtin_amdgcn_s_memrealtime();
+    if (h.pub && blockIdx.x == 0 && threadIdx.x == 0)
+      __hip_atomic_store(h.pub, h.pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+      int spins = 0;
+      unsigned long long t0 = 0;
+      if (h.wait_ticks) t0 = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        const int v1 = flow_ld(h.wait), v2 = flow_ld(g.wait2);
+        if (v1 >= h.wait_val && v2 >= g.wait2_val) break;
+        __builtin_amdgcn_s_sleep(4);
+        if ((++spins & 63) == 0 && flow_ld(h.abort)) break;
+        if (spins > FLOW_SPIN_LIMIT) {
+          __hip_atomic_store(h.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (h.info) atomicCAS(h.info, 0, GPMI_INFO_FLOW_TIMEOUT);
+          break;
+        }
+      }
+      if (h.wait_ticks) atomicAdd(h.wait_ticks, __builtin_amdgcn_s_memrealtime() - t0);
+      if (h.trace && blockIdx.x == 0) h.trace[1] = __builtin_amdgcn_s_memrealtime();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  }
+  const int tid = threadIdx.x, lane = tid & 63, c = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const int fr = lane & 15, fk = lane >> 4;
+  const int w = (int)blockIdx.x;
+  int r0, r1;  // the two strips of this workgroup: rows 16 r0 .., 16 r1 ..
+  const bool diag_pair = w >= 28;
+  if (diag_pair) {
+    r0 = 2 * (w - 28);
+    r1 = r0 + 1;
+  } else {
+    r0 = 1;
+    while (r0 * (r0 + 1) / 2 <= w) ++r0;  // off-diagonal tiles (i, j), j < i, row by row: w = i (i - 1) / 2 + j
+    r1 = w - r0 * (r0 - 1) / 2;
+  }
+  // ---- operands.  T: wave c fetches slab c (columns 16 c ..) of both strips, once per workgroup, and hands it on through
+  // LDS.  invD: wave c computes column block c of strip 0 and column block 7 - c of strip 1 - row blocks c and 7 - c of the
+  // lower-triangular invD, nine slabs and 36 MFMAs for every wave (one block of both strips per wave: 8 .. 64 MFMAs)
+  const int c1 = 7 - c;
+  const d4_t t0 = *reinterpret_cast<const d4_t*>(g.T + (int64_t)(16 * r0 + fr) * g.ld + 16 * c + 4 * fk);
+  const d4_t t1 = *reinterpret_cast<const d4_t*>(g.T + (int64_t)(16 * r1 + fr) * g.ld + 16 * c + 4 * fk);
+  const double* b0row = g.invD + (int64_t)(16 * c + fr) * NB + 4 * fk;
+  const double* b1row = g.invD + (int64_t)(16 * c1 + fr) * NB + 4 * fk;
+  d4_t b0[NB / 16], b1[NB / 16];
+#pragma unroll
+  for (int s = 0; s < NB / 16; ++s) {
+    if (s <= c) b0[s] = *reinterpret_cast<const d4_t*>(b0row + 16 * s);
+    if (s <= c1) b1[s] = *reinterpret_cast<const d4_t*>(b1row + 16 * s);
+  }
+  // the update tile(s) of this workgroup: one wave each; its C tile is requested now and arrives under the strips
+  const int ntile = diag_pair ? 2 : 1;
+  d4_t acc = {0.0, 0.0, 0.0, 0.0};
+  double* cp = nullptr;
+  if (c < ntile) {
+    const int ti = diag_pair ? (c == 0 ? r0 : r1) : r0, tj = diag_pair ? ti : r1;
+    cp = g.C + (int64_t)(16 * ti + fk) * g.ld + 16 * tj + fr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = cp[(int64_t)4 * r * g.ld];
+  }
+  *reinterpret_cast<d4_t*>(&Ts[0][fr * CF_APITCH + 16 * c + 4 * fk]) = t0;
+  *reinterpret_cast<d4_t*>(&Ts[1][fr * CF_APITCH + 16 * c + 4 * fk]) = t1;
+  __syncthreads();  // (every wave has its slab of T in registers and in LDS)
+  if (tid == 0) {
+    __hip_atomic_fetch_add(g.rowcnt + r0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(g.rowcnt + r1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- the strips (chain_trsm_kernel's sums: k = 16 s + 4 fk + q at step q of slab s, slabs beyond the block skipped)
+  d4_t x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < NB / 16; ++s) {
+    if (s <= c) {
+      const d4_t a = *reinterpret_cast<const d4_t*>(&Ts[0][fr * CF_APITCH + 16 * s + 4 * fk]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b0[s][q], x0, 0, 0, 0);
+    }
+    if (s <= c1) {
+      const d4_t a = *reinterpret_cast<const d4_t*>(&Ts[1][fr * CF_APITCH + 16 * s + 4 * fk]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b1[s][q], x1, 0, 0, 0);
+    }
+  }
+  // X strips to LDS in row-major form (the D layout of the MFMA: lane (fr, fk) holds rows fk + 4 r of its column block)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    Xs[0][(fk + 4 * r) * CF_PITCH + 16 * c + fr] = x0[r];
+    Xs[1][(fk + 4 * r) * CF_PITCH + 16 * c1 + fr] = x1[r];
+  }
+  __syncthreads();
+  // ---- the update tile(s): chain_syrk_kernel's sums (k = 8 st + 2 fk, + 1; A negated by the MFMA)
+  if (c < ntile) {
+    const double* xa = Xs[diag_pair ? c : 0] + fr * CF_PITCH + 2 * fk;
+    const double* xb = Xs[diag_pair ? c : 1] + fr * CF_PITCH + 2 * fk;
+#pragma unroll
+    for (int st = 0; st < NB / 8; ++st) {
+      const d2_t av = *reinterpret_cast<const d2_t*>(xa + 8 * st);
+      const d2_t bv = *reinterpret_cast<const d2_t*>(xb + 8 * st);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[h], bv[h], acc, 0, 0, 1);  // C - A B^T
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cp[(int64_t)4 * r * g.ld] = acc[r];
+  }
+  if (g.hook.trace && w == 0 && tid == 0) g.hook.trace[2] = g.hook.trace[3] = __builtin_amdgcn_s_memrealtime();
+  if (!diag_pair || c < ntile) return;
+  // ---- X in place of T (the diagonal-pair workgroups, the six waves without a tile, from LDS): strips r0 and r1, once
+  // nobody needs their rows of T any more
+  {
+    int spins = 0;
+    while (flow_ld(g.rowcnt + r0) < g.rowcnt_target || flow_ld(g.rowcnt + r1) < g.rowcnt_target) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 63) == 0 && flow_ld(g.hook.abort)) break;
+      if (spins > FLOW_SPIN_LIMIT) {
+        if (lane == 0) {
+          __hip_atomic_store(g.hook.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (g.hook.info) atomicCAS(g.hook.info, 0, GPMI_INFO_FLOW_TIMEOUT);
+        }
+        break;
+      }
+    }
+  }
+  for (int blk = c - ntile; blk < 16; blk += 8 - ntile) {  // block = (strip, column block)
+    const int st = blk >> 3, cb = blk & 7;
+    const double* xs = Xs[st] + fk * CF_PITCH + 16 * cb + fr;
+    double* o = g.T + (int64_t)(16 * (st ? r1 : r0) + fk) * g.ld + 16 * cb + fr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[(int64_t)4 * r * g.ld] = xs[4 * r * CF_PITCH];
+  }
 }
 
 template <int PROTO>
@@ -697,11 +858,15 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
       double* Akk = A0 + (int64_t)k * NB * ld + (int64_t)k * NB;
       double* invDk = invD0 + (int64_t)k * NB * NB;
       unsigned long long* ck = ctrace ? ctrace + (int64_t)k * (GPMI_STAMP_WORDS + 4) : nullptr;
-      launch_potrf_diag(sp, Akk, ld, invDk, info, (t0 + k) * NB, ck);
+      // GPMI_CHAIN_TILES=0: the generic kernels (32-row TRSM slabs, 64 x 64 update tiles) as until round 3; 1: the two
+      // 16 x 16-tile kernels; 2 (default): both products in one launch - same bits
+      static const int chain_mode = env_int("GPMI_CHAIN_TILES", 2);
+      // (fused: the strip X of column k - 1 was stored by the launch before this one; potrf_diag publishes it)
+      const bool pub_here = chain_mode == 2 && k > 0;
+      launch_potrf_diag(sp, Akk, ld, invDk, info, (t0 + k) * NB, ck, BatchShape(), pub_here ? Lcnt + k : nullptr, 4 * k);
       if (k + 1 < m) {
         double* A21 = Akk + (int64_t)NB * ld;
-        // GPMI_CHAIN_TILES=0: the generic kernels (32-row TRSM slabs, 64 x 64 update tiles) as until round 3 - same bits
-        static const bool chain_tiles = env_int("GPMI_CHAIN_TILES", 1) != 0;
+        const bool chain_tiles = chain_mode != 0;
         GemmBatch tc;
         tc.ncu_hint = c->pair_cus[0];
         tc.b_lower_tri = true;
@@ -722,7 +887,10 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
         uc.hook.info = info;
         uc.hook.wait_ticks = stats ? stats + 5 : nullptr;
         uc.hook.trace = ck ? ck + GPMI_STAMP_WORDS + 2 : nullptr;
-        if (chain_tiles) {
+        if (chain_mode == 2) {
+          ChainFusedArgs fa2{A21, A21 + NB, invDk, ld, fl + FL_ROWCNT, 8 * (k + 1), uc.hook.wait, uc.hook.wait_val, tc.hook};
+          hipLaunchKernelGGL(chain_fused_kernel, dim3(32), dim3(512), 0, sp, fa2);
+        } else if (chain_tiles) {
           ChainArgs ta{A21, A21 + NB, invDk, ld, tc.hook};
           hipLaunchKernelGGL(chain_trsm_kernel, dim3(NB / 16), dim3(512), 0, sp, ta);
           ChainArgs ua{A21, A21 + NB, invDk, ld, uc.hook};

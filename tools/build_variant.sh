@@ -6,7 +6,7 @@ name=$1; shift
 out=$ROOT/tools/variants; mkdir -p $out/obj_$name
 cd $ROOT/inference-tools_amd/csrc
 for f in api api_regression api_mix api_linv api_dense kbuild gemm_f64 potrf potrf_flow solve grad predgrad mix comm; do
-  if [ "$f" = potrf ] || [ ! -f build/$f.o ]; then
+  if [ "$f" = potrf ] || [ "$f" = potrf_flow ] || [ ! -f build/$f.o ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -I../../include -I. "$@" -c $f.hip -o $out/obj_$name/$f.o
   else
     cp build/$f.o $out/obj_$name/$f.o
