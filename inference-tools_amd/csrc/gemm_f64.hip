@@ -48,7 +48,25 @@ struct GemmArgs {
   // gridDim.x) of the logical tile list (launch_gemm_nt_range; 0 for whole products)
   int split, tile_base;
   FlowHook hook;  // potrf_flow.hip: flags published / awaited at the start of a chain launch
+  // > 0 (lockstep batches of a multiple of 8 problems): a one-dimensional launch of 8 x zlocal_tiles x (batch / 8)
+  // workgroups in which problem z runs entirely on XCD z % 8 (workgroup n -> XCD n % 8), its zlocal_tiles tiles in their
+  // logical order: a problem's operand panels are fetched into ONE L2 instead of all eight
+  int zlocal_tiles;
 };
+
+// (tile index within the launch's tile list, problem) of this workgroup
+struct WgId {
+  int wid;
+  int64_t bz;
+};
+__device__ inline int xcd_remap(int b, int nwg);
+__device__ inline WgId wg_id(int kskip, int zlocal_tiles) {
+  if (zlocal_tiles > 0) {
+    const int n = (int)blockIdx.x, m = n >> 3;
+    return {m % zlocal_tiles, (int64_t)(m / zlocal_tiles) * 8 + (n & 7)};
+  }
+  return {kskip ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x), (int64_t)blockIdx.z};
+}
 
 // B stored k-major: 16 rows of BN + 16 pad (rows 16 doubles apart mod 32)
 
@@ -110,7 +128,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   int ti, tj;
   // k-skipped launches have tiles of very different length (128 (ntr - ti) k-steps): deal them out
   // round-robin over the XCDs instead of in contiguous chunks, or the XCD holding the long tiles ends last
-  const int wid = g.kskip ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+  const WgId me = wg_id(g.kskip, g.zlocal_tiles);
+  const int wid = me.wid;
   if (g.split) {
     int bi, bj;
     tile_of<TILES>(g.tile_base + (wid >> 2), g.ntr >> 1, g.ntc >> 1, bi, bj);
@@ -139,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   }
   const int kbeg = (g.kskip == 1) ? ti * BM : 0;
   const int kend = (g.kskip == 2 && (tj + 1) * BN < g.k) ? (tj + 1) * BN : g.k;
-  const int64_t bz = blockIdx.z;
+  const int64_t bz = me.bz;
   const double* __restrict__ Ag = g.A + bz * g.sA + (int64_t)ti * BM * g.lda + kbeg;
   const double* __restrict__ Bg = BKN ? g.B + bz * g.sB + (int64_t)kbeg * g.ldb + (int64_t)tj * BN
                                       : g.B + bz * g.sB + (int64_t)tj * BN * g.ldb + kbeg;
@@ -180,7 +199,8 @@ __global__ __launch_bounds__(256, GPMI_DMA_WGS) void gemm_dma_kernel(GemmArgs g)
   flow_hook_enter(g.hook);
   int ti, tj;
   // k-skipped launches have tiles of very different length: dealt round-robin over the XCDs (see gemm_nt_kernel)
-  tile_of<TILES>(g.tile_base + (g.kskip ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x)), g.ntr, g.ntc, ti, tj);
+  const WgId me = wg_id(g.kskip, g.zlocal_tiles);
+  tile_of<TILES>(g.tile_base + me.wid, g.ntr, g.ntc, ti, tj);
   const int tid = threadIdx.x;
   const bool stamp_first = g.stamp && tid == 0 && blockIdx.x < 8 && blockIdx.z == 0;
   if (stamp_first) g.stamp[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
@@ -193,7 +213,7 @@ __global__ __launch_bounds__(256, GPMI_DMA_WGS) void gemm_dma_kernel(GemmArgs g)
   }
   const int kbeg = (g.kskip == 1) ? ti * 128 : 0;
   const int kend = (g.kskip == 2 && (tj + 1) * 128 < g.k) ? (tj + 1) * 128 : g.k;
-  const int64_t bz = blockIdx.z;  // batch (lockstep factorisations): problem z works on C + z sC, A + z sA, B + z sB
+  const int64_t bz = me.bz;  // batch (lockstep factorisations): problem z works on C + z sC, A + z sA, B + z sB
   const double* __restrict__ Ag = g.A + bz * g.sA + (int64_t)ti * 128 * g.lda + kbeg;
   const double* __restrict__ Bg = g.B + bz * g.sB + (int64_t)tj * 128 * g.ldb + kbeg;
   double* Cg = g.C + bz * g.sC + (int64_t)ti * 128 * g.ldc + (int64_t)tj * 128;
@@ -244,7 +264,8 @@ __global__ __launch_bounds__(256, 4) void gemm_dma64_kernel(GemmArgs g) {
   __shared__ double smem[DMA64_LDS_DOUBLES];
   flow_hook_enter(g.hook);
   int ti, tj;
-  const int wid = g.kskip ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+  const WgId me = wg_id(g.kskip, g.zlocal_tiles);
+  const int wid = me.wid;
   if (g.split) {
     int bi, bj;
     tile_of<TILES>(g.tile_base + (wid >> 2), g.ntr >> 1, g.ntc >> 1, bi, bj);
@@ -258,7 +279,7 @@ __global__ __launch_bounds__(256, 4) void gemm_dma64_kernel(GemmArgs g) {
   if (stamp_first) g.stamp[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
   const int kbeg = (g.kskip == 1) ? ti * 64 : 0;
   const int kend = (g.kskip == 2 && (tj + 1) * 64 < g.k) ? (tj + 1) * 64 : g.k;
-  const int64_t bz = blockIdx.z;
+  const int64_t bz = me.bz;
   const double* __restrict__ Ag = g.A + bz * g.sA + (int64_t)ti * 64 * g.lda + kbeg;
   const double* __restrict__ Bg = g.B + bz * g.sB + (int64_t)tj * 64 * g.ldb + kbeg;
   double* Cg = g.C + bz * g.sC + (int64_t)ti * 64 * g.ldc + (int64_t)tj * 64;
@@ -320,7 +341,7 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
   // the panel TRSM with the caller's word that B (the inverse of a diagonal block) is lower triangular
   if (bt.b_lower_tri && kskip == 0 && bn == 128 && bm <= 64 && ntc == 1 && k == 128 && !b_kmajor && op == OP_ASSIGN) kskip = 3;
   GemmArgs g{C, A, B, ldc, lda, ldb, ntr * (128 / bm), ntc * (128 / bn), k, kskip, stamp,
-             bt.sC, bt.sA, bt.sB, part == 2 ? 1 : 0, part >= 2 ? (int)nfull : 0, bt.hook};
+             bt.sC, bt.sA, bt.sB, part == 2 ? 1 : 0, part >= 2 ? (int)nfull : 0, bt.hook, 0};
   int64_t nwg;
   if (tiles == TILES_RECT)
     nwg = (int64_t)g.ntr * g.ntc;
@@ -332,6 +353,15 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
   if (part == 3) nwg = nend - nfull;
   if (nwg <= 0) return;
   dim3 grid((unsigned)nwg, 1, (unsigned)bt.count), block(256);
+  // lockstep batches of a multiple of 8 problems: every problem on ONE XCD (GemmArgs::zlocal_tiles; GPMI_BATCH_XCD=0: off)
+  static const bool batch_xcd = [] {
+    const char* e = std::getenv("GPMI_BATCH_XCD");
+    return !e || std::atoi(e) != 0;
+  }();
+  if (batch_xcd && bt.count >= 8 && bt.count % 8 == 0 && !stamp && nwg * bt.count < (int64_t)1 << 30) {
+    g.zlocal_tiles = (int)nwg;
+    grid = dim3((unsigned)(nwg * bt.count), 1, 1);
+  }
   // full 128 x 128 tiles with K-contiguous operands take the LDS-DMA ring kernel (GPMI_GEMM_NO_DMA=1: the
   // register-staged kernel everywhere, for A/B timing).  The ring kernels feed k = {0,2,4,6} / {1,3,5,7} of a stage to
   // their two MFMAs, the register-staged kernels k = {q, 4+q, 8+q, 12+q}: the sums differ in the last bit.  Lockstep
