@@ -255,6 +255,18 @@ int gpmi_lml_mix(gpmi_ctx* ctx, int nk, const int* kernels, const double* thetas
 int gpmi_lml_grad_mix(gpmi_ctx* ctx, int nk, const int* kernels, const double* thetas, const int* n_thetas,
                       const double* g_host, double extra_diag, const double* mu_host, double* lml,
                       double* grad_thetas, double* hrows_host, double* alpha_host, int* info);
+
+/* gpmi_lml_grad_mix for T hyper-parameter vectors in one call (round 4; regression.py:544-567 with a ChangePoint kernel,
+ * covariance.py:529-594, for the T starts of multistart_bfgs, regression.py:585-605).  N <= 4096: the evaluations advance
+ * in lockstep, every launch carrying all of them.  thetas: T rows, each the sub-kernels' parameters back to back
+ * (sum of n_thetas values); g: T x nk x n window weights; extra: T WhiteNoise variances (or NULL); one of mus (T x n) /
+ * mu_const (T).  Out: lml[T], grad_thetas[T x sum n_thetas], hrows[T x nk x n] (h_m(i) = sum_j Q_ij K_m,ij g_m(j), which
+ * the caller contracts with d g_m / d phi), optional alpha_out[T x n], qdiag_out[T x n] (diag(alpha alpha^T - K^-1)),
+ * info[T]. */
+int gpmi_lml_grad_batch_mix(gpmi_ctx* ctx, int nk, const int* kernels, int64_t T, const double* thetas,
+                            const int* n_thetas, const double* g, const double* extra, const double* mus,
+                            const double* mu_const, double* lml, double* grad_thetas, double* hrows,
+                            double* alpha_out, double* qdiag_out, int* info);
 /* alpha and diag(K^-1) at arbitrary hyper-parameters: the O(n^3) part of loo_likelihood (regression.py:468-487) */
 int gpmi_loo_terms_mix(gpmi_ctx* ctx, int nk, const int* kernels, const double* thetas, const int* n_thetas,
                        const double* g_host, double extra_diag, const double* mu_host, double* alpha_host,

@@ -200,9 +200,14 @@ void free_data(gpmi_ctx* c) {
   fr(c->bGout);
   fr(c->bLoo);
   fr(c->bNoise);
+  fr(c->bMixG);
+  fr(c->bMixH);
+  fr(c->bMixExtra);
+  if (c->bMixP) (void)hipFree(c->bMixP);
+  c->bMixP = nullptr;
   if (c->h_bGout) (void)hipHostFree(c->h_bGout);
   c->h_bGout = nullptr;
-  c->bgrad_cap = c->bgrad_ntheta = c->bLoo_cap = c->bNoise_cap = 0;
+  c->bgrad_cap = c->bgrad_ntheta = c->bLoo_cap = c->bNoise_cap = c->bMix_cap = 0;
   if (c->bInfo) (void)hipFree(c->bInfo);
   c->bInfo = nullptr;
   if (c->bParams) (void)hipFree(c->bParams);
@@ -381,7 +386,12 @@ int ensure_batch_ws(gpmi_ctx* c, int want) {
   fr(c->bGout);
   fr(c->bLoo);
   fr(c->bNoise);
-  c->bLoo_cap = c->bNoise_cap = 0;
+  fr(c->bMixG);
+  fr(c->bMixH);
+  fr(c->bMixExtra);
+  if (c->bMixP) (void)hipFree(c->bMixP);
+  c->bMixP = nullptr;
+  c->bLoo_cap = c->bNoise_cap = c->bMix_cap = 0;
   if (c->h_bGout) (void)hipHostFree(c->h_bGout);
   c->h_bGout = nullptr;
   c->bgrad_cap = c->bgrad_ntheta = 0;

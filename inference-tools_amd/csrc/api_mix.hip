@@ -185,6 +185,185 @@ int gpmi_lml_grad_mix(gpmi_ctx* c, int nk, const int* kernels, const double* the
   return GPMI_OK;
 }
 
+// gpmi_lml_grad_mix for T hyper-parameter vectors at once (round 4).  For N <= 4096 the evaluations advance in lockstep:
+// every sub-kernel build and fold, the factorisation, both sweeps, L^-T, the k-skipped SYRK, and per sub-kernel the
+// weight-scaled inverse, the fused contraction and the window row sums carry the chunk in blockIdx.z.  thetas: T rows of
+// the sub-kernels' parameters back to back (sum n_thetas each); g_host: T x nk x n window weights; hrows: T x nk x n;
+// qdiag_out (optional, T x n): diag(alpha alpha^T - K^-1) for the WhiteNoise term.  Larger problems: one at a time.
+int gpmi_lml_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, const double* thetas,
+                            const int* n_thetas, const double* g_host, const double* extra, const double* mus,
+                            const double* mu_const, double* lml, double* grad_thetas, double* hrows,
+                            double* alpha_out, double* qdiag_out, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->n > 0, "gpmi_set_data has not been called");
+  ARGCHK(c, T >= 1 && T <= RED_SLOTS, "T out of range");
+  ARGCHK(c, nk >= 1 && nk <= GPMI_MAX_MIX, "number of sub-kernels out of range (1..4)");
+  ARGCHK(c, kernels && thetas && n_thetas && g_host && lml && grad_thetas && hrows, "NULL argument");
+  ARGCHK(c, mus || mu_const, "one of mus / mu_const is required");
+  int tot_nt = 0, max_nt = 0;
+  for (int m = 0; m < nk; ++m) {
+    tot_nt += n_thetas[m];
+    max_nt = n_thetas[m] > max_nt ? n_thetas[m] : max_nt;
+  }
+  if (int rc = set_device(c)) return rc;
+  const bool lockstep = (T >= 2 || c->lockstep_always) && c->np <= 4096 && !c->ycov;
+  if (!lockstep) {
+    std::vector<double> mu_row((size_t)c->n);
+    for (int64_t t = 0; t < T; ++t) {
+      const double* mu_t = mus ? mus + t * c->n : mu_row.data();
+      if (!mus) std::fill(mu_row.begin(), mu_row.end(), mu_const[t]);
+      int inf = 0;
+      const int rc = gpmi_lml_grad_mix(c, nk, kernels, thetas + t * tot_nt, n_thetas, g_host + t * nk * c->n,
+                                       extra ? extra[t] : 0.0, mu_t, lml + t, grad_thetas + t * tot_nt,
+                                       hrows + t * nk * c->n, alpha_out ? alpha_out + t * c->n : nullptr, &inf);
+      if (info) info[t] = inf;
+      if (rc != GPMI_OK) return rc;
+      if (qdiag_out)
+        if (int rc2 = gpmi_lml_grad_qdiag(c, qdiag_out + t * c->n)) return rc2;
+    }
+    return GPMI_OK;
+  }
+  if (c->lanes.size() < 2)
+    if (int rc = ensure_lanes(c, 2)) return rc;
+  // parameters: ps[m][t]
+  std::vector<KParams> ps((size_t)nk * T);
+  for (int64_t t = 0; t < T; ++t) {
+    int off = 0;
+    for (int m = 0; m < nk; ++m) {
+      if (int rc = make_params(c, kernels[m], thetas + t * tot_nt + off, n_thetas[m], 0.0, ps[(size_t)m * T + t])) return rc;
+      off += n_thetas[m];
+    }
+  }
+  ARGCHK(c, c->bpend[0] == 0 && c->bpend[1] == 0,
+         "gpmi_lml_grad_batch_mix: an asynchronous batch is pending on this handle (gpmi_lml_batch_wait first)");
+  if (int rc = ensure_batch_ws(c, (int)(T < 64 ? (T < 2 ? 2 : T) : 64))) return rc;
+  const int W = max_nt + 1;  // values per sub-kernel and problem from the contraction
+  if (int rc = ensure_batch_grad_ws(c, c->bcap, nk * W - 1)) return rc;
+  if (!c->mix_zero) {
+    HIPCHK(c, hipMalloc(&c->mix_zero, sizeof(double) * c->np));
+    HIPCHK(c, hipMemset(c->mix_zero, 0, sizeof(double) * c->np));
+  }
+  const int cap = c->bgrad_cap;
+  if (c->bMix_cap < cap) {
+    auto fr = [](double*& p) {
+      if (p) (void)hipFree(p);
+      p = nullptr;
+    };
+    fr(c->bMixG);
+    fr(c->bMixH);
+    fr(c->bMixExtra);
+    if (c->bMixP) (void)hipFree(c->bMixP);
+    c->bMixP = nullptr;
+    c->bMix_cap = 0;
+    HIPCHK(c, hipMalloc(&c->bMixG, sizeof(double) * cap * GPMI_MAX_MIX * c->np));
+    HIPCHK(c, hipMalloc(&c->bMixH, sizeof(double) * cap * GPMI_MAX_MIX * c->np));
+    HIPCHK(c, hipMalloc(&c->bMixExtra, sizeof(double) * cap));
+    HIPCHK(c, hipMalloc(&c->bMixP, sizeof(KParams) * cap * GPMI_MAX_MIX));
+    c->bMix_cap = cap;
+  }
+  if (qdiag_out && c->bNoise_cap < cap) {
+    if (c->bNoise) (void)hipFree(c->bNoise);
+    c->bNoise = nullptr;
+    c->bNoise_cap = 0;
+    HIPCHK(c, hipMalloc(&c->bNoise, sizeof(double) * c->np * cap));
+    c->bNoise_cap = cap;
+  }
+  hipStream_t s = c->lanes[1].stream;
+  const int nt = (int)(c->np / GPMI_NB);
+  const BatchShape shape0{1, c->np * c->ld, (c->np / GPMI_NB) * GPMI_NB * GPMI_NB, 4 * c->np};
+  const int64_t sG = (int64_t)GPMI_MAX_MIX * c->np;  // between the problems' weight (and row-sum) sets
+  std::vector<double> gpad, ex;
+  for (int64_t t0 = 0; t0 < T; t0 += cap) {
+    const int B = (int)((T - t0 < cap) ? T - t0 : cap);
+    BatchShape bs = shape0;
+    bs.count = B;
+    // weights, padded like mix_prepare does (the identity in the padding belongs to sub-kernel 0)
+    gpad.assign((size_t)B * sG, 0.0);
+    for (int b = 0; b < B; ++b)
+      for (int m = 0; m < nk; ++m) {
+        double* dst = gpad.data() + (size_t)b * sG + (size_t)m * c->np;
+        const double* src = g_host + ((t0 + b) * nk + m) * c->n;
+        for (int64_t i = 0; i < c->np; ++i) dst[i] = i < c->n ? src[i] : (m == 0 ? 1.0 : 0.0);
+      }
+    ex.assign((size_t)B, 0.0);
+    if (extra)
+      for (int b = 0; b < B; ++b) ex[(size_t)b] = extra[t0 + b];
+    HIPCHK(c, hipMemcpyAsync(c->bMixG, gpad.data(), sizeof(double) * B * sG, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->bMixExtra, ex.data(), sizeof(double) * B, hipMemcpyHostToDevice, s));
+    for (int m = 0; m < nk; ++m)
+      HIPCHK(c, hipMemcpyAsync(c->bMixP + (int64_t)m * cap, ps.data() + (size_t)m * T + t0, sizeof(KParams) * B,
+                               hipMemcpyHostToDevice, s));
+    if (mus)
+      HIPCHK(c, hipMemcpyAsync(c->bMu, mus + t0 * c->n, sizeof(double) * B * c->n, hipMemcpyHostToDevice, s));
+    else
+      HIPCHK(c, hipMemcpyAsync(c->bMu, mu_const + t0, sizeof(double) * B, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(c->bInfo, 0, sizeof(int) * B, s));
+    // K = sum_m D_m K_m D_m + noise + extra: the sub-kernels' lower tiles into the second matrix, folded into the first
+    // (the upper triangle of the sum is never read before the mirror below)
+    for (int m = 0; m < nk; ++m) {
+      launch_kbuild_square_batched(s, kernels[m], c->bMixP + (int64_t)m * cap, B, c->x, c->n, c->np, c->mix_zero, c->bB2,
+                                   c->ld, bs.sMat, (int)c->d, 0);
+      launch_scale_add(s, c->bA, c->ld, c->bB2, c->ld, c->bMixG + (int64_t)m * c->np, c->bMixG + (int64_t)m * c->np,
+                       c->np, c->np, m > 0, B, bs.sMat, bs.sMat, sG);
+    }
+    launch_add_diag_vec(s, c->bA, c->ld, c->noise, 0.0, c->n, B, bs.sMat, c->bMixExtra);
+    potrf_lower_batched(c, s, c->bA, c->np, c->ld, c->bInv, c->bInfo, bs);
+    launch_residual_batched(s, c->y, mus ? c->bMu : nullptr, mus ? nullptr : c->bMu, c->bVec + 2 * c->np, c->n, c->np,
+                            bs);
+    trsv_forward(c, s, c->bA, c->np, c->ld, c->bInv, c->bVec + 2 * c->np, c->bVec, c->bInfo, bs);
+    launch_lml_reduce(s, c->bVec, c->bA, c->ld, c->np, c->bRed, bs);
+    double* alpha_dev = c->bVec + c->np;   // slot 1 of every problem's four work vectors
+    double* ua_dev = c->bVec + 2 * c->np;  // slot 2 (the residual is spent): g_m o alpha
+    trsv_backward(c, s, c->bA, c->np, c->ld, c->bInv, c->bVec, alpha_dev, c->bInfo, bs);
+    trsm_identity_batched(s, c->bA, c->np, c->ld, c->bInv, c->bB2, bs);
+    const GemmBatch syrk{B, bs.sMat, bs.sMat, bs.sMat};
+    launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, 1, c->bA, c->ld, c->bB2, c->ld, c->bB2, c->ld, nt, nt, (int)c->np,
+                nullptr, syrk);
+    launch_mirror_lower(s, c->bA, c->ld, c->np, B, bs.sMat);
+    if (qdiag_out) launch_qdiag_batched(s, B, c->bA, c->ld, alpha_dev, c->bNoise, c->n, bs.sMat, bs.sVec, c->np);
+    for (int m = 0; m < nk; ++m) {
+      const double* gm = c->bMixG + (int64_t)m * c->np;
+      const KParams* pm = c->bMixP + (int64_t)m * cap;
+      // 1/2 sum (D_m Q D_m) o dK_m: the fused contraction on the weight-scaled inverse with u = v = g_m o alpha
+      launch_scale_add(s, c->bB2, c->ld, c->bA, c->ld, gm, gm, c->np, c->np, false, B, bs.sMat, bs.sMat, sG);
+      launch_vec_mul(s, gm, alpha_dev, ua_dev, c->np, B, sG, bs.sVec, bs.sVec);
+      launch_lml_grad_batched(s, pm, B, n_thetas[m], c->x, c->n, c->np, c->bB2, c->ld, bs.sMat, ua_dev, ua_dev, bs.sVec,
+                              c->bGws, c->bGout + (int64_t)m * cap * W);
+      // window parameters: h_m(i) = sum_j Q_ij K_m,ij g_m(j) on the full K_m (lower tiles built, then mirrored)
+      launch_kbuild_square_batched(s, kernels[m], pm, B, c->x, c->n, c->np, c->mix_zero, c->bB2, c->ld, bs.sMat,
+                                   (int)c->d, 0);
+      launch_mirror_lower(s, c->bB2, c->ld, c->np, B, bs.sMat);
+      launch_mix_rowsum(s, c->bA, c->bB2, c->ld, alpha_dev, gm, c->bMixH + (int64_t)m * c->np, c->n, B, bs.sMat,
+                        bs.sVec, sG);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_bRed, c->bRed, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_bGout, c->bGout, sizeof(double) * nk * cap * W, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_bInfo, c->bInfo, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    for (int m = 0; m < nk; ++m)
+      HIPCHK(c, hipMemcpy2DAsync(hrows + (t0 * nk + m) * c->n, sizeof(double) * nk * c->n, c->bMixH + (int64_t)m * c->np,
+                                 sizeof(double) * sG, sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    if (alpha_out)
+      HIPCHK(c, hipMemcpy2DAsync(alpha_out + t0 * c->n, sizeof(double) * c->n, alpha_dev, sizeof(double) * bs.sVec,
+                                 sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    if (qdiag_out)
+      HIPCHK(c, hipMemcpy2DAsync(qdiag_out + t0 * c->n, sizeof(double) * c->n, c->bNoise, sizeof(double) * c->np,
+                                 sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int b = 0; b < B; ++b) {
+      const int inf = c->h_bInfo[b];
+      INFOCHK(c, inf);
+      lml[t0 + b] = -0.5 * c->h_bRed[2 * b] - c->h_bRed[2 * b + 1];
+      int o = 0;
+      for (int m = 0; m < nk; ++m)
+        for (int j = 0; j < n_thetas[m]; ++j)
+          grad_thetas[(t0 + b) * tot_nt + o++] = c->h_bGout[(int64_t)m * cap * W + (int64_t)b * (n_thetas[m] + 1) + j];
+      if (info) info[t0 + b] = inf;
+    }
+  }
+  return GPMI_OK;
+}
+
 int gpmi_loo_terms_mix(gpmi_ctx* c, int nk, const int* kernels, const double* thetas, const int* n_thetas,
                        const double* g_host, double extra_diag, const double* mu, double* alpha_out,
                        double* ikdiag, int* info) {

@@ -130,6 +130,13 @@ struct gpmi_ctx {
   double* bGws = nullptr;    // partial sums of the fused contraction
   double* bNoise = nullptr;  // gpmi_lml_grad_batch_noise: one noise-variance vector per problem
   int bNoise_cap = 0;
+  // gpmi_lml_grad_batch_mix: per problem the window weights g_m and the row sums h_m (GPMI_MAX_MIX x np each), the
+  // sub-kernels' parameters (GPMI_MAX_MIX arrays of bcap KParams) and the WhiteNoise variances
+  double* bMixG = nullptr;
+  double* bMixH = nullptr;
+  KParams* bMixP = nullptr;
+  double* bMixExtra = nullptr;
+  int bMix_cap = 0;
   double* bLoo = nullptr;    // gpmi_loo_grad_batch: 4 vectors per problem (diag K^-1, c1, sqrt c2, p)
   int bLoo_cap = 0;
   double* bGout = nullptr;   // (n_theta + 1) results per problem
@@ -251,13 +258,18 @@ struct BatchShape {
 
 // mix.hip: pieces of the mixture covariance K = sum_m diag(g_m) K_m diag(g_m) (ChangePoint)
 constexpr int GPMI_MAX_MIX = 4;
+// (batch > 1: problem z of a lockstep batch works on matrices sD / sS / sA / sMat apart and on weight vectors sG apart)
 void launch_scale_add(hipStream_t s, double* dst, int64_t ldd, const double* src, int64_t lds,
-                      const double* gr, const double* gc, int64_t rows, int64_t cols, bool accumulate);
-void launch_add_diag_vec(hipStream_t s, double* A, int64_t ld, const double* noise, double extra, int64_t n);
-void launch_vec_mul(hipStream_t s, const double* a, const double* b, double* out, int64_t n);
+                      const double* gr, const double* gc, int64_t rows, int64_t cols, bool accumulate, int batch = 1,
+                      int64_t sD = 0, int64_t sS = 0, int64_t sG = 0);
+void launch_add_diag_vec(hipStream_t s, double* A, int64_t ld, const double* noise, double extra, int64_t n,
+                         int batch = 1, int64_t sA = 0, const double* extras = nullptr);
+void launch_vec_mul(hipStream_t s, const double* a, const double* b, double* out, int64_t n, int batch = 1,
+                    int64_t sA = 0, int64_t sB = 0, int64_t sOut = 0);
 // h_i = sum_j (alpha_i alpha_j - iK_ij) Km_ij g_j  (iK, Km full n x n)
 void launch_mix_rowsum(hipStream_t s, const double* iK, const double* Km, int64_t ld, const double* alpha,
-                       const double* g, double* h, int64_t n);
+                       const double* g, double* h, int64_t n, int batch = 1, int64_t sMat = 0, int64_t sAlpha = 0,
+                       int64_t sG = 0);
 
 // gemm_f64.hip  (all dims multiples of 128, k multiple of 16)
 enum GemmTiles { TILES_RECT = 0, TILES_LOWER = 1 };

@@ -7,9 +7,14 @@
 namespace {
 
 // dst = (or +=) gr_i gc_j src_ij over rows x cols (both multiples of 128), 2 doubles per thread
+// (batched: problem blockIdx.z works on dst + z sD, src + z sS and the weight vectors gr / gc + z sG)
 __global__ void scale_add_kernel(double* __restrict__ dst, int64_t ldd, const double* __restrict__ src,
                                  int64_t lds, const double* __restrict__ gr, const double* __restrict__ gc,
-                                 int64_t cols, int accumulate) {
+                                 int64_t cols, int accumulate, int64_t sD, int64_t sS, int64_t sG) {
+  dst += (int64_t)blockIdx.z * sD;
+  src += (int64_t)blockIdx.z * sS;
+  gr += (int64_t)blockIdx.z * sG;
+  gc += (int64_t)blockIdx.z * sG;
   const int64_t i = blockIdx.y;
   const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
   if (j >= cols) return;
@@ -23,14 +28,20 @@ __global__ void scale_add_kernel(double* __restrict__ dst, int64_t ldd, const do
   *reinterpret_cast<d2_t*>(dst + i * ldd + j) = v;
 }
 
+// (batched: problem blockIdx.z works on A + z sA and adds extras[z] when `extras` is given)
 __global__ void add_diag_vec_kernel(double* __restrict__ A, int64_t ld, const double* __restrict__ noise,
-                                    double extra, int64_t n) {
+                                    double extra, int64_t n, int64_t sA, const double* __restrict__ extras) {
+  A += (int64_t)blockIdx.z * sA;
+  if (extras) extra = extras[blockIdx.z];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) A[i * ld + i] += noise[i] + extra;
 }
 
 __global__ void vec_mul_kernel(const double* __restrict__ a, const double* __restrict__ b,
-                               double* __restrict__ out, int64_t n) {
+                               double* __restrict__ out, int64_t n, int64_t sA, int64_t sB, int64_t sOut) {
+  a += (int64_t)blockIdx.z * sA;
+  b += (int64_t)blockIdx.z * sB;
+  out += (int64_t)blockIdx.z * sOut;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = a[i] * b[i];
 }
@@ -40,7 +51,13 @@ __global__ __launch_bounds__(256) void mix_rowsum_kernel(const double* __restric
                                                          const double* __restrict__ Km, int64_t ld,
                                                          const double* __restrict__ alpha,
                                                          const double* __restrict__ g,
-                                                         double* __restrict__ h, int64_t n) {
+                                                         double* __restrict__ h, int64_t n, int64_t sMat,
+                                                         int64_t sAlpha, int64_t sG) {
+  iK += (int64_t)blockIdx.z * sMat;
+  Km += (int64_t)blockIdx.z * sMat;
+  alpha += (int64_t)blockIdx.z * sAlpha;
+  g += (int64_t)blockIdx.z * sG;
+  h += (int64_t)blockIdx.z * sG;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
@@ -62,23 +79,27 @@ __global__ __launch_bounds__(256) void mix_rowsum_kernel(const double* __restric
 }  // namespace
 
 void launch_scale_add(hipStream_t s, double* dst, int64_t ldd, const double* src, int64_t lds,
-                      const double* gr, const double* gc, int64_t rows, int64_t cols, bool accumulate) {
-  dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)rows);
+                      const double* gr, const double* gc, int64_t rows, int64_t cols, bool accumulate, int batch,
+                      int64_t sD, int64_t sS, int64_t sG) {
+  dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)rows, (unsigned)batch);
   hipLaunchKernelGGL(scale_add_kernel, grid, dim3(256), 0, s, dst, ldd, src, lds, gr, gc, cols,
-                     accumulate ? 1 : 0);
+                     accumulate ? 1 : 0, sD, sS, sG);
 }
 
-void launch_add_diag_vec(hipStream_t s, double* A, int64_t ld, const double* noise, double extra, int64_t n) {
-  hipLaunchKernelGGL(add_diag_vec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A, ld, noise,
-                     extra, n);
+void launch_add_diag_vec(hipStream_t s, double* A, int64_t ld, const double* noise, double extra, int64_t n, int batch,
+                         int64_t sA, const double* extras) {
+  hipLaunchKernelGGL(add_diag_vec_kernel, dim3((unsigned)((n + 255) / 256), 1, (unsigned)batch), dim3(256), 0, s, A, ld,
+                     noise, extra, n, sA, extras);
 }
 
-void launch_vec_mul(hipStream_t s, const double* a, const double* b, double* out, int64_t n) {
-  hipLaunchKernelGGL(vec_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, out, n);
+void launch_vec_mul(hipStream_t s, const double* a, const double* b, double* out, int64_t n, int batch, int64_t sA,
+                    int64_t sB, int64_t sOut) {
+  hipLaunchKernelGGL(vec_mul_kernel, dim3((unsigned)((n + 255) / 256), 1, (unsigned)batch), dim3(256), 0, s, a, b, out, n,
+                     sA, sB, sOut);
 }
 
 void launch_mix_rowsum(hipStream_t s, const double* iK, const double* Km, int64_t ld, const double* alpha,
-                       const double* g, double* h, int64_t n) {
-  hipLaunchKernelGGL(mix_rowsum_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, iK, Km, ld, alpha, g, h,
-                     n);
+                       const double* g, double* h, int64_t n, int batch, int64_t sMat, int64_t sAlpha, int64_t sG) {
+  hipLaunchKernelGGL(mix_rowsum_kernel, dim3((unsigned)((n + 3) / 4), 1, (unsigned)batch), dim3(256), 0, s, iK, Km, ld,
+                     alpha, g, h, n, sMat, sAlpha, sG);
 }

@@ -193,6 +193,31 @@ class GpEngine(_DeviceCommMixin):
                     C.byref(lml), dptr(grad), dptr(hrows), dptr(alpha), C.byref(info))
         return lml.value, grad, hrows, alpha, info.value
 
+    def lml_grad_batch_mix(self, kernels, thetas, weights, extra_diag=None, mus=None, mu_const=None, want_qdiag=False):
+        """gpmi_lml_grad_batch_mix: T evaluations of the mixture likelihood and its gradient pieces in one call.
+        kernels: the nk sub-kernel ids; thetas: T lists of nk parameter vectors; weights: (T, nk, n) window weights.
+        Returns (lml (T,), grad (T, sum n_thetas), hrows (T, nk, n), alpha (T, n), qdiag (T, n) or None, info (T,))."""
+        ks = np.ascontiguousarray(kernels, dtype=np.int32)
+        nk = len(ks)
+        T = len(thetas)
+        nts = np.ascontiguousarray([len(t) for t in thetas[0]], dtype=np.int32)
+        th = as_f64(np.array([np.concatenate([np.asarray(v, dtype=float) for v in row]) for row in thetas]))
+        g = as_f64(np.asarray(weights, dtype=float).reshape(T, nk, self.n))
+        ex = None if extra_diag is None else as_f64(extra_diag)
+        mus = None if mus is None else as_f64(mus)
+        mc = None if mu_const is None else as_f64(mu_const)
+        lml = np.empty(T)
+        grad = np.empty((T, int(nts.sum())))
+        hrows = np.empty((T, nk, self.n))
+        alpha = np.empty((T, self.n))
+        qdiag = np.empty((T, self.n)) if want_qdiag else None
+        info = np.zeros(T, dtype=np.int32)
+        ip = C.POINTER(C.c_int)
+        self.h.call("gpmi_lml_grad_batch_mix", nk, ks.ctypes.data_as(ip), T, dptr(th), nts.ctypes.data_as(ip), dptr(g),
+                    dptr(ex), dptr(mus), dptr(mc), dptr(lml), dptr(grad), dptr(hrows), dptr(alpha), dptr(qdiag),
+                    info.ctypes.data_as(ip))
+        return lml, grad, hrows, alpha, qdiag, info
+
     def loo_terms_mix(self, kernels, thetas, weights, extra_diag, mu):
         nk, ks, kp, th, nts, ntp, g = self._mix_args(kernels, thetas, weights)
         mu = as_f64(mu)

@@ -622,7 +622,9 @@ class GpRegressor:
         (gpmi_lml_grad_batch: for N <= 4096 the evaluations advance in lockstep, every launch carrying all of them):
         returns (lml (T,), grad (T, P)).  What the lockstep multi-start search evaluates per round."""
         thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
-        if self._generic or self._mix is not None:  # the mixture's window weights are per point AND per evaluation
+        if self._mix is not None and not self._generic and self._mix.n_kernels == 2 and self._het_slice is None:
+            return self._mixture_gradient_batch(thetas)  # (round 4: gpmi_lml_grad_batch_mix)
+        if self._generic or self._mix is not None:  # more than two regions, or per-point noise on top: one at a time
             res = [self.marginal_likelihood_gradient(t) for t in thetas]
             return np.array([r[0] for r in res]), np.array([r[1] for r in res])
         th = np.array([np.ascontiguousarray(t[self.cov_slice][self._stat_slice]) for t in thetas])
@@ -668,6 +670,41 @@ class GpRegressor:
         grad[cp.cp_slc[0]] = [float((dw * (hrows[1] - hrows[0])).sum()) for dw in dws]
         trace_q = float(self.engine.lml_grad_qdiag().sum()) if self._wn_index is not None else 0.0
         return lml, grad, alpha, trace_q, info
+
+    def _mixture_gradient_batch(self, thetas):
+        """`marginal_likelihood_gradient` of a two-region ChangePoint model for T hyper-parameter vectors in one device
+        call: per evaluation the window weights (O(N) on the host) go along with the sub-kernels' parameters, the device
+        returns the sub-kernel gradients and the row sums h_m, and the window parameters' gradient is contracted here
+        as in `_mixture_gradient` (covariance.py:561-594)."""
+        cp = self._mix
+        T = len(thetas)
+        stat = [np.ascontiguousarray(t[self.cov_slice][self._stat_slice]) for t in thetas]
+        ex = np.array([float(np.exp(2 * t[self.cov_slice][self._wn_index])) if self._wn_index is not None else 0.0
+                       for t in thetas])
+        means = [self.mean.mean_and_gradients(t[self.mean_slice]) for t in thetas]
+        mean_kw = (dict(mu_const=thetas[:, 0]) if isinstance(self.mean, ConstantMean)
+                   else dict(mus=np.array([m[0] for m in means])))
+        args = [self._mix_args(s_) for s_ in stat]
+        kernels = args[0][0]
+        lml, g_sub, hrows, alpha, qdiag, info = self.engine.lml_grad_batch_mix(
+            kernels, [a[1] for a in args], np.array([a[2] for a in args]), ex, want_qdiag=self._wn_index is not None,
+            **mean_kw)
+        self._mix_fit_stale = True
+        if (info != 0).any():
+            raise LinAlgError("Matrix is not positive definite")  # regression.py:555 has no guard
+        grads = zeros((T, self.n_hyperpars))
+        for t in range(T):
+            g_cp = zeros(cp.n_params)
+            g_cp[: g_sub.shape[1]] = g_sub[t]
+            w, dws = cp.logistic_and_gradient(cp.x_cp, stat[t][cp.cp_slc[0]])
+            g_cp[cp.cp_slc[0]] = [float((dw * (hrows[t, 1] - hrows[t, 0])).sum()) for dw in dws]
+            grads[t, self.mean_slice] = array([(alpha[t] * dmu).sum() for dmu in means[t][1]])
+            g_cov = zeros(self.cov.n_params)
+            g_cov[self._stat_slice] = g_cp
+            if self._wn_index is not None:
+                g_cov[self._wn_index] = ex[t] * float(qdiag[t].sum())
+            grads[t, self.cov_slice] = g_cov
+        return lml, grads
 
     # ---------------------------------------------------------------------------------
     # covariance functions that only implement the plugin ABC: the plugin's host methods make the dense
@@ -892,12 +929,13 @@ class GpRegressor:
         leave-one-out likelihood of a kernel with a fused device gradient and the problem is small enough for batched
         (lockstep) device evaluations; the values of a start are then those of `launch_bfgs` evaluated through the same
         batched kernels (`batch_independent_values`).  HeteroscedasticNoise - one variance per point and evaluation - rides
-        along for the marginal likelihood (gpmi_lml_grad_batch_noise); its leave-one-out gradient and the ChangePoint
-        mixtures (window weights per point and evaluation, several sub-kernel builds) have no batched kernels: their
-        starts run one after another."""
+        along for the marginal likelihood (gpmi_lml_grad_batch_noise), and so do two-region ChangePoint mixtures (window
+        weights per point and evaluation, gpmi_lml_grad_batch_mix).  Their leave-one-out gradients, mixtures over more
+        regions and mixtures with per-point noise have no batched kernels: those starts run one after another."""
         lml = self.model_selector_gradient == self.marginal_likelihood_gradient
         loo = self.model_selector_gradient == self.loo_likelihood_gradient
-        return ((lml or (loo and self._het_slice is None)) and not self._generic and self._mix is None
+        mix_ok = self._mix is None or (lml and self._mix.n_kernels == 2 and self._het_slice is None)
+        return ((lml or (loo and self._het_slice is None)) and not self._generic and mix_ok
                 and self._y_cov is None and self.engine.capacity() <= 4096)
 
     def __str__(self):

@@ -934,6 +934,36 @@ def test_change_point_vs_reference(golden, gp_mod, tag, subs, wn):
     check([gp.loo_likelihood(t) for t in th], g[f"{tag}_loo"], what="loo likelihood")
 
 
+@pytest.mark.parametrize("tag,subs,wn", [("sese", (wl.SE, wl.SE), False), ("serq", (wl.SE, wl.RQ), False),
+                                          ("sesewn", (wl.SE, wl.SE), True)])
+def test_change_point_batched_gradient(golden, gp_mod, tag, subs, wn):
+    """gpmi_lml_grad_batch_mix (round 4): the mixture's LML and full gradient for several hyper-parameter vectors in one
+    lockstep call - against the reference's values (the `cp` fixture) and against one-at-a-time evaluations, for ragged
+    batch sizes; the lockstep search is on for such a model and the fitted state survives the batch."""
+    g = golden("cp")
+    x, y, e, pts = g["x"], g["y"], g["y_err"], g["pts"]
+    th = g[f"{tag}_thetas"]
+    cov = gp_mod.ChangePoint(kernels=[kernel_cls(gp_mod, k) for k in subs])
+    if wn:
+        cov = cov + gp_mod.WhiteNoise()
+    gp = gp_mod.GpRegressor(x, y, y_err=e, kernel=cov, hyperpars=th[1])
+    assert gp._lockstep_search()
+    rng = np.random.default_rng(8)
+    more = np.vstack([th, th[0] + 0.05 * rng.standard_normal((5, th.shape[1]))])
+    single = [gp.marginal_likelihood_gradient(t) for t in more]
+    for b in (len(more), len(th), 1):
+        f, gr = gp.marginal_likelihood_gradient_batch(more[:b])
+        check(f, [r[0] for r in single[:b]], 1e-12, f"mixture LML, batch of {b}")
+        for k in range(b):
+            check_each(gr[k], single[k][1], 1e-11, what=f"mixture gradient, batch of {b}")
+    f, gr = gp.marginal_likelihood_gradient_batch(th)
+    check(f, g[f"{tag}_lml2"], what="mixture LML (batched) vs reference")
+    for r, ref in zip(gr, g[f"{tag}_grad"]):
+        check_each(r, ref, what="mixture gradient (batched) vs reference")
+    mu, sig = gp(pts)  # the batch used the shared weight buffers: the fit is restored lazily
+    check(mu, g[f"{tag}_mu"], what="mu after the batched evaluations")
+
+
 def test_change_point_search_and_limits(gp_mod):
     """Hyper-parameter search through the mixture path (L-BFGS-B with the analytic gradient); three regions
     work for fit / predict / LML / gradient (dense device path); sub-kernels without device code take the dense path."""

@@ -1,7 +1,7 @@
 """Constructor-with-search time (multi-start L-BFGS-B over the hyper-parameters, regression.py:585-605) for BASELINE
 configs 1 and 4, lockstep (one batched gradient evaluation per round for all starts) against one start after another;
 for the marginal likelihood and (round 4: gpmi_loo_grad_batch) the cross-validation objective (cross_val=True,
-regression.py:159-164).
+regression.py:159-164); and for a two-region ChangePoint model (round 4: gpmi_lml_grad_batch_mix).
 usage: python tools/search_time.py"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,6 +35,27 @@ for cfg, n, d in ((1, 512, 2), (5, 2048, 4), (4, 4096, 4)):
         gp = GpRegressor(x, y, y_err=e, cross_val=True)
         row["cross_val_" + mode + "_seconds"] = time.perf_counter() - t0
         row["cross_val_" + mode + "_loo"] = float(gp.loo_likelihood(gp.hyperpars))
+    GpRegressor._lockstep_search = keep
+    out.append(row)
+# a two-region ChangePoint model (covariance.py:371-606; round 4: gpmi_lml_grad_batch_mix), 1-D step in the length scale
+from inference_amd.gp import ChangePoint, SquaredExponential
+
+rng = np.random.default_rng(11)
+for n in (512, 2048):
+    x = np.sort(rng.uniform(0, 1, n)).reshape(-1, 1)
+    y = np.where(x[:, 0] < 0.5, np.sin(4 * x[:, 0]), np.sin(40 * x[:, 0])) + 0.05 * rng.normal(size=n)
+    e = np.full(n, 0.05)
+    row = {"config": "ChangePoint[SE, SE]", "N": n, "d": 1}
+    keep = GpRegressor._lockstep_search
+    for mode in ("warm", "serial", "lockstep"):
+        np.random.seed(3)
+        GpRegressor._lockstep_search = (lambda self: False) if mode == "serial" else keep
+        t0 = time.perf_counter()
+        gp = GpRegressor(x, y, y_err=e, kernel=ChangePoint(kernels=[SquaredExponential] * 2))
+        if mode != "warm":
+            row[mode + "_seconds"] = time.perf_counter() - t0
+            row[mode + "_lml"] = float(gp.marginal_likelihood(gp.hyperpars))
+            row["starts"] = int(2 * np.sqrt(len(gp.hp_bounds))) + 1
     GpRegressor._lockstep_search = keep
     out.append(row)
 print(json.dumps(out, indent=1))
