@@ -226,7 +226,7 @@ def kernel_rows(eng, step, _lib, N, M):
                      "launches": ts["launches"], "avg_ms": ts["ms"] / ts["launches"], "flops": "M N^2 per predict"})
     if pn["ms"] > 0:
         rows.append({"kernel": "panel chain (potrf_diag_kernel + panel TRSM + inner K=128 updates; 32 CUs, hidden behind the "
-                     "trailing update during the look-ahead regime, >= 60 trailing tile rows)", "bound": "latency", "launches": pn["launches"],
+                     "trailing update during the look-ahead regime, >= 52 trailing tile rows)", "bound": "latency", "launches": pn["launches"],
                      "total_ms_per_step": pn["ms"] / 2})
     return rows
 
@@ -559,7 +559,7 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                 },
                 "flow_tail_scope": "one flag-ordered tail per device at a time, process-wide: of several evaluation lanes factoring side by side (the config-3 sweep) only one gets it, the others take the stream-ordered schedule (same bits)",
                 "flow_tail": {
-                    "what": "the chain-bound last tile rows of the factorisation (below 60 trailing tile rows) as ONE persistent tile-task launch on the update stream's 224 CUs beside the bare panel chain (csrc/potrf_flow.hip): FLOPs of its K = 128 / K = 512 update tasks over the launch's whole duration - the launch waits for the chain most of the time, so this is the overlap achieved, not a kernel rate; not part of all_trailing",
+                    "what": "the chain-bound last tile rows of the factorisation (below 52 trailing tile rows) as ONE persistent tile-task launch on the update stream's 224 CUs beside the bare panel chain (csrc/potrf_flow.hip): FLOPs of its K = 128 / K = 512 update tasks over the launch's whole duration - the launch waits for the chain most of the time, so this is the overlap achieved, not a kernel rate; not part of all_trailing",
                     "achieved": (prof_flow["flops"] / (prof_flow["ms"] * 1e-3) / 1e12) if prof_flow["ms"] > 0 else 0.0,
                     "launches": prof_flow["launches"],
                     "ms_per_step": prof_flow["ms"] / max(args.steps, 1),

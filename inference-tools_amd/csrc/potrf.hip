@@ -770,7 +770,7 @@ constexpr int OUTER_TILES = 4;  // tile columns per outer panel
 int lookahead_min() {
   static const int v = [] {
     const char* e = std::getenv("GPMI_LOOKAHEAD_MIN");
-    const int x = e ? std::atoi(e) : 60;
+    const int x = e ? std::atoi(e) : 52;  // (60 until the chain step of the flag-ordered tail went from 57 to 33 us)
     return x > 0 ? x : (1 << 30);
   }();
   return v;
@@ -793,7 +793,7 @@ void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, dou
   // overlap on a pair of CU-masked streams (disjoint CUs: a 75 KiB potrf_diag workgroup never finds a slot
   // on a chip saturated by GEMM workgroups): the update stream first updates the columns of panel p + 1
   // ("la"), the panel stream then factors them on 32 CUs while the update stream applies the rest on the
-  // other 224.  Below GPMI_LOOKAHEAD_MIN (60) trailing tile rows the update is shorter than the panel chain on its 32 CUs
+  // other 224.  Below GPMI_LOOKAHEAD_MIN (52) trailing tile rows the update is shorter than the panel chain on its 32 CUs
   // and everything runs in order on the full-chip stream - and so does the very first panel (nothing to overlap
   // it with: 0.49 instead of 0.92 ms).
   // Measured and dropped: a second pair with 16 | 240 CUs for the early panels (the
