@@ -732,7 +732,7 @@ void update_slice(gpmi_ctx* c, hipStream_t s, double* A, int64_t ld, int nt, int
 // update's last tiles (the far-right column strips, which neither the next look-ahead update nor the next panel
 // touch) runs there behind the chain.  Cost model in microseconds, fitted to the measured timeline
 // (profiles/r02_bench_timeline.txt): 64.4 us per tile and CU pair slot at K = 512 (0.29 us per tile on 224 CUs, 2.0 on
-// 32), the chain 200 + 7.6 us per trailing tile row; the slice takes GPMI_SLICE_PCT % (default 100; 0: none) of the
+// 32), the chain 146 + 6.1 us per trailing tile row (re-fitted in round 4; 200 + 7.6 before); the slice takes GPMI_SLICE_PCT % (default 100; 0: none) of the
 // balance point, rounded down to whole rounds of the reserved CUs.  Measured: 36.4 -> 35.9 ms per step at 100 and 130 %,
 // 37.0 at 160 % (the next update then waits for the slice); the 32 extra CUs lower the clock of the other 224 from
 // 2.364 to 2.352 GHz (the update runs at the chip's power limit), which is why the gain is a third of the idle time.
@@ -744,12 +744,20 @@ int64_t slice_tiles(int rem, int64_t tiles_la, int64_t tiles_main, int kw, int n
   if (PCT <= 0 || kw != 4 * NB) return 0;
   const double tile_us = 64.4 * 2.0;  // one CU works on two tiles at a time
   const double per_main = tile_us / (2.0 * ncu_main), per_panel = tile_us / (2.0 * ncu_panel);
-  // (200 us until round 4, whose potrf_diag takes 8 us less per column; GPMI_SLICE_CHAIN_US for A/B runs)
+  // The panel chain of one outer panel on the reserved CUs, re-fitted to round 4's timeline (profiles/r04_bench_timeline.txt:
+  // 880 us at 120 trailing tile rows = 4 x potrf_diag 20 + 4 x panel TRSM 0.56 us per row + inner updates 3.8 us per row +
+  // launch gaps): 146 + 6.1 us per row (200 + 7.6 until round 3).  The slices grow by 30 % with it: 32.76 -> 32.53 ms per
+  // step (medians of six alternating runs, tools/scratch/knobs4.sh); 45 % more is too much (32.86: the next update waits
+  // for the slice).  GPMI_SLICE_CHAIN_US / GPMI_SLICE_CHAIN_SLOPE for A/B runs.
   static const double CHAIN0 = [] {
     const char* e = std::getenv("GPMI_SLICE_CHAIN_US");
-    return e ? std::atof(e) : 168.0;
+    return e ? std::atof(e) : 146.0;
   }();
-  const double chain = CHAIN0 + 7.6 * rem;
+  static const double SLOPE = [] {
+    const char* e = std::getenv("GPMI_SLICE_CHAIN_SLOPE");
+    return e ? std::atof(e) : 6.1;
+  }();
+  const double chain = CHAIN0 + SLOPE * rem;
   const double su = 20.0 + (double)(tiles_la + tiles_main) * per_main;
   double x = (su - chain) / (per_main + per_panel) * PCT / 100.0;
   const int64_t round = 2 * ncu_panel;
