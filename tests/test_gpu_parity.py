@@ -1443,7 +1443,9 @@ def test_schedule_variants_agree(tmp_path):
         {"GPMI_LOOKAHEAD_MIN": "0"},
         {"GPMI_LOOKAHEAD_MIN": "24", "GPMI_KBUILD_NO_SPLIT": "1"},
         {"GPMI_M32_MAX": "0", "GPMI_SPLIT_PCT": "0", "GPMI_BIG_MIN": "64"},
-        {"GPMI_FLOW": "0"},  # the last 60 tile rows in stream order instead of as flag-ordered tile tasks
+        {"GPMI_FLOW": "0"},  # the last 52 tile rows in stream order instead of as flag-ordered tile tasks
+        {"GPMI_CHAIN_TILES": "1"},  # the tail's chain: two 16 x 16-tile launches per column instead of the fused one
+        {"GPMI_CHAIN_TILES": "0"},  # ... and the generic tile kernels
         {"GPMI_LOOKAHEAD_MIN": "84", "GPMI_FLOW_NEAR_WGS": "64", "GPMI_FLOW_NEAR": "0", "GPMI_FLOW_NEAR_D": "5"},
     ]
     base = None
@@ -1460,7 +1462,7 @@ def test_schedule_variants_agree(tmp_path):
             continue
         for q in ("alpha", "logdet", "mu", "sig"):
             check(r[q + "0"], base[q + "0"], 1e-11, f"{q} under {extra}")
-            if "GPMI_FLOW" in extra or "GPMI_FLOW_NEAR" in extra:  # same bodies, same summation order: same bits
+            if "GPMI_FLOW" in extra or "GPMI_FLOW_NEAR" in extra or "GPMI_CHAIN_TILES" in extra:  # same sums: same bits
                 assert np.array_equal(r[q + "0"], base[q + "0"]), (extra, q)
 
 
