@@ -9,9 +9,9 @@ value = (N^3/3 + M N^2) FLOP per step * steps * n_gpus / wall  in GFLOP/s (whole
 
 N GPUs: one process per GPU, each rank runs the same step at its own hyper-parameter vector (the path
 shards over independent hyper-parameter evaluations, weak scaling) and the per-rank results
-(log-determinant, alpha norm, predictive checksum) are all-gathered over RCCL / xGMI inside the timed
-region through the library's own communicator (gpmi_comm_*); barriers and the max-over-ranks of the
-timing are RCCL all-gathers too.  The ranks launched by torch.distributed.run read RANK / LOCAL_RANK /
+(log-determinant, alpha norm, predictive checksum of every step) are all-gathered over RCCL / xGMI in ONE
+collective at the end of the timed region through the library's own communicator (gpmi_comm_*); barriers and
+the max-over-ranks of the timing are RCCL all-gathers too.  The ranks launched by torch.distributed.run read RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_PORT from the environment and exchange the RCCL unique id through a per-job
 directory in /tmp (inference_amd.sharding.FileRendezvous): torch itself is NOT imported, because
 importing it loads torch's bundled HIP / HSA runtime beside the system ROCm 7.2 one, and RCCL then
@@ -381,8 +381,8 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
     theta = thetas[rank % len(thetas)] if world > 1 else thetas[0]
     pts = wl.query_points(2, M, d)
 
-    gp = GpRegressor(x, y, y_err=e, hyperpars=theta, kernel=SquaredExponential,
-                     device=local_rank % max(_lib.device_count(), 1))
+    dev_index = local_rank % max(_lib.device_count(), 1)
+    gp = GpRegressor(x, y, y_err=e, hyperpars=theta, kernel=SquaredExponential, device=dev_index)
     eng = gp.engine
     gather = "none"
     if world > 1:
@@ -401,14 +401,22 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
             except Exception as err:
                 box["ok"], box["why"] = False, f"{type(err).__name__}: {err}"
 
-        th = threading.Thread(target=bootstrap, daemon=True)
-        th.start()
-        th.join(float(os.environ.get("GPMI_BENCH_RCCL_TIMEOUT", "120")))  # < the rendezvous' own time limit (main)
-        if th.is_alive():
-            STUCK.append(True)
-            ok, why = False, "RCCL bootstrap did not return within the time limit"
+        # ranks that share a device (bench.py --gpus 2 on a 1-GPU box) never try: RCCL refuses duplicate devices, and
+        # while one rank is refused at once another can sit in the bootstrap waiting for it until the watchdog fires
+        import socket
+
+        where = rdv.allgather_obj(f"{socket.gethostname()}:{dev_index}")
+        if len(set(where)) < world:
+            ok, why = False, "ranks share a device (RCCL refuses duplicate devices)"
         else:
-            ok, why = box.get("ok", False), box.get("why", "")
+            th = threading.Thread(target=bootstrap, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("GPMI_BENCH_RCCL_TIMEOUT", "120")))  # < the rendezvous' own time limit (main)
+            if th.is_alive():
+                STUCK.append(True)
+                ok, why = False, "RCCL bootstrap did not return within the time limit"
+            else:
+                ok, why = box.get("ok", False), box.get("why", "")
         # every rank must take the same path
         oks = rdv.allgather_obj(ok)
         gather = "rccl" if all(oks) else f"file-fallback ({'; '.join(str(o) for o in oks)}{'' if ok else ' ' + why})"
@@ -435,10 +443,7 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
         # plain NumPy reductions only: a BLAS call here (np.linalg.norm -> OpenBLAS nrm2) starts OpenBLAS's
         # spinning worker pool, which starves the HIP runtime's completion handling and doubled the
         # step time from the next step on (tools/scratch/phase_times3.py)
-        res = np.array([gp._logdet, float(np.sqrt(np.sum(gp.alpha**2))), float(mu.sum()), float(sig.sum())])
-        if world > 1:
-            res = allgather(res)
-        return res
+        return np.array([gp._logdet, float(np.sqrt(np.sum(gp.alpha**2))), float(mu.sum()), float(sig.sum())])
 
     for _ in range(args.warmup):
         step()
@@ -454,9 +459,14 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
     fence()
     t0 = time.perf_counter()
     marks = []
+    results = []
     for _ in range(args.steps):
-        res = step()
+        results.append(step())
         marks.append(time.perf_counter())
+    # the ranks' results meet ONCE, still inside the timed region (the units are independent: a gather per step would
+    # only make every rank wait for the slowest one at every step - and cost a file round trip per step whenever the
+    # communicator could not be created)
+    res = allgather(np.concatenate(results)) if world > 1 else results[-1]
     fence()
     dt = time.perf_counter() - t0
     if os.environ.get("BENCH_STEP_TIMES") and rank == 0:  # debugging aid: host-side completion time of each step
@@ -510,6 +520,7 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                 "flop_per_step": flops_step,
                 "pct_fp64_mfma_peak_whole_step": 100.0 * value / world / 1e3 / PEAK_FP64_MFMA_TFLOPS,
                 "parallelism": f"{world} independent hyper-parameter evaluations (one per GPU), result all-gather: {gather}",
+                "gathered_values": int(np.size(res)),  # steps x 4 per rank, all ranks' in ONE collective inside the timed region
                 **RCCL_INFO,
             },
             "roofline": {
