@@ -31,10 +31,14 @@ Extra objects on the JSON line:
                 bytes per launch from the PMC passes of the same command committed under profiles/ (separate
                 rocprofv3 --pmc runs cannot be part of this run); `kernels` lists the other kernels of a step
                 (K-build, the two triangular sweeps, the predict TRSM) from an extra, un-timed pass with events.
-  cpu_baseline  the CPU oracle (NumPy/SciPy restatement of the reference, kind "port") timed on the
-                host cores on a bounded sample of the same workload (rank 0, N=1 only); `at_metric_size` (round 4):
-                ONE run of the same oracle at the metric's own N, d, M with K-build / potrf / solves / predict seconds
-                apart (--no-cpu-metric-size skips it: about a minute of host time)
+  cpu_baseline  the CPU oracle (NumPy/SciPy restatement of the reference, kind "port") timed on the host cores (rank 0,
+                N=1 only).  `value` (round 5) = ONE run at the metric's own N, d, M with K-build / potrf / solves / predict
+                seconds apart, after the bounded N=4096 sample (`sample_n4096`: warm-up + median of 3) has warmed the BLAS
+                pool; --no-cpu-metric-size leaves the sample as `value`.  `configs` = the same oracle at the sizes of
+                BASELINE configs 2-5, one bounded run each (--no-cpu-configs skips them: about two minutes of host time)
+  configs       device timings of the BASELINE configurations the headline and `sharded` do not cover, after the timed
+                region: config 2 (fit / predict / LML / LML + gradient at N=8192), config 4 (EI, -ln EI + gradient at 1000
+                candidates, one propose_evaluation) and the LML gradient at the metric's own size (--no-configs skips them)
 """
 import argparse
 import json
@@ -46,6 +50,43 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "inference-tools_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+
+
+def _rank_cpu_setup():
+    """A rank of a multi-rank job keeps to its own share of the host: cores (sched_setaffinity) and BLAS / OpenMP
+    threads = cores // ranks, set HERE - in the child, before NumPy loads its BLAS and before anything touches the GPU.
+    Eight ranks with a 64-thread OpenBLAS pool each on 64 cores would spin against one another and against the HIP
+    runtime's completion threads (one stray BLAS call doubled the step time: see step() below).  BENCH_NO_PIN=1 leaves
+    the affinity alone; thread counts the caller has set are respected."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" not in os.environ or world <= 1:
+        return None
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % local_world
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cpus = list(range(os.cpu_count() or 1))
+    per = max(1, len(cpus) // local_world)
+    mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
+    pinned = False
+    if not os.environ.get("BENCH_NO_PIN"):
+        try:
+            os.sched_setaffinity(0, mine)
+            pinned = True
+        except (AttributeError, OSError):
+            pass
+    for var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+        if var == "OMP_NUM_THREADS" and os.environ.get(var) == "1" and "TORCHELASTIC_RUN_ID" in os.environ:
+            os.environ[var] = str(per)  # torch.distributed.run's own default of 1, not a choice of the caller
+        else:
+            os.environ.setdefault(var, str(per))
+    return {"cores_per_rank": per, "pinned": pinned, "first_core": mine[0],
+            "blas_threads": os.environ.get("OPENBLAS_NUM_THREADS")}
+
+
+RANK_CPU = _rank_cpu_setup()
 
 import numpy as np  # noqa: E402
 
@@ -162,8 +203,167 @@ def cpu_at_metric_size(n, d, m):
         "seconds": {"k_build": t_build, "potrf": t_potrf, "alpha_solves": t_solve, "predict": t_pred, "total": total},
         "potrf_gflops": n**3 / 3.0 / t_potrf / 1e9,
         "sample": f"ONE run of the memory-lean oracle at the metric's own size, SE N={n} d={d} M={m} (no warm-up: a second "
-        f"run would double the {total:.0f} s); checksum mu[0]={float(mu[0]):.12g} sig[0]={float(sig[0]):.6g}",
+        f"run would double the {total:.0f} s; the BLAS pool is warm from the N=4096 sample before it); checksum mu[0]={float(mu[0]):.12g} sig[0]={float(sig[0]):.6g}",
     }
+
+
+def _timeit(fn, reps=3, warm=1):
+    for _ in range(warm):
+        fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    return (time.perf_counter() - t0) / reps, out
+
+
+def _rate(flops, seconds):
+    t = flops / seconds / 1e12
+    return {"ms": seconds * 1e3, "tflops": t, "frac_of_fp64_mfma_peak": t / PEAK_FP64_MFMA_TFLOPS}
+
+
+def device_configs(wl, dev, head_gp, head_theta, N):
+    """The BASELINE.json configurations the headline does not cover, timed on the device AFTER the timed region through
+    the public classes (median-free: warm-up + mean of 3 calls, host wall clock around synchronous calls):
+    config 2 (SE N = 8192 d = 8: fit, predict of 1024 points, LML, LML + gradient - regression.py:218-244,188-216,528-567),
+    config 4 (SE N = 4096 d = 4: EI and -ln EI with gradient at 1000 candidates, one GpOptimiser.propose_evaluation -
+    acquisition.py:76-125, optimisation.py:202-249) and the LML gradient at the metric's own size.  FLOP counts: potrf
+    N^3/3, predict M N^2, LML + gradient N^3."""
+    from inference_amd.gp import ExpectedImprovement, GpOptimiser, GpRegressor
+
+    out = {}
+    n2, d2, m2 = 8192, 8, 1024
+    x, y, e = wl.synthetic_dataset(2, n2, d2)
+    th = wl.timing_theta(wl.SE, y, d2)
+    pts = wl.query_points(2, m2, d2)
+    gp = GpRegressor(x, y, y_err=e, hyperpars=th, device=dev)
+    gp.prepare_gradient()
+    fit, _ = _timeit(lambda: gp.set_hyperparameters(th), reps=5)
+    pred, _ = _timeit(lambda: gp(pts))
+    lml, _ = _timeit(lambda: gp.marginal_likelihood(th))
+    grad, _ = _timeit(lambda: gp.marginal_likelihood_gradient(th))
+    out["config2"] = {
+        "workload": f"GpRegressor SquaredExponential N={n2} d={d2}: set_hyperparameters / __call__ on M={m2} points / "
+                    "marginal_likelihood / marginal_likelihood_gradient, fixed theta",
+        "fit": _rate(n2**3 / 3.0, fit), "predict": _rate(m2 * float(n2) ** 2, pred),
+        "lml": _rate(n2**3 / 3.0, lml), "lml_gradient": _rate(float(n2) ** 3, grad),
+    }
+    gp.engine.close()
+
+    n4, d4 = 4096, 4
+    x, y, e = wl.synthetic_dataset(4, n4, d4)
+    th = wl.timing_theta(wl.SE, y, d4)
+    cand = wl.query_points(4004, 1000, d4)
+    opt = GpOptimiser(x, y, bounds=[(0.0, 1.0)] * d4, y_err=e, hyperpars=th, acquisition=ExpectedImprovement)
+    ei = opt.acquisition
+    ei_v, _ = _timeit(lambda: ei.call_batch(cand))
+    ei_g, _ = _timeit(lambda: ei.opt_func_gradient_batch(cand))
+
+    def propose():
+        np.random.seed(1)
+        return opt.propose_evaluation()
+
+    prop, where = _timeit(propose, reps=1)
+    out["config4"] = {
+        "workload": f"GpOptimiser / ExpectedImprovement on SquaredExponential N={n4} d={d4}, fixed theta: 1000 candidates per "
+                    f"call; one propose_evaluation = {n4} x 20 probes for the starting positions + {n4} L-BFGS-B runs in lockstep",
+        "ei_1000_candidates": {"ms": ei_v * 1e3, "candidates_per_s": 1000 / ei_v},
+        "minus_ln_ei_and_gradient_1000_candidates": {"ms": ei_g * 1e3, "candidates_per_s": 1000 / ei_g},
+        "propose_evaluation": {"seconds": prop, "proposal": [float(v) for v in np.ravel(where)]},
+    }
+    opt.gp.engine.close()
+
+    head_gp.prepare_gradient()
+    hg, _ = _timeit(lambda: head_gp.marginal_likelihood_gradient(head_theta))
+    out["lml_gradient_at_metric_size"] = {
+        "workload": f"GpRegressor SquaredExponential N={N}: marginal_likelihood_gradient (K-build, potrf, L^-T by TRSM, "
+                    "k-skipped SYRK, fused trace pass)", **_rate(float(N) ** 3, hg)}
+    return out
+
+
+def cpu_configs(wl, d_head):
+    """The CPU oracle (kind "port": the reference's NumPy / LAPACK calls, oracle/gp_oracle.py) on the host cores at every
+    BASELINE.json configuration's own size - one bounded run each, after the N = 4096 sample of
+    cpu_baseline has warmed the BLAS pool.  Config 3: ONE of the 64 grid points (x 64 stated, not measured); config 4: the
+    reference's per-candidate loop on a 50-candidate sample beside the batched restatement at 1000; config 5: LML
+    evaluations per second of one process.  The LML gradient at N = 16384 is not timed (N^3 = 4.4 TFLOP of dtrtri-like
+    work + 9 N x N gradient matrices: about two minutes)."""
+    from oracle import gp_oracle as orc  # checker / baseline only
+
+    out = {}
+
+    def clock(fn):
+        t0 = time.perf_counter()
+        r = fn()
+        return time.perf_counter() - t0, r
+
+    # config 2
+    n, d, m = 8192, 8, 1024
+    x, y, e = wl.synthetic_dataset(2, n, d)
+    th = wl.timing_theta(wl.SE, y, d)
+    pts = wl.query_points(2, m, d)
+    t_fit, gp = clock(lambda: orc.OracleGp(x, y, e, kernel=orc.SE, hyperpars=th))
+    t_pred, _ = clock(lambda: gp(pts))
+    t_lml, _ = clock(lambda: gp.marginal_likelihood(th))
+    del gp.K_xx, gp.L
+    t_grad, _ = clock(lambda: gp.marginal_likelihood_gradient_lean(th))
+    out["config2"] = {"fit_s": t_fit, "predict_s": t_pred, "lml_s": t_lml, "lml_gradient_s": t_grad,
+                      "fit_gflops": n**3 / 3.0 / t_fit / 1e9, "lml_gradient_gflops": float(n) ** 3 / t_grad / 1e9,
+                      "sample": f"one run each, SE N={n} d={d} M={m}; gradient by the one-matrix-at-a-time form"}
+    del gp
+    # config 3: one grid point
+    n, d = 16384, 16
+    x, y, e = wl.synthetic_dataset(3, n, d)
+    g0 = wl.theta_grid_cfg3(y, d)[0]
+    o3 = orc.OracleGp(x, y, e, kernel=orc.RQ)
+    t_one, _ = clock(lambda: o3.marginal_likelihood(g0))
+    out["config3"] = {"one_grid_point_s": t_one, "grid_of_64_s_extrapolated": 64 * t_one, "lml_evals_per_s": 1.0 / t_one,
+                      "sample": f"ONE marginal_likelihood of the 64-point grid, RQ N={n} d={d}; x 64 is an extrapolation"}
+    del o3
+    # config 4
+    n, d = 4096, 4
+    x, y, e = wl.synthetic_dataset(4, n, d)
+    th = wl.timing_theta(wl.SE, y, d)
+    cand = wl.query_points(4004, 1000, d)
+    gp = orc.OracleGp(x, y, e, kernel=orc.SE, hyperpars=th)
+    mu_max = float(y.max())
+
+    def loop_value():
+        for p in cand[:50]:
+            mu, sig = gp(p)
+            orc.ei_value(mu, sig, mu_max)
+
+    def loop_grad():
+        for p in cand[:50]:
+            mu, sig = gp(p)
+            sm, sv = gp.spatial_derivatives(p)
+            orc.ei_opt_func_gradient(mu, sig, sm, sv, mu_max)
+
+    def batched():
+        mu, sig = gp(cand)
+        return orc.ei_value(mu, sig, mu_max)
+
+    t_v, _ = clock(loop_value)
+    t_g, _ = clock(loop_grad)
+    t_b, _ = clock(batched)
+    out["config4"] = {"ei_per_candidate_loop_candidates_per_s": 50 / t_v, "minus_ln_ei_gradient_loop_candidates_per_s": 50 / t_g,
+                      "ei_batched_restatement_candidates_per_s": 1000 / t_b,
+                      "sample": f"SE N={n} d={d}: the reference's call structure (one solve_triangular per candidate, "
+                                "regression.py:205-216, 387-419) on 50 candidates; one TRSM over 1000 candidates for the batched form"}
+    del gp
+    # config 5
+    n, d = 2048, 4
+    x, y, e = wl.synthetic_dataset(5, n, d)
+    th = wl.timing_theta(wl.SE, y, d)
+    gp = orc.OracleGp(x, y, e, kernel=orc.SE)
+    rng = np.random.default_rng(0)
+    ths = th + 0.05 * rng.standard_normal((12, th.size))
+    gp.marginal_likelihood(ths[0])
+    t_e, _ = clock(lambda: [gp.marginal_likelihood(t) for t in ths[1:]])
+    out["config5"] = {"lml_evals_per_s": 11 / t_e,
+                      "sample": f"11 marginal_likelihood calls in one process, SE N={n} d={d} (the reference runs one process per chain: "
+                                "mcmc/parallel.py:127-136)"}
+    return out
+
 
 
 def pmc_traffic():
@@ -257,7 +457,7 @@ def sharded_configs(args, wl, sharding, rank, world, local_rank, rdv, gather, en
            "units per rank, ONE all-gather of the results at the end"}
     grid_n = int(os.environ.get("BENCH_CFG3_POINTS", "64"))
     if grid_n > 0:
-        n3, d3 = 16384, 16
+        n3, d3 = int(os.environ.get("BENCH_CFG3_N", "16384")), 16  # (the size is an aid of the tests only)
         x, y, e = wl.synthetic_dataset(3, n3, d3)
         grid = wl.theta_grid_cfg3(y, d3)[:grid_n]
         gp3 = GpRegressor(x, y, y_err=e, hyperpars=grid[0], kernel=RationalQuadratic, device=dev)
@@ -306,7 +506,17 @@ def launch_ranks(n_ranks):
     import subprocess
 
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    # dmabuf IPC: on this image's host driver the legacy IPC mode fails RCCL's cross-process buffer registration with
+    # `hipIpcGetMemHandle: invalid argument`; the image exports 0 already, setdefault keeps a caller's own choice
+    # 
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["LOCAL_WORLD_SIZE"] = str(n_ranks)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    for var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):  # (each child also pins itself: _rank_cpu_setup)
+        env.setdefault(var, str(max(1, cores // n_ranks)))
     env.update(WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=env.get("MASTER_PORT", "29511"),
                GPMI_RDV_KEY=f"bench_{os.getpid()}_{secrets.token_hex(6)}")
     procs = []
@@ -336,6 +546,10 @@ def main():
     ap.add_argument("--no-cpu-metric-size", action="store_true",
                     help="skip the one CPU run at the metric's own size (about a minute of host time)")
     ap.add_argument("--no-sharded", action="store_true", help="skip the config 3 / config 5 runs behind the timed region")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the device timings of BASELINE configs 2 and 4 and of the LML gradient behind the timed region")
+    ap.add_argument("--no-cpu-configs", action="store_true",
+                    help="skip the CPU oracle at the sizes of BASELINE configs 2-5 (about two minutes of host time)")
     args = ap.parse_args()
 
     if "RANK" not in os.environ and args.gpus > 1:
@@ -355,7 +569,8 @@ def main():
     # the rendezvous must outlive the RCCL bootstrap watchdog below: a rank whose bootstrap returned at once waits in
     # allgather_obj for the ranks still inside th.join
     rccl_timeout = float(os.environ.get("GPMI_BENCH_RCCL_TIMEOUT", "120"))
-    rdv = sharding.FileRendezvous(rank, world, timeout=rccl_timeout + 90.0) if world > 1 else None
+    # (two watchdog waits at most: the bootstrap and the start-up broadcast)
+    rdv = sharding.FileRendezvous(rank, world, timeout=2 * rccl_timeout + 90.0) if world > 1 else None
     try:
         run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, local_rank, rdv)
     finally:
@@ -392,6 +607,7 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
         import threading
 
         box = {}
+        rccl_limit = float(os.environ.get("GPMI_BENCH_RCCL_TIMEOUT", "120"))
 
         def bootstrap():
             try:
@@ -405,13 +621,17 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
         # while one rank is refused at once another can sit in the bootstrap waiting for it until the watchdog fires
         import socket
 
-        where = rdv.allgather_obj(f"{socket.gethostname()}:{dev_index}")
+        # (a physical identity: with one HIP_VISIBLE_DEVICES mask per rank every rank's device has index 0)
+        ident = _lib.device_identity(dev_index) or (
+            f"index {dev_index} under HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')} "
+            f"ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')}")
+        where = rdv.allgather_obj(f"{socket.gethostname()}:{ident}")
         if len(set(where)) < world:
             ok, why = False, "ranks share a device (RCCL refuses duplicate devices)"
         else:
             th = threading.Thread(target=bootstrap, daemon=True)
             th.start()
-            th.join(float(os.environ.get("GPMI_BENCH_RCCL_TIMEOUT", "120")))  # < the rendezvous' own time limit (main)
+            th.join(rccl_limit)  # < the rendezvous' own time limit (main)
             if th.is_alive():
                 STUCK.append(True)
                 ok, why = False, "RCCL bootstrap did not return within the time limit"
@@ -422,15 +642,30 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
         gather = "rccl" if all(oks) else f"file-fallback ({'; '.join(str(o) for o in oks)}{'' if ok else ' ' + why})"
         if gather == "rccl":
             # the start-up distribution of SURVEY section 8(e) on the live communicator: rank 0's data set to every rank by
-            # ncclBroadcast, compared with the copy each rank generated itself; and the rank count RCCL itself reports
-            try:
-                RCCL_INFO["rccl_ranks_seen"] = eng.comm_count()
-                bx, by, be = sharding.broadcast_dataset(x, y, e, comm=eng) if rank == 0 else sharding.broadcast_dataset(comm=eng)
-                same = bool(np.array_equal(bx, x) and np.array_equal(by, y) and np.array_equal(be, e))
-                RCCL_INFO["dataset_broadcast"] = "ncclBroadcast from rank 0: " + (
-                    "identical to the locally generated copy" if same else "DIFFERS from the locally generated copy")
-            except Exception as err:
-                RCCL_INFO["dataset_broadcast"] = f"failed: {type(err).__name__}: {err}"
+            # ncclBroadcast, compared with the copy each rank generated itself; and the rank count RCCL itself reports.
+            # Under the same watchdog as the bootstrap: a rank that raises before it enters the collective would leave the
+            # others inside hipStreamSynchronize for ever
+            def startup():
+                try:
+                    RCCL_INFO["rccl_ranks_seen"] = eng.comm_count()
+                    bx, by, be = sharding.broadcast_dataset(x, y, e, comm=eng) if rank == 0 else sharding.broadcast_dataset(comm=eng)
+                    same = bool(np.array_equal(bx, x) and np.array_equal(by, y) and np.array_equal(be, e))
+                    RCCL_INFO["dataset_broadcast"] = "ncclBroadcast from rank 0: " + (
+                        "identical to the locally generated copy" if same else "DIFFERS from the locally generated copy")
+                except Exception as err:
+                    RCCL_INFO["dataset_broadcast"] = f"failed: {type(err).__name__}: {err}"
+
+            th = threading.Thread(target=startup, daemon=True)
+            th.start()
+            th.join(rccl_limit)
+            alive = th.is_alive()
+            if alive:
+                STUCK.append(True)
+                RCCL_INFO["dataset_broadcast"] = "did not return within the time limit"
+            # a rank whose collective never returned takes every rank off the communicator
+            if any(rdv.allgather_obj(alive)):
+                gather = "file-fallback (the start-up broadcast over RCCL did not return on every rank)"
+            RCCL_INFO["rccl_ranks_match"] = RCCL_INFO.get("rccl_ranks_seen") == world
 
     def allgather(vec):
         if gather == "rccl":
@@ -521,6 +756,10 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                 "pct_fp64_mfma_peak_whole_step": 100.0 * value / world / 1e3 / PEAK_FP64_MFMA_TFLOPS,
                 "parallelism": f"{world} independent hyper-parameter evaluations (one per GPU), result all-gather: {gather}",
                 "gathered_values": int(np.size(res)),  # steps x 4 per rank, all ranks' in ONE collective inside the timed region
+                # (schema note: until round 3 the ranks met in one all-gather PER STEP; multi-rank values of r03 and earlier
+                # paid a wait for the slowest rank - and a file round trip on the fallback - every step and are not comparable)
+                "gather_schedule": "once_at_end",
+                **({"rank_cpu": RANK_CPU} if RANK_CPU else {}),
                 **RCCL_INFO,
             },
             "roofline": {
@@ -590,10 +829,32 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
             line["sharded"] = sharded
         if world == 1:
             line["roofline"]["kernels"] = kernel_rows(eng, step, _lib, N, M)
+        if world == 1 and not args.no_configs:
+            try:
+                line["configs"] = device_configs(wl, dev_index, gp, theta, N)
+            except Exception as err:  # the headline line must not be lost to a failure behind the timed region
+                line["configs"] = {"error": f"{type(err).__name__}: {err}"}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(4096, d, 256)  # ~10-15 s of host work in all
-            if not args.no_cpu_metric_size:
-                line["cpu_baseline"]["at_metric_size"] = cpu_at_metric_size(N, d, M)
+            # the bounded N = 4096 sample first: it also warms the BLAS pool for the run at the metric's own size, whose
+            # figure is the one `value` carries (round 5; until round 4 `value` was the sample's)
+            sample = cpu_baseline(4096, d, 256)  # ~10-15 s of host work in all
+            if args.no_cpu_metric_size:
+                line["cpu_baseline"] = sample
+            else:
+                full = cpu_at_metric_size(N, d, M)
+                line["cpu_baseline"] = {
+                    "value": full["value"], "unit": "GFLOP/s", "cores": sample["cores"], "kind": "port",
+                    "sample": full["sample"] + "; " + sample["sample"].split("; ", 1)[-1],
+                    "seconds": full["seconds"], "potrf_gflops": full["potrf_gflops"],
+                    "gpu_over_cpu": value / full["value"],
+                    "sample_n4096": {k: sample[k] for k in ("value", "unit", "sample")},
+                    "faithful": sample["faithful"],
+                }
+            if not args.no_cpu_configs:
+                try:
+                    line["cpu_baseline"]["configs"] = cpu_configs(wl, d)
+                except Exception as err:
+                    line["cpu_baseline"]["configs"] = {"error": f"{type(err).__name__}: {err}"}
         print(json.dumps(line), flush=True)
 
 

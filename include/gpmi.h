@@ -52,6 +52,10 @@ typedef struct gpmi_ctx gpmi_ctx;
 int gpmi_version(void);
 /* number of visible HIP devices (does not create a context) */
 int gpmi_device_count(int* count);
+/* PCI bus id ("0000:c1:00.0") of visible device `device` into buf (cap >= 16 bytes, NUL-terminated): a physical identity
+ * that does not depend on HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES, used by the sharded drivers to tell whether two
+ * ranks share a device (no reference counterpart: regression.py:597-601 farms its work over CPU processes) */
+int gpmi_device_pci_bus_id(int device, char* buf, int cap);
 /* create a handle bound to `device` (own stream + workspaces) */
 int gpmi_create(int device, gpmi_ctx** ctx);
 int gpmi_destroy(gpmi_ctx* ctx);

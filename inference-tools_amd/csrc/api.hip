@@ -543,6 +543,18 @@ int gpmi_device_count(int* count) {
   return GPMI_OK;
 }
 
+int gpmi_device_pci_bus_id(int device, char* buf, int cap) {
+  if (!buf || cap < 16) return GPMI_ERR_ARG;
+  buf[0] = 0;
+  if (hipDeviceGetPCIBusId(buf, cap, device) != hipSuccess) {
+    (void)hipGetLastError();
+    buf[0] = 0;
+    return GPMI_ERR_NODEVICE;
+  }
+  buf[cap - 1] = 0;
+  return GPMI_OK;
+}
+
 int gpmi_create(int device, gpmi_ctx** out) {
   if (!out) return GPMI_ERR_ARG;
   *out = nullptr;

@@ -42,6 +42,7 @@ _i64 = C.c_int64
 SIGNATURES = {
     "gpmi_version": (C.c_int, []),
     "gpmi_device_count": (C.c_int, [_ip]),
+    "gpmi_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "gpmi_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "gpmi_destroy": (C.c_int, [_vp]),
     "gpmi_last_error": (C.c_char_p, [_vp]),
@@ -141,6 +142,14 @@ def device_count() -> int:
     cnt = C.c_int(0)
     load().gpmi_device_count(C.byref(cnt))
     return cnt.value
+
+
+def device_identity(device: int) -> str:
+    """Physical identity of visible device `device`: its PCI bus id, which - unlike the index - does not depend on the
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES mask of the process ("" if the runtime cannot tell)."""
+    buf = C.create_string_buffer(64)
+    rc = load().gpmi_device_pci_bus_id(int(device), buf, 64)
+    return buf.value.decode() if rc == 0 else ""
 
 
 def dptr(a):

@@ -624,7 +624,9 @@ class GpRegressor:
         thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
         if self._mix is not None and not self._generic and self._mix.n_kernels == 2 and self._het_slice is None:
             return self._mixture_gradient_batch(thetas)  # (round 4: gpmi_lml_grad_batch_mix)
-        if self._generic or self._mix is not None:  # more than two regions, or per-point noise on top: one at a time
+        # more than two regions, or per-point noise on top, or per-point noise beside a dense y_cov (gpmi_lml_grad_batch_noise
+        # carries diagonals only - the condition of _lockstep_search): one at a time
+        if self._generic or self._mix is not None or (self._het_slice is not None and self._y_cov is not None):
             res = [self.marginal_likelihood_gradient(t) for t in thetas]
             return np.array([r[0] for r in res]), np.array([r[1] for r in res])
         th = np.array([np.ascontiguousarray(t[self.cov_slice][self._stat_slice]) for t in thetas])

@@ -89,6 +89,9 @@ def broadcast_dataset(x=None, y=None, y_err=None, comm=None, src: int = 0):
     communicator spans the job - is given, else over the bootstrap channel.  The other ranks pass nothing.  y_err may be
     None on the source (it then is None everywhere)."""
     rank, size = world()
+    if not 0 <= src < size:
+        raise ValueError(f"broadcast_dataset: source rank {src} is not a rank of this job (world size {size})")
+    err = None
     if rank == src:
         x = np.ascontiguousarray(x, dtype=np.float64)
         if x.ndim == 1:
@@ -99,7 +102,12 @@ def broadcast_dataset(x=None, y=None, y_err=None, comm=None, src: int = 0):
             raise ValueError("broadcast_dataset: x, y, y_err disagree in length")
     if size == 1:
         return x, y, err
-    if comm is not None and getattr(comm, "comm_world", 0) == size:
+    if comm is not None and getattr(comm, "comm_world", 0) != size:
+        # ranks that disagree about the channel would dead-lock, one inside ncclBroadcast and one in the bootstrap
+        # broadcast: a communicator that does not span the job is an error, never a silent fall-back
+        raise ValueError(f"broadcast_dataset: the communicator spans {getattr(comm, 'comm_world', 0)} rank(s), the job "
+                         f"{size}; pass comm=None on EVERY rank to use the bootstrap channel")
+    if comm is not None:
         head = np.array([x.shape[0], x.shape[1], 0.0 if err is None else 1.0]) if rank == src else np.zeros(3)
         n, d, has_err = (int(v) for v in comm.comm_broadcast(head, src))
         flat = np.zeros(n * (d + 1 + has_err))

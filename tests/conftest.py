@@ -15,6 +15,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_report_header(config):
+    """Which native library the suite runs against: GPMI_LIB lets an environment variable put another build of libgpmi.so
+    under the tests (A/B timing of kernel variants) - the header says which file was loaded, and its version."""
+    try:
+        from inference_amd import _lib
+
+        path = _lib.LIB_PATH
+        if not os.path.exists(path):
+            return f"libgpmi: {path} (NOT BUILT)"
+        return (f"libgpmi: {path} (gpmi_version {_lib.load().gpmi_version()}"
+                f"{', selected by GPMI_LIB' if os.environ.get('GPMI_LIB') else ''})")
+    except Exception as err:  # the header must never break a run
+        return f"libgpmi: not loadable here ({type(err).__name__}: {err})"
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

@@ -39,6 +39,11 @@ Cases
              element-wise operations in the same order, the same numpy.linalg.cholesky / solve_triangular - which
              tests/test_oracle_golden.py pins to the imported reference up to N = 8192 (K bit-exact).  The script
              first re-checks that pin at N = 2048 with these very code paths before it writes anything.
+  gradpin    the reference's LML / LOO gradients at SE N=2048 d=8 and RQ N=1536 d=16: pins of the oracle's
+             one-matrix-at-a-time gradients
+  cfg2g      BASELINE config 2 (SE, N=8192, d=8): the reference's LML gradient (2 thetas), LOO value, gradient and
+             predictions (~20 GB RSS)
+  head16kg   SE, N=16384, d=8: LML gradient (2 thetas) and LOO gradient from the oracle's one-matrix-at-a-time forms
   cfg3_16k   BASELINE config 3 at full size: RQ, N=16384, d=16, 8 thetas of the 64-point grid (one GPU's share of
              the 8-GPU sweep: grid rows 0, 9, 18, ... 63): LML and logdet each; alpha / predict at the first
 """
@@ -782,6 +787,73 @@ def case_cfg3_16k():
     return out
 
 
+def case_gradpin():
+    """The imported reference's LML and LOO gradients (regression.py:489-526,544-567) at sizes between the 32-point test
+    set and config 2 - SE N = 2048 d = 8, RQ N = 1536 d = 16, at the second theta of theta_set - which pin the oracle's
+    one-matrix-at-a-time gradients (tests/test_oracle_golden.py) before head16kg relies on them."""
+    out = {}
+    for tag, cfg, kid, n, d in (("se", 2, wl.SE, 2048, 8), ("rq", 3, wl.RQ, 1536, 16)):
+        x, y, e = wl.synthetic_dataset(cfg, n, d)
+        t = wl.theta_set(kid, y, d, 2)[1]
+        gp = GpRegressor(x, y, y_err=e, hyperpars=t, kernel=kernel_cls(kid))
+        out[tag + "_theta"] = t
+        out[tag + "_lml_g_val"], out[tag + "_lml_g_grad"] = gp.marginal_likelihood_gradient(t)
+        out[tag + "_loo_g_val"], out[tag + "_loo_g_grad"] = gp.loo_likelihood_gradient(t)
+    return out
+
+
+def case_cfg2g():
+    """BASELINE config 2 (SE, N = 8192, d = 8): the imported reference's LML gradient at two thetas and its LOO value and
+    gradient at one (regression.py:468-526,544-567) - the sizes above 4096 take a different chain of device kernels
+    (one lane, k-skipped SYRK, L^-T by TRSM), and the round-4 timings of the gradient are quoted there."""
+    out = {}
+    x, y, e = wl.synthetic_dataset(2, 8192, 8)
+    thetas = wl.theta_set(wl.SE, y, 8, 2)
+    gp = GpRegressor(x, y, y_err=e, hyperpars=thetas[0], kernel=SquaredExponential)
+    res = [gp.marginal_likelihood_gradient(t) for t in thetas]
+    out["thetas"] = thetas
+    out["lml_g_val"] = np.array([r[0] for r in res])
+    out["lml_g_grad"] = np.array([r[1] for r in res])
+    out["loo"] = np.array([gp.loo_likelihood(thetas[1])])
+    v, g = gp.loo_likelihood_gradient(thetas[1])
+    out["loo_g_val"], out["loo_g_grad"] = np.array([v]), np.array([g])
+    lm, ls = gp.loo_predictions()
+    ii = idx64(8192)
+    out["loo_idx"], out["loo_mu_sub"], out["loo_sig_sub"] = ii, lm[ii], ls[ii]
+    out["meta"] = np.array([2, wl.SE, 8192, 8])
+    return out
+
+
+def case_head16kg():
+    """The metric's own size (SE, N = 16384, d = 8): LML gradient at two thetas, LOO value and gradient at one, from the
+    oracle's one-matrix-at-a-time forms (the reference's list of d + 1 gradient matrices is 19 GB there, beside 34 GB of
+    difference tensors), which tests/test_oracle_golden.py pins to the imported reference at N = 32 ... 2048 and which
+    this script re-checks against the reference at N = 2048 / 1536 (case gradpin) before writing anything."""
+    from oracle import gp_oracle as orc
+
+    pin = case_gradpin()
+    for tag, cfg, kid, n, d in (("se", 2, wl.SE, 2048, 8), ("rq", 3, wl.RQ, 1536, 16)):
+        x, y, e = wl.synthetic_dataset(cfg, n, d)
+        o = orc.OracleGp(x, y, e, kernel=kid)
+        for nm, fn in (("lml", o.marginal_likelihood_gradient_lean), ("loo", o.loo_likelihood_gradient_lean)):
+            v, g = fn(pin[tag + "_theta"])
+            assert abs(v - pin[f"{tag}_{nm}_g_val"]) <= 1e-11 * abs(pin[f"{tag}_{nm}_g_val"])
+            assert np.abs(g - pin[f"{tag}_{nm}_g_grad"]).max() <= 1e-10 * np.abs(pin[f"{tag}_{nm}_g_grad"]).max()
+    out = {}
+    n, d = 16384, 8
+    x, y, e = wl.synthetic_dataset(2, n, d)
+    thetas = wl.theta_set(wl.SE, y, d, 2)
+    o = orc.OracleGp(x, y, e, kernel=orc.SE)
+    res = [o.marginal_likelihood_gradient_lean(t) for t in thetas]
+    out["thetas"] = thetas
+    out["lml_g_val"] = np.array([r[0] for r in res])
+    out["lml_g_grad"] = np.array([r[1] for r in res])
+    v, g = o.loo_likelihood_gradient_lean(thetas[1])
+    out["loo_g_val"], out["loo_g_grad"] = np.array([v]), np.array([g])
+    out["meta"] = np.array([2, wl.SE, n, d])
+    return out
+
+
 IDX_TOMO = np.arange(0, 400, 7)  # 58 rows / columns of the 400 x 400 posterior covariance
 
 CASES = {
@@ -801,6 +873,9 @@ CASES = {
     "cfg2": case_cfg2,
     "fail": case_fail,
     "head16k": case_head16k,
+    "gradpin": case_gradpin,
+    "cfg2g": case_cfg2g,
+    "head16kg": case_head16kg,
     "cfg3_16k": case_cfg3_16k,
 }
 

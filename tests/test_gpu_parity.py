@@ -658,6 +658,103 @@ def test_two_ranks_on_one_device(tmp_path):
             assert np.array_equal(got[k], ref[k]), (r, k)
 
 
+@pytest.mark.parametrize("case,n", [("cfg2g", 8192), ("head16kg", 16384)])
+def test_gradients_above_4096_vs_reference(golden, gp_mod, case, n):
+    """The LML and LOO gradients at the sizes their timings are quoted for.  Above N = 4096 they take a chain of kernels of
+    their own (one lane, L^-T by TRSM on the identity, the k-skipped SYRK, the fused trace pass: api_regression.hip), which
+    until round 4 was only checked to N = 6500.  cfg2g = the imported reference at BASELINE config 2's size (N = 8192,
+    regression.py:468-526,544-567); head16kg = the metric's own size, from the oracle's one-matrix-at-a-time gradients,
+    themselves pinned to the reference in tests/test_oracle_golden.py (N = 32 ... 2048)."""
+    g = golden(case)
+    d = 8
+    x, y, e = wl.synthetic_dataset(2, n, d)
+    th = g["thetas"]
+    assert np.array_equal(th, wl.theta_set(wl.SE, y, d, 2))
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=th[0])
+    for t, val, ref in zip(th, g["lml_g_val"], g["lml_g_grad"]):
+        v, gr = gp.marginal_likelihood_gradient(t)
+        check(v, val, what=f"lml (gradient path), N = {n}")
+        check_each(gr, ref, what=f"lml gradient, N = {n}")
+    v, gr = gp.loo_likelihood_gradient(th[1])
+    check(v, g["loo_g_val"][0], what=f"loo (gradient path), N = {n}")
+    check_each(gr, g["loo_g_grad"][0], what=f"loo gradient, N = {n}")
+    if "loo" in g:
+        check(gp.loo_likelihood(th[1]), g["loo"][0], what=f"loo likelihood, N = {n}")
+        lm, ls = gp.loo_predictions()  # at the fitted th[0]
+        check(lm[g["loo_idx"]], g["loo_mu_sub"], what=f"loo means, N = {n}")
+        check(ls[g["loo_idx"]], g["loo_sig_sub"], what=f"loo sigmas, N = {n}")
+
+
+def test_size_32768_identities(gp_mod):
+    """One size above the metric's: SE, N = 32768, d = 8 (8.6 GB per matrix; the reference has no limit but RAM,
+    regression.py:241).  Proves tile indices, workspaces and the flag-ordered tail's hand-over past N = 16384 through
+    identities whose right-hand sides are formed on the host from the oracle's kernel function, without downloading L:
+    (i) rows of K alpha = y - mu (2048 rows: the first and last 512 and 1024 drawn at random); (ii) the LML of a second,
+    independent evaluation against -1/2 r.alpha - log det of the fit; (iii) mean and variance at training inputs,
+    mu*(x_i) = y_i - D_ii alpha_i and var*(x_i) = D_ii - D_ii^2 (K^-1)_ii with (K^-1)_ii from the leave-one-out path."""
+    from oracle import gp_oracle as orc
+
+    n, d = 32768, 8
+    x, y, e = wl.synthetic_dataset(2, n, d)
+    th = wl.timing_theta(wl.SE, y, d)
+    gp = gp_mod.GpRegressor(x, y, y_err=e, hyperpars=th)
+    alpha = gp.alpha.copy()
+    assert np.isfinite(alpha).all()
+    r = y - th[0]
+    a2 = np.exp(2.0 * th[1])
+    D = e**2 + 1e-12 * a2
+    rows = np.unique(np.concatenate([np.arange(512), np.arange(n - 512, n),
+                                     np.random.default_rng(8).choice(n, 1024, replace=False)]))
+    Ka = np.empty(rows.size)
+    for lo in range(0, rows.size, 256):
+        sel = rows[lo:lo + 256]
+        blk = orc.kernel_cross(orc.SE, x[sel], x, th[1:])
+        blk[np.arange(sel.size), sel] += D[sel]
+        Ka[lo:lo + 256] = (blk * alpha[None, :]).sum(axis=1)
+    check(Ka, r[rows], 1e-10, "K alpha = y - mu at N = 32768 (2048 rows)")
+    lml = gp.marginal_likelihood(th)
+    ident = -0.5 * float((r * alpha).sum()) - gp._logdet
+    assert abs(lml - ident) <= 1e-10 * abs(lml), (lml, ident)
+    _record("LML identity at N = 32768", abs(lml - ident) / abs(lml), 1e-10)
+    idx = np.random.default_rng(9).choice(n, 256, replace=False)
+    mu, sig = gp(x[idx])
+    check(mu, y[idx] - D[idx] * alpha[idx], 1e-10, "mean at training inputs, N = 32768")
+    _, loo_sig = gp.loo_predictions()
+    var_expected = D[idx] - D[idx] ** 2 / loo_sig[idx] ** 2
+    assert np.abs(sig**2 - var_expected).max() <= 1e-10 * a2
+    gp.engine.close()
+
+
+def test_bench_eight_ranks_on_one_device(tmp_path):
+    """The driver's 8-GPU command on the hardware there is: `bench.py --gpus 8` with all eight ranks on ONE device
+    (reduced sizes).  The ranks must agree that they share a device (physical identity, not the visible index), skip
+    RCCL, gather through the rendezvous files, report both sharded configurations, and leave no rendezvous directory."""
+    import glob
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env.update(BENCH_CFG3_POINTS="8", BENCH_CFG5_LADDERS="8", BENCH_CFG5_STEPS="4", BENCH_CFG3_N="4096",
+               GPMI_RDV_DIR=str(tmp_path), MASTER_PORT="29533")
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                          "--n", "4096", "--m", "256"], env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["steps"] == 2
+    par = line["config"]["parallelism"]
+    assert "file-fallback" in par and "share a device" in par, par
+    assert "rccl_ranks_seen" not in line["config"]  # nobody claims a communicator that was never made
+    assert line["config"]["gather_schedule"] == "once_at_end"
+    assert line["config"]["rank_cpu"]["cores_per_rank"] >= 1
+    sh = line["sharded"]
+    assert "error" not in sh and sh["config3"]["lml_evals_per_s"] > 0 and sh["config5"]["lml_evals_per_s"] > 0, sh
+    assert np.isfinite(line["value"]) and line["value"] > 0
+    assert glob.glob(str(tmp_path / "*")) == [], "the rendezvous directory is removed at the end"
+
+
 # ---------------------------------------------------------------------------------------
 # BASELINE.json's full sizes: the oracle needs minutes there, so the checks are identities
 # that hold at any size, with every right-hand side formed on the host from the oracle's kernels

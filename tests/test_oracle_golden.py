@@ -54,6 +54,46 @@ def test_t32_all_methods(golden, name, kid):
     close([r[1] for r in res], g[name + "loo_g_grad"], rtol=1e-10)
 
 
+@pytest.mark.parametrize("name,kid", [("se_", orc.SE), ("rq_", orc.RQ)])
+def test_lean_gradients_equal_the_reference(golden, name, kid):
+    """The one-matrix-at-a-time gradients (the forms make_golden.py runs at N = 16384, where the reference's list of
+    gradient matrices does not fit) against the imported reference's regression.py:489-526,544-567."""
+    g = golden("t32")
+    th = g[name + "thetas"]
+    gp = orc.OracleGp(g["x"], g["y"], g["y_err"], kernel=kid, hyperpars=th[0])
+    res = [gp.marginal_likelihood_gradient_lean(t) for t in th]
+    close([r[0] for r in res], g[name + "lml_g_val"])
+    close([r[1] for r in res], g[name + "lml_g_grad"], rtol=1e-10)
+    res = [gp.loo_likelihood_gradient_lean(t) for t in th]
+    close([r[0] for r in res], g[name + "loo_g_val"])
+    close([r[1] for r in res], g[name + "loo_g_grad"], rtol=1e-10)
+    # and bit for bit the oracle's list-of-matrices form of the LML gradient (same expressions, same sums)
+    for t in th[:2]:
+        a, b = gp.marginal_likelihood_gradient(t), gp.marginal_likelihood_gradient_lean(t)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1])
+
+
+def test_lean_gradients_white_noise_and_mid_size(golden):
+    g = golden("t32")
+    th = g["sewn_theta"]
+    gp = orc.OracleGp(g["x"], g["y"], g["y_err"], kernel=orc.SE, hyperpars=th, white_noise=True)
+    v, gr = gp.marginal_likelihood_gradient_lean(th)
+    close(v, g["sewn_lml_g_val"])
+    close(gr, g["sewn_lml_g_grad"], rtol=1e-10)
+    # the reference at N = 1536 (RQ, d = 16) and N = 2048 (SE, d = 8): tests/golden/make_golden.py gradpin
+    g = golden("gradpin")
+    for tag, cfg, kid, n, d in (("se", 2, orc.SE, 2048, 8), ("rq", 3, orc.RQ, 1536, 16)):
+        x, y, e = wl.synthetic_dataset(cfg, n, d)
+        t = g[tag + "_theta"]
+        gp = orc.OracleGp(x, y, e, kernel=kid)
+        v, gr = gp.marginal_likelihood_gradient_lean(t)
+        close(v, g[tag + "_lml_g_val"])
+        close(gr, g[tag + "_lml_g_grad"], rtol=1e-10)
+        v, gr = gp.loo_likelihood_gradient_lean(t)
+        close(v, g[tag + "_loo_g_val"])
+        close(gr, g[tag + "_loo_g_grad"], rtol=1e-10)
+
+
 def test_t32_spatial_gradients_and_acquisition(golden):
     g = golden("t32")
     gp = orc.OracleGp(g["x"], g["y"], g["y_err"], kernel=orc.SE, hyperpars=g["se_thetas"][0])
