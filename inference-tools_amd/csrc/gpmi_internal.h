@@ -303,6 +303,7 @@ hipStream_t potrf_first_update_stream(gpmi_ctx* c, Lane& lane, int64_t np, bool 
 void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0,
                        unsigned long long* dbg = nullptr, const BatchShape& bs = BatchShape(), int* pub = nullptr,
                        int pub_val = 0);
+void launch_potrf_diag_fault(hipStream_t s, double* Ablk, int64_t ld, const BatchShape& bs = BatchShape());  // test hook
 // batched, in-order factorisation of bs.count matrices (small problems: no look-ahead)
 void potrf_lower_batched(gpmi_ctx* c, hipStream_t s, double* A, int64_t np, int64_t ld, double* invD,
                          int* info, const BatchShape& bs);

@@ -50,6 +50,7 @@
 #include <vector>
 
 #include "gemm_tiles.h"
+#include "potrf_diag.h"
 
 using namespace gemm_tiles;
 
@@ -74,7 +75,9 @@ struct FlowTask {
 static_assert(sizeof(FlowTask) == 12, "FlowTask layout");
 
 // hot words on lines of their own
-constexpr int FL_DDONE = 0, FL_ABORT = 32, FL_T0 = 48, FL_STATS = 64, FL_ROWCNT = 96, FL_LCNT = 128;  // FL_ROWCNT: 8 words (chain_fused_kernel)
+// FL_ROWCNT: 8 words (chain_fused_kernel, chain_column_kernel); FL_INVROW: 8 words on lines of their own (row blocks of
+// the current inverse diagonal block, chain_column_kernel)
+constexpr int FL_DDONE = 0, FL_ABORT = 32, FL_T0 = 48, FL_STATS = 64, FL_ROWCNT = 96, FL_INVROW = 128, FL_LCNT = 384;
 __host__ __device__ inline int flow_f_off(int m) { return FL_LCNT + ((m + 31) / 32) * 32; }
 __host__ __device__ inline int flow_owner_off(int m) { return flow_f_off(m) + ((m * m + 31) / 32) * 32; }  // one word per list
 inline int flow_flag_ints(int m, int nwg) { return flow_owner_off(m) + nwg; }
@@ -364,6 +367,240 @@ __global__ __launch_bounds__(512) void chain_fused_kernel(ChainFusedArgs g) {
     double* o = g.T + (int64_t)(16 * (st ? r1 : r0) + fk) * g.ld + 16 * cb + fr;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[(int64_t)4 * r * g.ld] = xs[4 * r * CF_PITCH];
+  }
+}
+
+// ---- D(k), Tc(k) and Uc(k) in ONE launch (round 5, GPMI_CHAIN_TILES=3, the default) ---------------------------------------
+// Until round 4 a column of the chain was potrf_diag, a kernel boundary, and the fused Tc / Uc launch, which could not start
+// before the whole inverse of the diagonal block existed: 18.5 + 2 + 13 us.  But row block c of the inverse is final after
+// step c of potrf_diag's eight (the inverse is built right-looking), column block c of X = T invD^T needs row block c of the
+// inverse only (X_c = sum_{s <= c} T_s invD[c][s]^T), and the update C -= X X^T takes the column blocks of X in order.
+// So the two products run BESIDE potrf_diag, one row block behind it:
+//   workgroup 0      potrf_diag (potrf_diag.h, PUB build): every byte of the inverse stored write-through, row block r
+//                    counted in at flags[FL_INVROW + 32 r] by the four inverse waves once their stores are acknowledged
+//   workgroups 1..28 the 36 lower 16 x 16 tiles of the update: 24 off-diagonal tiles, one per workgroup (two strips of X
+//                    each), and 4 workgroups with the tiles (2p, 2p), (2p+1, 2p+1), (2p+1, 2p) (the same two strips).
+//                    T and C are fetched at the start (under potrf_diag); wave c computes column block c of strip 0 when
+//                    row block c arrives and column block 7 - c of strip 1 when row block 7 - c does; the tile waves add
+//                    -X_c X_c^T for c = 0, 1, ... as the blocks land in LDS (per-block LDS counters, no workgroup barrier
+//                    after the prologue).  The four pair workgroups also store X over T (strips 2p, 2p + 1) once every
+//                    reader of those rows has them (FL_ROWCNT, seven readers per strip).
+// Behind potrf_diag's last elimination there is left: the last row block of the inverse (one MFMA chain of 4 + its stores'
+// acknowledgement), the hand-off, 32 MFMAs of the last column block, 4 of the update, the C store: ~6 us instead of 15.
+// Same sums in the same order as chain_trsm_kernel / chain_syrk_kernel, i.e. as the generic tile bodies: bit-identical.
+// Deadlock-free with any number of resident workgroups: workgroup 0 is dispatched first and waits for nobody in the
+// launch; the others wait for workgroup 0 and - the pair workgroups, dispatched last - for workgroups before them.
+struct ChainColArgs {
+  double* Akk;          // tile (k, k); T = tile (k+1, k) and C = tile (k+1, k+1) follow from ld
+  double* invD;         // inverse of diagonal block k
+  int64_t ld;
+  int* info;
+  int col0;
+  unsigned long long* dbg;  // potrf_diag's 24-word stamp slot (tools) or nullptr
+  int* pub;                 // published at the start: Lcnt[k] = pub_val (the strip the launch before stored); nullptr for k = 0
+  int pub_val;
+  int* flags;               // the factorisation's flag block (FL_*)
+  int k;                    // column of the tail
+  const int* wait1;         // tile (k+1, k) has taken the columns before k
+  const int* wait2;         // tile (k+1, k+1) likewise
+  int wait_val;
+  unsigned long long* wait_ticks;
+  unsigned long long* trace;  // 4 words (worker 0): launch start, flags seen, last MFMA, end
+};
+constexpr int CC_WORKERS = 28;
+constexpr int CC_READERS = 7;  // workgroups that load a strip of T: 6 off-diagonal tiles + the strip's pair workgroup
+
+__global__ __launch_bounds__(512) void chain_column_kernel(ChainColArgs g) {
+  __shared__ potrf_diag::DiagShared sh;
+  int* fl = g.flags;
+  if (blockIdx.x == 0) {
+    if (g.pub && threadIdx.x == 0) __hip_atomic_store(g.pub, g.pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    potrf_diag::DiagPub pub;
+    pub.rows = fl + FL_INVROW;
+    pub.base = potrf_diag::DIAG_INVERSE * g.k;
+    pub.ddone = fl + FL_DDONE;
+    pub.ddone_val = g.k + 1;
+    potrf_diag::potrf_diag_body<true>(g.Akk, g.ld, g.invD, g.info, g.col0, g.dbg, sh, pub);
+    return;
+  }
+  // ------------------------------------------------------------------------------------------------ a worker
+  const int w = (int)blockIdx.x - 1;
+  const int tid = threadIdx.x, lane = tid & 63, c = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const int fr = lane & 15, fk = lane >> 4;
+  double* Ts = sh.S;                            // [2][16 * CF_APITCH]  strips of T, row-major
+  double* Xs = sh.S + 2 * 16 * CF_APITCH;       // [2][16 * CF_PITCH]   strips of X, row-major
+  int* xs_cnt = reinterpret_cast<int*>(sh.Xl);  // [8] strips whose column block cb is in Xs (0 .. 2)
+  static_assert(2 * 16 * (CF_APITCH + CF_PITCH) <= potrf_diag::S_DOUBLES, "the worker's strips fit the block image");
+  double* T = g.Akk + (int64_t)NB * g.ld;
+  double* C = T + NB;
+  int* abortw = fl + FL_ABORT;
+  auto give_up = [&]() {
+    if (lane == 0) {
+      __hip_atomic_store(abortw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (g.info) atomicCAS(g.info, 0, GPMI_INFO_FLOW_TIMEOUT);
+    }
+  };
+  if (tid < 8) xs_cnt[tid] = 0;
+  if (g.trace && w == 0 && tid == 0) g.trace[0] = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0) {  // both tiles have taken the columns before k (normally long set; one round trip for the two)
+    int spins = 0;
+    unsigned long long t0 = 0;
+    if (g.wait_ticks) t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+      const int v1 = flow_ld(g.wait1), v2 = flow_ld(g.wait2);
+      if (v1 >= g.wait_val && v2 >= g.wait_val) break;
+      __builtin_amdgcn_s_sleep(4);
+      if ((++spins & 63) == 0 && flow_ld(abortw)) break;
+      if (spins > FLOW_SPIN_LIMIT) {
+        give_up();
+        break;
+      }
+    }
+    if (g.wait_ticks) atomicAdd(g.wait_ticks, __builtin_amdgcn_s_memrealtime() - t0);
+    if (g.trace && w == 0) g.trace[1] = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  // the two strips of this workgroup (rows 16 r0 .., 16 r1 ..) and its tiles
+  const bool pair = w >= 24;
+  int r0, r1;
+  if (pair) {
+    r0 = 2 * (w - 24);
+    r1 = r0 + 1;
+  } else {
+    // the 24 off-diagonal tiles (i, j), j < i, that no pair workgroup owns, row by row
+    int n = w, i = 1, j = 0;
+    for (;;) {
+      const bool pair_tile = (i & 1) && j == i - 1;
+      if (!pair_tile) {
+        if (n == 0) break;
+        --n;
+      }
+      if (++j == i) {
+        ++i;
+        j = 0;
+      }
+    }
+    r0 = i;
+    r1 = j;
+  }
+  r0 = __builtin_amdgcn_readfirstlane(r0);
+  r1 = __builtin_amdgcn_readfirstlane(r1);
+  // T: wave c fetches slab c (columns 16 c ..) of both strips, once per workgroup, and hands it on through LDS
+  const d4_t t0 = *reinterpret_cast<const d4_t*>(T + (int64_t)(16 * r0 + fr) * g.ld + 16 * c + 4 * fk);
+  const d4_t t1 = *reinterpret_cast<const d4_t*>(T + (int64_t)(16 * r1 + fr) * g.ld + 16 * c + 4 * fk);
+  // tile waves: 3 (off-diagonal tile (r0, r1); in a pair workgroup tile (r0, r0)), 4: (r1, r1), 5: (r1, r0) - waves whose own
+  // column blocks are in the middle of the sequence, so that nothing of theirs sits behind the last row block
+  const bool tile_wave = pair ? (c >= 3 && c <= 5) : c == 3;
+  int ti = r0, tj = r1;  // strips of the tile's A and B operand
+  if (pair) {
+    ti = c == 3 ? r0 : r1;
+    tj = c == 4 ? r1 : r0;
+  }
+  d4_t acc = {0.0, 0.0, 0.0, 0.0};
+  double* cp = C + (int64_t)(16 * ti + fk) * g.ld + 16 * tj + fr;
+  if (tile_wave) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = cp[(int64_t)4 * r * g.ld];
+  }
+  *reinterpret_cast<d4_t*>(&Ts[fr * CF_APITCH + 16 * c + 4 * fk]) = t0;
+  *reinterpret_cast<d4_t*>(&Ts[16 * CF_APITCH + fr * CF_APITCH + 16 * c + 4 * fk]) = t1;
+  __syncthreads();  // (every wave has its slab of T in registers and in LDS; the LDS counters are zero)
+  if (tid == 0) {
+    __hip_atomic_fetch_add(fl + FL_ROWCNT + r0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(fl + FL_ROWCNT + r1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const int row_target = potrf_diag::DIAG_INVERSE * (g.k + 1);
+  const int readers_target = CC_READERS * (g.k + 1);
+  const double* xa = Xs + (pair ? (ti == r0 ? 0 : 1) : 0) * 16 * CF_PITCH + fr * CF_PITCH + 2 * fk;
+  const double* xb = Xs + (pair ? (tj == r0 ? 0 : 1) : 1) * 16 * CF_PITCH + fr * CF_PITCH + 2 * fk;
+  bool readers_seen = false;
+#pragma unroll
+  for (int row = 0; row < NB / 16; ++row) {
+    // ---- this wave's column block of a strip, if row block `row` of the inverse is its operand
+    if (row == c || row == 7 - c) {
+      const int strip = row == c ? 0 : 1;
+      {
+        int spins = 0;
+        while (flow_ld(fl + FL_INVROW + 32 * row) < row_target) {
+          __builtin_amdgcn_s_sleep(2);
+          if ((++spins & 63) == 0 && flow_ld(abortw)) break;
+          if (spins > FLOW_SPIN_LIMIT) {
+            give_up();
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      const double* brow = g.invD + (int64_t)(16 * row + fr) * NB + 4 * fk;
+      d4_t b[NB / 16];
+#pragma unroll
+      for (int s = 0; s <= row; ++s) b[s] = *reinterpret_cast<const d4_t*>(brow + 16 * s);
+      // (chain_trsm_kernel's sums: k = 16 s + 4 fk + q at step q of slab s, slabs beyond the block skipped)
+      d4_t x = {0.0, 0.0, 0.0, 0.0};
+      const double* ts = Ts + strip * 16 * CF_APITCH + fr * CF_APITCH + 4 * fk;
+#pragma unroll
+      for (int s = 0; s <= row; ++s) {
+        const d4_t a = *reinterpret_cast<const d4_t*>(ts + 16 * s);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[s][q], x, 0, 0, 0);
+      }
+      // X block to LDS in row-major form (the D layout of the MFMA: lane (fr, fk) holds rows fk + 4 r of its column block)
+      double* xo = Xs + strip * 16 * CF_PITCH + fk * CF_PITCH + 16 * row + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xo[4 * r * CF_PITCH] = x[r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(xs_cnt + row, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (pair) {
+        // X in place of T, once nobody needs the strip's rows of T any more (long the case: T is fetched under potrf_diag)
+        if (!readers_seen) {
+          int spins = 0;
+          while (flow_ld(fl + FL_ROWCNT + r0) < readers_target || flow_ld(fl + FL_ROWCNT + r1) < readers_target) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 63) == 0 && flow_ld(abortw)) break;
+            if (spins > FLOW_SPIN_LIMIT) {
+              give_up();
+              break;
+            }
+          }
+          readers_seen = true;
+        }
+        double* o = T + (int64_t)(16 * (strip ? r1 : r0) + fk) * g.ld + 16 * row + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(int64_t)4 * r * g.ld] = x[r];
+      }
+    }
+    // ---- the tile waves: column block `row` of both strips (chain_syrk_kernel's sums: k = 8 st + 2 fk, + 1; A negated
+    // by the MFMA), as soon as the two blocks are in LDS
+    if (tile_wave) {
+      int polls = 0;
+      while (__hip_atomic_load(xs_cnt + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++polls & 1023) == 0 && flow_ld(abortw)) break;
+        if (polls > (1 << 24)) {
+          give_up();
+          break;
+        }
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int st = 2 * row; st < 2 * row + 2; ++st) {
+        const d2_t av = *reinterpret_cast<const d2_t*>(xa + 8 * st);
+        const d2_t bv = *reinterpret_cast<const d2_t*>(xb + 8 * st);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[h], bv[h], acc, 0, 0, 1);  // C - A B^T
+      }
+    }
+  }
+  if (tile_wave) {
+    if (g.trace && w == 0) g.trace[2] = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cp[(int64_t)4 * r * g.ld] = acc[r];
+    if (g.trace && w == 0 && lane == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      g.trace[3] = __builtin_amdgcn_s_memrealtime();
+    }
   }
 }
 
@@ -859,8 +1096,32 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
       double* invDk = invD0 + (int64_t)k * NB * NB;
       unsigned long long* ck = ctrace ? ctrace + (int64_t)k * (GPMI_STAMP_WORDS + 4) : nullptr;
       // GPMI_CHAIN_TILES=0: the generic kernels (32-row TRSM slabs, 64 x 64 update tiles) as until round 3; 1: the two
-      // 16 x 16-tile kernels; 2 (default): both products in one launch - same bits
-      static const int chain_mode = env_int("GPMI_CHAIN_TILES", 2);
+      // 16 x 16-tile kernels; 2: both products in one launch behind potrf_diag (round 4); 3 (default, round 5): potrf_diag
+      // and both products in ONE launch, the products one row block of the inverse behind the factorisation - same bits
+      static const int chain_mode = env_int("GPMI_CHAIN_TILES", 3);
+      if (chain_mode == 3) {
+        ChainColArgs ca{};
+        ca.Akk = Akk;
+        ca.invD = invDk;
+        ca.ld = ld;
+        ca.info = info;
+        ca.col0 = (t0 + k) * NB;
+        ca.dbg = ck;
+        ca.pub = k > 0 ? Lcnt + k : nullptr;  // (the strip X of column k - 1 was stored by the launch before this one)
+        ca.pub_val = 4 * k;
+        ca.flags = fl;
+        ca.k = k;
+        ca.wait1 = F + (k + 1) * m + k;
+        ca.wait2 = F + (k + 1) * m + (k + 1);
+        ca.wait_val = 4 * k;
+        ca.wait_ticks = stats ? stats + 4 : nullptr;
+        ca.trace = ck ? ck + GPMI_STAMP_WORDS : nullptr;
+        const bool has_next = k + 1 < m;
+        if (!has_next) ca.wait1 = ca.wait2 = nullptr;
+        hipLaunchKernelGGL(chain_column_kernel, dim3(has_next ? 1 + CC_WORKERS : 1), dim3(512), 0, sp, ca);
+        launch_potrf_diag_fault(sp, Akk, ld);
+        continue;
+      }
       // (fused: the strip X of column k - 1 was stored by the launch before this one; potrf_diag publishes it)
       const bool pub_here = chain_mode == 2 && k > 0;
       launch_potrf_diag(sp, Akk, ld, invDk, info, (t0 + k) * NB, ck, BatchShape(), pub_here ? Lcnt + k : nullptr, 4 * k);

@@ -30,6 +30,14 @@ for ty in range(4):
         continue
     print(f"  {names[ty]} tasks: {sel.sum()}  body {np.median(dur[sel]):.1f} us median, {dur[sel].mean():.1f} mean, {np.percentile(dur[sel], 95):.1f} p95;"
           f" publish {np.median((tt[sel, 3] - tt[sel, 2]) * 0.01):.2f} us")
+# the chain step: start of potrf_diag(k) to start of potrf_diag(k + 1); in the last third of the tail the chain never waits for
+# the task kernel, so the median there is the bare step (D + the two products behind it + launch boundaries)
+steps = np.array([(ct[k + 1, 0] - ct[k, 0]) * 0.01 for k in range(m - 1)])
+diag = np.array([(ct[k, 8] - ct[k, 0]) * 0.01 for k in range(m)])
+tail = slice(max(0, 2 * (m - 1) // 3), m - 1)
+print(f"  chain step (D(k) start -> D(k+1) start): median {np.median(steps):.1f} us over all {m - 1}, "
+      f"{np.median(steps[tail]):.1f} us median / {steps[tail].min():.1f} min over the last third; potrf_diag itself "
+      f"{np.median(diag):.1f} us median; behind potrf_diag's end to the next start {np.median(steps[tail] - diag[:-1][tail]):.1f} us")
 for k in range(k0, min(k0 + nk, m - 1)):
     d0, d1 = us(ct[k, 0]), us(ct[k, 8])
     tc0, tc1 = us(ct[k, 24]), us(ct[k, 25])

@@ -1,0 +1,450 @@
+"""Timing model of the flag-ordered tail AS SHIPPED (csrc/potrf_flow.hip: static in-order task lists per workgroup + the
+chain's one launch per column) and a test bench for list builders.  The device kernel runs whatever lists flow_build()
+hands it, so a schedule is a function  tasks -> (workgroup, position); this file prices such functions before they are
+ported to C++.
+
+  python tools/sim/flow_sched.py [m] [policy ...]      policies: shipped, heft
+"""
+import heapq
+import sys
+from collections import defaultdict
+
+OBT = 4
+
+
+def lazy_panels(i, j, near=4):
+    P = j // OBT
+    e = P - 1 if i < OBT * P + OBT + near else P
+    return max(e, 0)
+
+
+def build_tasks(m, near=4):
+    """The decomposition of potrf_flow.hip: flow_build (which tasks exist is fixed: bit-identity with the stream-ordered
+    factorisation).  Returns list of dicts."""
+    tasks = []
+    for k in range(m):
+        for i in range(k + 2, m):
+            for s in range(4):
+                tasks.append(dict(t="T", i=i, j=0, k=k, s=s, add=1))
+            for j in range(k + 1, i + 1):
+                if OBT * lazy_panels(i, j, near) > k:
+                    continue
+                for s in range(4):
+                    if i == j and s == 1:
+                        continue
+                    tasks.append(dict(t="U", i=i, j=j, k=k, s=s, add=2 if (i == j and s == 0) else 1))
+    for i in range(m):
+        for j in range(i + 1):
+            for q in range(lazy_panels(i, j, near)):
+                tasks.append(dict(t="Z", i=i, j=j, k=q, s=0, add=4 * OBT))
+    return tasks
+
+
+class Model:
+    """Durations in us (measured: profiles/r05 traces): single-column task bodies 7, hop (flag visible -> body starts) 1.8,
+    K = 512 chunk 125 with a busy neighbour on its CU / 76 alone, chain: potrf_diag 21.5, DDONE visible 0.5 after it, the
+    launch ends 6.5 after max(potrf_diag's end, the worker flags seen + 3), next launch 2.2 later."""
+    cT = 7.2
+    cU = 7.2
+    cZ2 = 124.0
+    cZ1 = 76.0
+    hop = 1.8
+    vis = 0.4
+    cD = 21.5
+    cTail = 6.5
+    cLoad = 3.0
+    cB = 2.2
+
+
+def simulate(m, lists, mod=Model, near=4, verbose=False):
+    """lists: list (per workgroup) of task dicts in execution order.  Workgroups b and b + len(lists)//2 share a CU."""
+    nw = len(lists)
+    half = nw // 2
+    Lcnt = [0] * m
+    F = [[0] * (m) for _ in range(m)]
+    DD = [0]
+    t = [0.0]
+    ev = []
+    seq = [0]
+
+    def at(time, fn, *a):
+        seq[0] += 1
+        heapq.heappush(ev, (time, seq[0], fn, a))
+
+    def ready(x):
+        ty, i, j, k = x["t"], x["i"], x["j"], x["k"]
+        if ty == "T":
+            return DD[0] >= k + 1 and F[i][k] == 4 * k
+        if ty == "U":
+            return Lcnt[i] >= 4 * (k + 1) and Lcnt[j] >= 4 * (k + 1) and F[i][j] >= 4 * k
+        return Lcnt[i] >= 4 * OBT * (k + 1) and Lcnt[j] >= 4 * OBT * (k + 1) and F[i][j] == 4 * OBT * k
+
+    pos = [0] * nw
+    busy = [False] * nw
+    zrun = [False] * nw
+    busy_us = [0.0]
+    stall = [0.0]
+    starts = {}
+
+    def try_wg(b):
+        if busy[b] or pos[b] >= len(lists[b]):
+            return
+        x = lists[b][pos[b]]
+        if not ready(x):
+            return
+        busy[b] = True
+        if x["t"] == "Z":
+            mate = (b + half) % nw
+            dur = mod.cZ2 if zrun[mate] else mod.cZ1
+            # (a chunk that starts beside a running one slows that one too; the model prices only the newcomer, and the
+            # mate's remaining time is stretched in proportion)
+            zrun[b] = True
+        else:
+            dur = mod.cT if x["t"] == "T" else mod.cU
+        starts[id(x)] = t[0] + mod.hop
+        busy_us[0] += dur
+        at(t[0] + mod.hop + dur, done, b, x)
+
+    def done(b, x):
+        busy[b] = False
+        zrun[b] = False
+        pos[b] += 1
+        at(t[0] + mod.vis, publish, x)
+        try_wg(b)
+
+    def publish(x):
+        if x["t"] == "T":
+            Lcnt[x["i"]] += x["add"]
+        else:
+            F[x["i"]][x["j"]] += x["add"]
+        wake()
+
+    # the chain: one launch per column
+    ch = dict(k=0, dend=None, waiting=False, t_launch=0.0, ends=[])
+
+    def launch(k):
+        ch["k"] = k
+        ch["t_launch"] = t[0]
+        if k > 0:
+            Lcnt[k] = 4 * k
+        ch["dend"] = t[0] + mod.cD
+        at(ch["dend"] + 0.5, ddone, k)
+        ch["waiting"] = True
+        wake()
+
+    def ddone(k):
+        DD[0] = k + 1
+        wake()
+
+    def chain_check():
+        if not ch["waiting"]:
+            return
+        k = ch["k"]
+        if k + 1 >= m:
+            ch["waiting"] = False
+            at(max(ch["dend"], t[0]) + 1.0, finish_launch, k)
+            return
+        if F[k + 1][k] >= 4 * k and F[k + 1][k + 1] >= 4 * k:
+            ch["waiting"] = False
+            flags_seen = t[0] + 1.0
+            end = max(ch["dend"], flags_seen + mod.cLoad) + mod.cTail
+            stall[0] += max(0.0, flags_seen + mod.cLoad - ch["dend"])
+            at(end, finish_launch, k)
+
+    def finish_launch(k):
+        ch["ends"].append(t[0])
+        if k + 1 < m:
+            F[k + 1][k + 1] = 4 * (k + 1)
+            at(t[0] + mod.cB, launch, k + 1)
+
+    def wake():
+        chain_check()
+        for b in range(nw):
+            try_wg(b)
+
+    at(0.0, launch, 0)
+    while ev:
+        t[0], _, fn, a = heapq.heappop(ev)
+        fn(*a)
+    left = sum(len(l) - p for l, p in zip(lists, pos))
+    assert left == 0 and len(ch["ends"]) == m, (left, len(ch["ends"]))
+    return dict(total=t[0], chain_end=ch["ends"][-1], stall=stall[0], util=busy_us[0] / (nw * t[0]), starts=starts,
+                col_ends=ch["ends"])
+
+
+# ---- list builders ----------------------------------------------------------------------------------------------------
+def shipped_lists(m, nwg=448, near_d=3, near_wgs=32, near=4):
+    """potrf_flow.hip: flow_build as of round 4."""
+    tasks = build_tasks(m, near)
+    nearl, rest, zt = [], [], []
+    for x in tasks:
+        if x["t"] == "T":
+            key = (4 * x["k"], x["i"], 0, x["s"])
+        elif x["t"] == "U":
+            key = (4 * x["k"] + 2, x["i"], x["j"], x["s"])
+        else:
+            key = (4 * (OBT * x["k"] + OBT - 1) + 1, x["i"], x["j"], 0)
+        x["key"] = key
+        if x["t"] == "Z":
+            zt.append(x)
+        elif x["i"] - x["k"] <= near_d:
+            nearl.append(x)
+        else:
+            rest.append(x)
+    nearl.sort(key=lambda x: x["key"])
+    rest.sort(key=lambda x: x["key"])
+    zt.sort(key=lambda x: x["key"])
+    nn = near_wgs if nwg > 2 * near_wgs else 0
+    lists = [[] for _ in range(nwg)]
+    if nn == 0:
+        rest = sorted(rest + nearl, key=lambda x: x["key"])
+        nearl = []
+    for n, x in enumerate(nearl):
+        lists[n % nn].append(x)
+    for n, x in enumerate(rest):
+        lists[nn + n % (nwg - nn)].append(x)
+    for n, x in enumerate(zt):
+        lists[nn + (n + len(rest)) % (nwg - nn)].append(x)
+    for l in lists:
+        l.sort(key=lambda x: x["key"])
+    return lists
+
+
+if __name__ == "__main__":
+    m = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+    lists = shipped_lists(m)
+    print("tasks", sum(len(l) for l in lists))
+    r = simulate(m, lists)
+    print(f"shipped: total {r['total']:.0f} us, chain stalls {r['stall']:.0f} us, workgroup utilisation {r['util']:.2f}")
+    ce = r["col_ends"]
+    print("panel periods:", [round(ce[k + 4] - ce[k]) for k in range(3, m - 4, 4)])
+
+
+# ---- dependency graph + list scheduling ("simulate, then freeze") ------------------------------------------------------
+def graph(m, tasks, near=4):
+    """preds[n] = list of task indices / ('L', k) chain launch starts / ('D', k) potrf_diag ends that task n waits for;
+    chain_preds[k] = tasks whose flags launch k's workers wait for."""
+    idx = {}
+    for n, x in enumerate(tasks):
+        idx[(x["t"], x["i"], x["j"], x["k"], x["s"])] = n
+
+    def subs(i, j, k):  # the sub-updates of column k on tile (i, j)
+        return [idx[("U", i, j, k, s)] for s in range(4) if not (i == j and s == 1)]
+
+    def tile_state(i, j, upto):
+        """tasks that bring tile (i, j) to 'all columns < upto applied' (only the last link of the per-tile sequence)"""
+        lz = lazy_panels(i, j, near)
+        if upto - 1 >= OBT * lz and upto >= 1 and ("U", i, j, upto - 1, 0) in idx:
+            return subs(i, j, upto - 1)
+        if lz > 0 and upto >= OBT * lz:
+            return [idx[("Z", i, j, lz - 1, 0)]]
+        return []
+
+    def row_col(i, k):  # L(i, k) final
+        if i >= k + 2:
+            return [idx[("T", i, 0, k, s)] for s in range(4)]
+        return [("L", k + 1)]  # i == k + 1: the chain's strip, published at the start of launch k + 1
+
+    preds = []
+    for x in tasks:
+        t, i, j, k = x["t"], x["i"], x["j"], x["k"]
+        if t == "T":
+            p = [("D", k)] + tile_state(i, k, k)
+        elif t == "U":
+            p = row_col(i, k) + row_col(j, k) + tile_state(i, j, k)
+        else:
+            p = row_col(i, OBT * k + OBT - 1) + row_col(j, OBT * k + OBT - 1)
+            if k > 0:
+                p.append(idx[("Z", i, j, k - 1, 0)])
+        preds.append(p)
+    chain_preds = []
+    for k in range(m):
+        p = []
+        if k + 1 < m and k >= 1:
+            p = tile_state(k + 1, k, k) + tile_state(k + 1, k + 1, k)
+        chain_preds.append(p)
+    return preds, chain_preds
+
+
+def heft_lists(m, nwg=448, short_wgs=64, mod=Model, near=4, zprio=1.0, verbose=False, urgent_wgs=0, urgent=None):
+    """urgent: set of task keys (t, i, j, k, s) of chunks that may use the `urgent_wgs` workgroups behind the short-only ones"""
+    tasks = build_tasks(m, near)
+    preds, chain_preds = graph(m, tasks, near)
+    n = len(tasks)
+    dur = [mod.cT + mod.hop if x["t"] != "Z" else 0.5 * (mod.cZ1 + mod.cZ2) + mod.hop for x in tasks]
+    step = mod.cD + mod.cTail + mod.cB
+    # successors; chain nodes: ('L', k) = launch k start, ('D', k) = potrf_diag(k) end
+    succ = defaultdict(list)
+    for v, p in enumerate(preds):
+        for u in p:
+            succ[u].append(v)
+    for k, p in enumerate(chain_preds):
+        for u in p:
+            succ[u].append(("W", k))  # workers of launch k
+    # upward rank by reverse topological order: process chain backwards, tasks by descending "level".  A simple way:
+    # memoised recursion (depth is bounded by ~m * 10; use an explicit stack)
+    rank = {}
+    sys.setrecursionlimit(1000000)
+
+    def r(u):
+        if u in rank:
+            return rank[u]
+        if isinstance(u, tuple):
+            kind, k = u
+            if kind == "L":  # launch k start: -> D(k) end -> ...; and its own successors (tasks waiting for the strip)
+                v = max([mod.cD + r(("D", k))] + [r(s) for s in succ.get(u, [])])
+            elif kind == "D":  # potrf_diag(k) end -> launch end (tail) -> next launch
+                nxt = (mod.cTail + mod.cB + r(("L", k + 1))) if k + 1 < m else 0.0
+                v = max([nxt] + [r(s) for s in succ.get(u, [])])
+            else:  # 'W': workers of launch k have their flags: -> tail -> next launch
+                v = (mod.cLoad + mod.cTail + mod.cB + r(("L", k + 1))) if k + 1 < m else 0.0
+        else:
+            v = dur[u] + max([0.0] + [r(s) for s in succ.get(u, [])])
+        rank[u] = v
+        return v
+
+    for k in range(m - 1, -1, -1):
+        r(("L", k))
+    for u in range(n):
+        r(u)
+    prio = [rank[u] * (zprio if tasks[u]["t"] == "Z" else 1.0) for u in range(n)]
+    # ---- list scheduling with the timing model
+    half = nwg // 2
+    remaining = [len(set(map(lambda q: q if not isinstance(q, tuple) else q, p))) for p in preds]
+    # count distinct predecessor events (a tuple event counts once)
+    pred_sets = [set(p) for p in preds]
+    remaining = [len(s) for s in pred_sets]
+    users = defaultdict(list)
+    for v, s in enumerate(pred_sets):
+        for u in s:
+            users[u].append(v)
+    cp_sets = [set(p) for p in chain_preds]
+    cp_left = [len(s) for s in cp_sets]
+    cusers = defaultdict(list)
+    for k, s in enumerate(cp_sets):
+        for u in s:
+            cusers[u].append(k)
+    t = [0.0]
+    ev = []
+    seq = [0]
+
+    def at(time, fn, *a):
+        seq[0] += 1
+        heapq.heappush(ev, (time, seq[0], fn, a))
+
+    ready_short, ready_z, ready_uz = [], [], []  # heaps of (-prio, n)
+    free_short = list(range(short_wgs))           # workgroups that never take a chunk
+    free_urg = list(range(short_wgs, short_wgs + urgent_wgs))  # short tasks and urgent chunks
+    free_any = list(range(short_wgs + urgent_wgs, nwg))
+    is_urgent = [urgent is not None and (x['t'], x['i'], x['j'], x['k'], x['s']) in urgent for x in tasks]
+    zrun = [False] * nwg
+    lists = [[] for _ in range(nwg)]
+    order = []
+
+    def release(u):
+        for v in users.get(u, []):
+            remaining[v] -= 1
+            if remaining[v] == 0:
+                push(v)
+        for k in cusers.get(u, []):
+            cp_left[k] -= 1
+            if cp_left[k] == 0:
+                chain_flags(k)
+        dispatch()
+
+    def push(v):
+        if tasks[v]["t"] != "Z":
+            heapq.heappush(ready_short, (-prio[v], v))
+        elif is_urgent[v]:
+            heapq.heappush(ready_uz, (-prio[v], v))
+        else:
+            heapq.heappush(ready_z, (-prio[v], v))
+
+    def startz(b, v):
+        mate = (b + half) % nwg
+        zrun[b] = True
+        start(b, v, mod.cZ2 if zrun[mate] else mod.cZ1)
+
+    def dispatch():
+        while ready_short and (free_short or free_urg or free_any):
+            b = free_short.pop() if free_short else (free_urg.pop() if free_urg else free_any.pop())
+            _, v = heapq.heappop(ready_short)
+            start(b, v, mod.cT)
+        while ready_uz and (free_urg or free_any):
+            b = free_urg.pop() if free_urg else free_any.pop()
+            _, v = heapq.heappop(ready_uz)
+            startz(b, v)
+        while ready_z and free_any:
+            b = free_any.pop()
+            _, v = heapq.heappop(ready_z)
+            startz(b, v)
+
+    def start(b, v, d):
+        lists[b].append(tasks[v])
+        tasks[v]["sim_start"] = t[0] + mod.hop
+        order.append(v)
+        at(t[0] + mod.hop + d, fin, b, v)
+
+    def fin(b, v):
+        zrun[b] = False
+        (free_short if b < short_wgs else (free_urg if b < short_wgs + urgent_wgs else free_any)).append(b)
+        at(t[0] + mod.vis, release, v)
+        dispatch()
+
+    ch = dict(dend=0.0, flags=None, k=0)
+
+    def launch(k):
+        ch["k"] = k
+        ch["dend"] = t[0] + mod.cD
+        ch["flags"] = None
+        at(ch["dend"] + 0.5, release, ("D", k))
+        release(("L", k))
+        if k + 1 >= m:
+            at(ch["dend"] + 1.0, launch_end, k)
+        elif cp_left[k] == 0:
+            chain_flags(k)
+
+    def chain_flags(k):
+        if ch["k"] != k or ch["flags"] is not None:
+            return
+        ch["flags"] = t[0] + 1.0
+        at(max(ch["dend"], ch["flags"] + mod.cLoad) + mod.cTail, launch_end, k)
+
+    ends = []
+
+    def launch_end(k):
+        ends.append(t[0])
+        if k + 1 < m:
+            at(t[0] + mod.cB, launch, k + 1)
+
+    for v in range(n):
+        if remaining[v] == 0:
+            push(v)
+    at(0.0, launch, 0)
+    while ev:
+        t[0], _, fn, a = heapq.heappop(ev)
+        fn(*a)
+    assert len(order) == n and len(ends) == m, (len(order), n, len(ends))
+    if verbose:
+        print(f"  list scheduling itself: {t[0]:.0f} us")
+    heft_lists.last = dict(rank=rank, tasks=tasks, makespan=t[0])
+    return lists
+
+
+if __name__ == "__main__":
+    # slack of every chunk from the unlimited-workgroup schedule: ASAP start there against ALAP start (makespan - rank)
+    heft_lists(m, nwg=20000, short_wgs=10000)
+    info = heft_lists.last
+    slack = {}
+    for n, x in enumerate(info["tasks"]):
+        if x["t"] == "Z":
+            slack[(x["t"], x["i"], x["j"], x["k"], x["s"])] = info["makespan"] - info["rank"][n] - x["sim_start"]
+    import statistics
+    sl = sorted(slack.values())
+    print("chunk slack (us): min %.0f, 10%% %.0f, median %.0f, 90%% %.0f" % (sl[0], sl[len(sl)//10], statistics.median(sl), sl[9*len(sl)//10]))
+    for thr in (50, 150, 300):
+        urgent = {k for k, v in slack.items() if v < thr}
+        for sw, uw in ((32, 32), (32, 64), (32, 96), (64, 64)):
+            lists = heft_lists(m, short_wgs=sw, urgent_wgs=uw, urgent=urgent)
+            r = simulate(m, lists)
+            print(f"slack<{thr} ({len(urgent)} chunks) short_wgs={sw} urgent_wgs={uw}: total {r['total']:.0f} us, chain stalls {r['stall']:.0f}, util {r['util']:.2f}")
