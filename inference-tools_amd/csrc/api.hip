@@ -69,8 +69,16 @@ int lane_masked_streams(gpmi_ctx* c, Lane& L) {
       panel[(size_t)i / 32] |= 1u << (i % 32);
       upd[(size_t)i / 32] &= ~(1u << (i % 32));
     }
-    if (hipExtStreamCreateWithCUMask(&L.sp[k], (uint32_t)panel.size(), panel.data()) != hipSuccess ||
-        hipExtStreamCreateWithCUMask(&L.su[k], (uint32_t)upd.size(), upd.data()) != hipSuccess) {
+    hipError_t e1 = hipExtStreamCreateWithCUMask(&L.sp[k], (uint32_t)panel.size(), panel.data());
+    hipError_t e2 = e1 == hipSuccess ? hipExtStreamCreateWithCUMask(&L.su[k], (uint32_t)upd.size(), upd.data()) : e1;
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      // (said once per process: such a lane factors in stream order on the full chip - same bits, slower)
+      static bool told = false;
+      if (!told) {
+        told = true;
+        std::fprintf(stderr, "[gpmi] a CU-masked stream pair could not be created (%s): this evaluation lane runs without "
+                             "look-ahead and without the flag-ordered tail\n", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+      }
       if (L.sp[k]) (void)hipStreamDestroy(L.sp[k]);
       if (L.su[k]) (void)hipStreamDestroy(L.su[k]);
       L.sp[k] = L.su[k] = nullptr;  // no look-ahead: everything on the full-chip stream
@@ -87,8 +95,20 @@ int lane_alloc(gpmi_ctx* c, Lane& L) {
   // lanes[0] or lanes[1] (the lane has just been appended) of a problem large enough to ever enter the look-ahead
   // regime: destroying a CU-masked stream takes the runtime about a second, which small models (a GpOptimiser
   // builds a new regressor per added evaluation) should not pay
-  if (c->lanes.size() <= 2 && c->np >= 40 * GPMI_NB)
+  if (c->lanes.size() == 1 && c->np >= 40 * GPMI_NB)
     if (int rc = lane_masked_streams(c, L)) return rc;
+  // Lane 1 (single evaluations: marginal_likelihood, the gradients) borrows lane 0's pair.  The entry points of a handle
+  // are synchronous, so the fitted lane never factorises while lane 1 does - and a pair of its own made lane 1's speed a
+  // lottery of the order in which the process had created its queues: with any other handle created (and closed) before,
+  // the chain launches on lane 1's own panel stream ran 40 % slower (LML at N = 8192: 7.7 against 5.3 ms, round 5,
+  // tools/probe_lml.py), while lane 0's pair was fast in every order tried.  Two HSA queues per handle less as well.
+  if (c->lanes.size() == 2 && c->np >= 40 * GPMI_NB) {
+    for (int k = 0; k < GPMI_NPAIRS; ++k) {
+      L.sp[k] = c->lanes[0].sp[k];
+      L.su[k] = c->lanes[0].su[k];
+    }
+    L.owns_pair = false;
+  }
   const int64_t nt = c->np / GPMI_NB;
   HIPCHK(c, hipMalloc(&L.A, sizeof(double) * c->np * c->ld));
   HIPCHK(c, hipMalloc(&L.invD, sizeof(double) * nt * GPMI_NB * GPMI_NB));
@@ -108,6 +128,8 @@ void lane_free(Lane& L) {
   DBG_FREE("lane: sync main stream");
   if (L.stream) (void)hipStreamSynchronize(L.stream);
   DBG_FREE("lane: sync masked streams");
+  if (!L.owns_pair)
+    for (int k = 0; k < GPMI_NPAIRS; ++k) L.sp[k] = L.su[k] = nullptr;  // (lane 0's: synchronised and destroyed with it)
   for (int k = 0; k < GPMI_NPAIRS; ++k) {
     if (L.sp[k]) (void)hipStreamSynchronize(L.sp[k]);
     if (L.su[k]) (void)hipStreamSynchronize(L.su[k]);

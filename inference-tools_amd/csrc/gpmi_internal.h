@@ -42,6 +42,7 @@ struct Lane {
   // gpmi_ctx::pair_cus[k] CUs (sp) while the trailing update runs on all the others (su)
   hipStream_t sp[GPMI_NPAIRS] = {nullptr};
   hipStream_t su[GPMI_NPAIRS] = {nullptr};
+  bool owns_pair = true;           // false (lane 1): the pair is lane 0's (api.hip: lane_alloc)
   hipEvent_t ev_la = nullptr, ev_panel = nullptr, ev_join = nullptr, ev_main = nullptr, ev_slice = nullptr;
   double* A = nullptr;      // np x ld scratch (K then L)
   double* invD = nullptr;   // (np/128) x 128 x 128 inverses of the diagonal blocks
