@@ -371,7 +371,7 @@ def pmc_traffic():
     command (profiles/rNN_pmc.json, written by tools/pmc_bench.sh + tools/make_profiles.py: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
     coalesced reads on gfx950); (None, None) if absent."""
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)["kernels"]["update128"]["hbm_bytes_per_launch"], "profiles/" + name
@@ -385,7 +385,7 @@ def rocprof_duration_ratio():
     file): from the committed kernel-trace summary of this command (profiles/rNN_pmc.json `cross_check`).  rocprofv3
     times a launch from its dispatch to its completion signal - the end-of-kernel write-back included -, the stamps
     from the first workgroup's first instruction to the last workgroup's last acknowledged store."""
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
+    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 x = json.load(f)["cross_check"]

@@ -208,6 +208,14 @@ int gpmi_loo_grad_batch(gpmi_ctx* ctx, int kernel, int64_t T, const double* thet
                         const double* extra_diag_host, const double* mus_host, const double* mu_const_host,
                         double* alpha_host, double* ikdiag_host, double* p_host, double* grad_theta_host,
                         double* trace_q_host, int* info);
+/* gpmi_loo_grad_batch with noise variances of their own for every evaluation (noise_var_host: T x n) and, back, the diagonal of
+ * M = K^-1 diag(c2) K^-1 (mdiag_host: T x n): the leave-one-out gradient with respect to HeteroscedasticNoise's parameter of
+ * point i is 2 exp(2 theta_i) (p_i alpha_i - M_ii) (regression.py:509-514 with dK = 2 s_i^2 e_i e_i^T, covariance.py:683-689).
+ * Lockstep sizes only (n <= 4096, diagonal data errors); the cross_val = True search of such a model advances its starts on it. */
+int gpmi_loo_grad_batch_noise(gpmi_ctx* ctx, int kernel, int64_t T, const double* thetas_host, int n_theta,
+                              const double* extra_diag_host, const double* mus_host, const double* mu_const_host,
+                              const double* noise_var_host, double* alpha_host, double* ikdiag_host, double* p_host,
+                              double* mdiag_host, double* grad_theta_host, double* trace_q_host, int* info);
 
 /* ---- covariance plugin surface -----------------------------------------------------
  * Replaces CovarianceFunction.build_covariance (covariance.py:247-255, 343-348): the n x n matrix
@@ -271,6 +279,15 @@ int gpmi_lml_grad_batch_mix(gpmi_ctx* ctx, int nk, const int* kernels, int64_t T
                             const int* n_thetas, const double* g, const double* extra, const double* mus,
                             const double* mu_const, double* lml, double* grad_thetas, double* hrows,
                             double* alpha_out, double* qdiag_out, int* info);
+/* The leave-one-out counterpart (regression.py:489-526 with covariance.py:529-594) for T hyper-parameter vectors in lockstep:
+ * alpha, diag(K^-1), p = K^-1 (alpha / diag) and diag(M), M = K^-1 diag(c2) K^-1, per evaluation (T x n each); the
+ * sub-kernels' gradient components (T x sum n_thetas) and the window row sums h_m(i) = sum_j (sym(p alpha^T) - M)_ij K_m,ij g_m(j)
+ * (T x nk x n; window parameters: 2 sum_i dw_i (h_1 - h_0)_i on the host; WhiteNoise: 2 s^2 sum(p o alpha - diag M)).
+ * Lockstep sizes only (n <= 4096, diagonal data errors). */
+int gpmi_loo_grad_batch_mix(gpmi_ctx* ctx, int nk, const int* kernels, int64_t T, const double* thetas_host,
+                            const int* n_thetas, const double* g_host, const double* extra_diag_host,
+                            const double* mus_host, const double* mu_const_host, double* alpha_host, double* ikdiag_host,
+                            double* p_host, double* mdiag_host, double* grad_thetas_host, double* hrows_host, int* info);
 /* alpha and diag(K^-1) at arbitrary hyper-parameters: the O(n^3) part of loo_likelihood (regression.py:468-487) */
 int gpmi_loo_terms_mix(gpmi_ctx* ctx, int nk, const int* kernels, const double* thetas, const int* n_thetas,
                        const double* g_host, double extra_diag, const double* mu_host, double* alpha_host,

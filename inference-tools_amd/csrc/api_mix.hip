@@ -364,6 +364,190 @@ int gpmi_lml_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
   return GPMI_OK;
 }
 
+// Leave-one-out terms and gradient (regression.py:489-526) of a two-or-more-region ChangePoint mixture for T hyper-parameter
+// vectors in lockstep (round 5): gpmi_lml_grad_batch_mix's build / factorisation / inverse, then the leave-one-out
+// vectors, M = K^-1 diag(c2) K^-1 and, per sub-kernel, the weight-scaled M with u = g_m o p, v = g_m o alpha in the
+// fused contraction and the window row sums h_m(i) = sum_j (sym(p alpha^T) - M)_ij K_m,ij g_m(j).  Outputs per evaluation:
+// alpha, diag(K^-1), p = K^-1 c1, diag(M) (WhiteNoise: 2 s^2 sum(p o alpha - diag M)), the sub-kernels' gradients and the
+// row sums (window parameters: 2 sum_i dw_i (h_1 - h_0)_i, contracted on the host).  Lockstep sizes only.
+int gpmi_loo_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, const double* thetas,
+                            const int* n_thetas, const double* g_host, const double* extra, const double* mus,
+                            const double* mu_const, double* alpha_out, double* ikdiag_out, double* p_out,
+                            double* mdiag_out, double* grad_thetas, double* hrows, int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, c->n > 0, "gpmi_set_data has not been called");
+  ARGCHK(c, T >= 1 && T <= RED_SLOTS, "T out of range");
+  ARGCHK(c, nk >= 1 && nk <= GPMI_MAX_MIX, "number of sub-kernels out of range (1..4)");
+  ARGCHK(c, kernels && thetas && n_thetas && g_host && alpha_out && ikdiag_out && p_out && mdiag_out && grad_thetas && hrows,
+         "NULL argument");
+  ARGCHK(c, mus || mu_const, "one of mus / mu_const is required");
+  int tot_nt = 0, max_nt = 0;
+  for (int m = 0; m < nk; ++m) {
+    tot_nt += n_thetas[m];
+    max_nt = n_thetas[m] > max_nt ? n_thetas[m] : max_nt;
+  }
+  if (int rc = set_device(c)) return rc;
+  ARGCHK(c, c->np <= 4096 && !c->ycov, "lockstep sizes only (n <= 4096, diagonal data errors)");
+  if (c->lanes.size() < 2)
+    if (int rc = ensure_lanes(c, 2)) return rc;
+  // parameters: ps[m][t]
+  std::vector<KParams> ps((size_t)nk * T);
+  for (int64_t t = 0; t < T; ++t) {
+    int off = 0;
+    for (int m = 0; m < nk; ++m) {
+      if (int rc = make_params(c, kernels[m], thetas + t * tot_nt + off, n_thetas[m], 0.0, ps[(size_t)m * T + t])) return rc;
+      off += n_thetas[m];
+    }
+  }
+  ARGCHK(c, c->bpend[0] == 0 && c->bpend[1] == 0,
+         "gpmi_loo_grad_batch_mix: an asynchronous batch is pending on this handle (gpmi_lml_batch_wait first)");
+  if (int rc = ensure_batch_ws(c, (int)(T < 64 ? (T < 2 ? 2 : T) : 64))) return rc;
+  const int W = max_nt + 1;  // values per sub-kernel and problem from the contraction
+  if (int rc = ensure_batch_grad_ws(c, c->bcap, nk * W - 1)) return rc;
+  if (!c->mix_zero) {
+    HIPCHK(c, hipMalloc(&c->mix_zero, sizeof(double) * c->np));
+    HIPCHK(c, hipMemset(c->mix_zero, 0, sizeof(double) * c->np));
+  }
+  const int cap = c->bgrad_cap;
+  if (c->bMix_cap < cap) {
+    auto fr = [](double*& p) {
+      if (p) (void)hipFree(p);
+      p = nullptr;
+    };
+    fr(c->bMixG);
+    fr(c->bMixH);
+    fr(c->bMixExtra);
+    if (c->bMixP) (void)hipFree(c->bMixP);
+    c->bMixP = nullptr;
+    c->bMix_cap = 0;
+    HIPCHK(c, hipMalloc(&c->bMixG, sizeof(double) * cap * GPMI_MAX_MIX * c->np));
+    HIPCHK(c, hipMalloc(&c->bMixH, sizeof(double) * cap * GPMI_MAX_MIX * c->np));
+    HIPCHK(c, hipMalloc(&c->bMixExtra, sizeof(double) * cap));
+    HIPCHK(c, hipMalloc(&c->bMixP, sizeof(KParams) * cap * GPMI_MAX_MIX));
+    c->bMix_cap = cap;
+  }
+  // four more vectors per problem: diag(K^-1), c1, sqrt(c2) - later diag(M) -, p = K^-1 c1 (regression.py:505-513).
+  // (the same stride as the work vectors': the fused contraction takes u = p and v = alpha with ONE stride)
+  const int64_t sLoo = 4 * c->np;
+  if (c->bLoo_cap < cap) {
+    if (c->bLoo) (void)hipFree(c->bLoo);
+    c->bLoo = nullptr;
+    c->bLoo_cap = 0;
+    HIPCHK(c, hipMalloc(&c->bLoo, sizeof(double) * sLoo * cap));
+    c->bLoo_cap = cap;
+  }
+  hipStream_t s = c->lanes[1].stream;
+  const int nt = (int)(c->np / GPMI_NB);
+  const BatchShape shape0{1, c->np * c->ld, (c->np / GPMI_NB) * GPMI_NB * GPMI_NB, 4 * c->np};
+  const int64_t sG = (int64_t)GPMI_MAX_MIX * c->np;  // between the problems' weight (and row-sum) sets
+  std::vector<double> gpad, ex;
+  for (int64_t t0 = 0; t0 < T; t0 += cap) {
+    const int B = (int)((T - t0 < cap) ? T - t0 : cap);
+    BatchShape bs = shape0;
+    bs.count = B;
+    // weights, padded like mix_prepare does (the identity in the padding belongs to sub-kernel 0)
+    gpad.assign((size_t)B * sG, 0.0);
+    for (int b = 0; b < B; ++b)
+      for (int m = 0; m < nk; ++m) {
+        double* dst = gpad.data() + (size_t)b * sG + (size_t)m * c->np;
+        const double* src = g_host + ((t0 + b) * nk + m) * c->n;
+        for (int64_t i = 0; i < c->np; ++i) dst[i] = i < c->n ? src[i] : (m == 0 ? 1.0 : 0.0);
+      }
+    ex.assign((size_t)B, 0.0);
+    if (extra)
+      for (int b = 0; b < B; ++b) ex[(size_t)b] = extra[t0 + b];
+    HIPCHK(c, hipMemcpyAsync(c->bMixG, gpad.data(), sizeof(double) * B * sG, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->bMixExtra, ex.data(), sizeof(double) * B, hipMemcpyHostToDevice, s));
+    for (int m = 0; m < nk; ++m)
+      HIPCHK(c, hipMemcpyAsync(c->bMixP + (int64_t)m * cap, ps.data() + (size_t)m * T + t0, sizeof(KParams) * B,
+                               hipMemcpyHostToDevice, s));
+    if (mus)
+      HIPCHK(c, hipMemcpyAsync(c->bMu, mus + t0 * c->n, sizeof(double) * B * c->n, hipMemcpyHostToDevice, s));
+    else
+      HIPCHK(c, hipMemcpyAsync(c->bMu, mu_const + t0, sizeof(double) * B, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(c->bInfo, 0, sizeof(int) * B, s));
+    // K = sum_m D_m K_m D_m + noise + extra: the sub-kernels' lower tiles into the second matrix, folded into the first
+    // (the upper triangle of the sum is never read before the mirror below)
+    for (int m = 0; m < nk; ++m) {
+      launch_kbuild_square_batched(s, kernels[m], c->bMixP + (int64_t)m * cap, B, c->x, c->n, c->np, c->mix_zero, c->bB2,
+                                   c->ld, bs.sMat, (int)c->d, 0);
+      launch_scale_add(s, c->bA, c->ld, c->bB2, c->ld, c->bMixG + (int64_t)m * c->np, c->bMixG + (int64_t)m * c->np,
+                       c->np, c->np, m > 0, B, bs.sMat, bs.sMat, sG);
+    }
+    launch_add_diag_vec(s, c->bA, c->ld, c->noise, 0.0, c->n, B, bs.sMat, c->bMixExtra);
+    potrf_lower_batched(c, s, c->bA, c->np, c->ld, c->bInv, c->bInfo, bs);
+    launch_residual_batched(s, c->y, mus ? c->bMu : nullptr, mus ? nullptr : c->bMu, c->bVec + 2 * c->np, c->n, c->np,
+                            bs);
+    trsv_forward(c, s, c->bA, c->np, c->ld, c->bInv, c->bVec + 2 * c->np, c->bVec, c->bInfo, bs);
+    double* alpha_dev = c->bVec + c->np;   // slot 1 of every problem's four work vectors
+    double* ua_dev = c->bVec + 2 * c->np;  // slot 2 (the residual is spent): g_m o alpha
+    trsv_backward(c, s, c->bA, c->np, c->ld, c->bInv, c->bVec, alpha_dev, c->bInfo, bs);
+    double* va_dev = c->bVec + 3 * c->np;  // slot 3: g_m o alpha (slot 2: g_m o p)
+    double* diag_dev = c->bLoo;
+    double* c1_dev = c->bLoo + c->np;
+    double* sc2_dev = c->bLoo + 2 * c->np;
+    double* p_dev = c->bLoo + 3 * c->np;
+    double* mdiag_dev = sc2_dev;  // (sqrt(c2) is spent once G = K^-1 diag(sqrt c2) exists)
+    // L^-T, its row sums of squares = diag(K^-1), K^-1 in full, the leave-one-out vectors, p = K^-1 c1, then
+    // M = K^-1 diag(c2) K^-1 = G G^T with G = K^-1 diag(sqrt c2), in full as well (it is read row-wise below)
+    trsm_identity_batched(s, c->bA, c->np, c->ld, c->bInv, c->bB2, bs);
+    launch_rows_sumsq(s, c->bB2, c->ld, c->np, c->np, 0.0, diag_dev, B, bs.sMat, sLoo, -1.0);
+    const GemmBatch syrk{B, bs.sMat, bs.sMat, bs.sMat};
+    launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, 1, c->bA, c->ld, c->bB2, c->ld, c->bB2, c->ld, nt, nt, (int)c->np,
+                nullptr, syrk);
+    launch_mirror_lower(s, c->bA, c->ld, c->np, B, bs.sMat);
+    launch_loo_vectors(s, alpha_dev, diag_dev, c1_dev, sc2_dev, c->n, c->np, B, bs.sVec, sLoo);
+    launch_rows_dot(s, c->bA, c->ld, c->np, c->np, c1_dev, p_dev, B, bs.sMat, sLoo);
+    launch_scale_columns(s, c->bA, sc2_dev, c->bB2, c->ld, c->np, B, bs.sMat, sLoo);
+    launch_rows_sumsq(s, c->bB2, c->ld, c->np, c->np, 0.0, mdiag_dev, B, bs.sMat, sLoo, -1.0);  // M_ii = |row i of G|^2
+    launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, 0, c->bA, c->ld, c->bB2, c->ld, c->bB2, c->ld, nt, nt, (int)c->np,
+                nullptr, syrk);
+    launch_mirror_lower(s, c->bA, c->ld, c->np, B, bs.sMat);
+    for (int m = 0; m < nk; ++m) {
+      const double* gm = c->bMixG + (int64_t)m * c->np;
+      const KParams* pm = c->bMixP + (int64_t)m * cap;
+      // sum (D_m Q D_m) o dK_m with Q = sym(p alpha^T) - M: the fused contraction on the weight-scaled M with
+      // u = g_m o p, v = g_m o alpha (it returns 1/2 of the sum; the leave-one-out gradient has no 1/2: doubled below)
+      launch_scale_add(s, c->bB2, c->ld, c->bA, c->ld, gm, gm, c->np, c->np, false, B, bs.sMat, bs.sMat, sG);
+      launch_vec_mul(s, gm, p_dev, ua_dev, c->np, B, sG, sLoo, bs.sVec);
+      launch_vec_mul(s, gm, alpha_dev, va_dev, c->np, B, sG, bs.sVec, bs.sVec);
+      launch_lml_grad_batched(s, pm, B, n_thetas[m], c->x, c->n, c->np, c->bB2, c->ld, bs.sMat, ua_dev, va_dev, bs.sVec,
+                              c->bGws, c->bGout + (int64_t)m * cap * W);
+      // window parameters: h_m(i) = sum_j Q_ij K_m,ij g_m(j) on the full K_m (lower tiles built, then mirrored)
+      launch_kbuild_square_batched(s, kernels[m], pm, B, c->x, c->n, c->np, c->mix_zero, c->bB2, c->ld, bs.sMat,
+                                   (int)c->d, 0);
+      launch_mirror_lower(s, c->bB2, c->ld, c->np, B, bs.sMat);
+      launch_mix_rowsum(s, c->bA, c->bB2, c->ld, alpha_dev, gm, c->bMixH + (int64_t)m * c->np, c->n, B, bs.sMat,
+                        bs.sVec, sG, p_dev, sLoo);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_bGout, c->bGout, sizeof(double) * nk * cap * W, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_bInfo, c->bInfo, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    for (int m = 0; m < nk; ++m)
+      HIPCHK(c, hipMemcpy2DAsync(hrows + (t0 * nk + m) * c->n, sizeof(double) * nk * c->n, c->bMixH + (int64_t)m * c->np,
+                                 sizeof(double) * sG, sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpy2DAsync(alpha_out + t0 * c->n, sizeof(double) * c->n, alpha_dev, sizeof(double) * bs.sVec,
+                               sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpy2DAsync(ikdiag_out + t0 * c->n, sizeof(double) * c->n, diag_dev, sizeof(double) * sLoo,
+                               sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpy2DAsync(p_out + t0 * c->n, sizeof(double) * c->n, p_dev, sizeof(double) * sLoo,
+                               sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpy2DAsync(mdiag_out + t0 * c->n, sizeof(double) * c->n, mdiag_dev, sizeof(double) * sLoo,
+                               sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int b = 0; b < B; ++b) {
+      const int inf = c->h_bInfo[b];
+      INFOCHK(c, inf);
+      int o = 0;
+      for (int m = 0; m < nk; ++m)
+        for (int j = 0; j < n_thetas[m]; ++j)
+          grad_thetas[(t0 + b) * tot_nt + o++] = 2.0 * c->h_bGout[(int64_t)m * cap * W + (int64_t)b * (n_thetas[m] + 1) + j];
+      if (info) info[t0 + b] = inf;
+    }
+  }
+  return GPMI_OK;
+}
+
 int gpmi_loo_terms_mix(gpmi_ctx* c, int nk, const int* kernels, const double* thetas, const int* n_thetas,
                        const double* g_host, double extra_diag, const double* mu, double* alpha_out,
                        double* ikdiag, int* info) {

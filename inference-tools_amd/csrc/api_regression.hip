@@ -441,15 +441,20 @@ int gpmi_lml_grad_batch_noise(gpmi_ctx* c, int kernel, int64_t T, const double* 
 // Leave-one-out log-likelihood terms and gradient (regression.py:489-526) for T hyper-parameter vectors in lockstep: the
 // batched form of gpmi_loo_grad - every launch carries the chunk in blockIdx.z.  What the reference's `multiprocessing.Pool`
 // farms out start by start (regression.py:597-601) when the model selector is the cross-validation objective.
-int gpmi_loo_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int n_theta, const double* extra,
-                        const double* mus, const double* mu_const, double* alpha_out, double* ikdiag_out, double* p_out,
-                        double* grad_theta, double* trace_q, int* info) {
+// noise_batch (T x n, host) / mdiag_out (T x n, host): the per-problem noise variances of HeteroscedasticNoise and the
+// diagonal of M = K^-1 diag(c2) K^-1, which the gradient with respect to a point's own noise needs (dK = 2 s_i^2 e_i e_i^T:
+// 2 s_i^2 (p_i alpha_i - M_ii)); both NULL for the plain form.  With them every call takes the lockstep path.
+static int loo_grad_batch_impl(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int n_theta, const double* extra,
+                               const double* mus, const double* mu_const, const double* noise_batch, double* alpha_out,
+                               double* ikdiag_out, double* p_out, double* mdiag_out, double* grad_theta, double* trace_q,
+                               int* info) {
   if (!c) return GPMI_ERR_ARG;
   ARGCHK(c, T >= 1 && T <= RED_SLOTS, "T out of range");
   ARGCHK(c, thetas && alpha_out && ikdiag_out && p_out && grad_theta, "NULL argument");
   ARGCHK(c, mus || mu_const, "one of mus / mu_const is required");
   if (int rc = set_device(c)) return rc;
-  const bool lockstep = (T >= 2 || c->lockstep_always) && c->np <= 4096 && !c->ycov;
+  const bool lockstep = (T >= 2 || c->lockstep_always || noise_batch) && c->np <= 4096 && !c->ycov;
+  ARGCHK(c, lockstep || !noise_batch, "per-point noise in the batch: lockstep sizes only (n <= 4096, diagonal data errors)");
   if (!lockstep) {
     std::vector<double> mu_row((size_t)c->n);
     for (int64_t t = 0; t < T; ++t) {
@@ -473,8 +478,16 @@ int gpmi_loo_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas
          "gpmi_loo_grad_batch: an asynchronous batch is pending on this handle (gpmi_lml_batch_wait first)");
   if (int rc = ensure_batch_ws(c, (int)(T < 64 ? (T < 2 ? 2 : T) : 64))) return rc;
   if (int rc = ensure_batch_grad_ws(c, c->bcap, n_theta)) return rc;
-  // four more vectors per problem: diag(K^-1), c1, sqrt(c2), p = K^-1 c1 (regression.py:505-513)
+  // four more vectors per problem: diag(K^-1), c1, sqrt(c2) - later diag(M) -, p = K^-1 c1 (regression.py:505-513).
+  // (the same stride as the work vectors': the fused contraction takes u = p and v = alpha with ONE stride)
   const int64_t sLoo = 4 * c->np;
+  if (noise_batch && c->bNoise_cap < c->bgrad_cap) {
+    if (c->bNoise) (void)hipFree(c->bNoise);
+    c->bNoise = nullptr;
+    c->bNoise_cap = 0;
+    HIPCHK(c, hipMalloc(&c->bNoise, sizeof(double) * c->np * c->bgrad_cap));
+    c->bNoise_cap = c->bgrad_cap;
+  }
   if (c->bLoo_cap < c->bgrad_cap) {
     if (c->bLoo) (void)hipFree(c->bLoo);
     c->bLoo = nullptr;
@@ -496,8 +509,11 @@ int gpmi_loo_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas
     else
       HIPCHK(c, hipMemcpyAsync(c->bMu, mu_const + t0, sizeof(double) * B, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemsetAsync(c->bInfo, 0, sizeof(int) * B, s));
-    launch_kbuild_square_batched(s, ps[0].kernel, c->bParams, B, c->x, c->n, c->np, c->noise, c->bA, c->ld, bs.sMat,
-                                 (int)c->d);
+    if (noise_batch)
+      HIPCHK(c, hipMemcpy2DAsync(c->bNoise, sizeof(double) * c->np, noise_batch + t0 * c->n, sizeof(double) * c->n,
+                                 sizeof(double) * c->n, B, hipMemcpyHostToDevice, s));
+    launch_kbuild_square_batched(s, ps[0].kernel, c->bParams, B, c->x, c->n, c->np, noise_batch ? c->bNoise : c->noise,
+                                 c->bA, c->ld, bs.sMat, (int)c->d, noise_batch ? c->np : 0);
     potrf_lower_batched(c, s, c->bA, c->np, c->ld, c->bInv, c->bInfo, bs);
     launch_residual_batched(s, c->y, mus ? c->bMu : nullptr, mus ? nullptr : c->bMu, c->bVec + 2 * c->np, c->n, c->np,
                             bs);
@@ -519,6 +535,8 @@ int gpmi_loo_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas
     launch_rows_dot(s, c->bA, c->ld, c->np, c->np, c1_dev, p_dev, B, bs.sMat, sLoo);
     // M = K^-1 diag(c2) K^-1 = G G^T with G = K^-1 diag(sqrt c2); lower tiles, overwriting K^-1
     launch_scale_columns(s, c->bA, sc2_dev, c->bB2, c->ld, c->np, B, bs.sMat, sLoo);
+    double* mdiag_dev = sc2_dev;  // (sqrt(c2) is spent once G = K^-1 diag(sqrt c2) exists)
+    if (mdiag_out) launch_rows_sumsq(s, c->bB2, c->ld, c->np, c->np, 0.0, mdiag_dev, B, bs.sMat, sLoo, -1.0);  // M_ii = |row i of G|^2
     launch_gemm(s, TILES_LOWER, OP_ASSIGN, false, 0, c->bA, c->ld, c->bB2, c->ld, c->bB2, c->ld, nt, nt, (int)c->np,
                 nullptr, syrk);
     launch_lml_grad_batched(s, c->bParams, B, n_theta, c->x, c->n, c->np, c->bA, c->ld, bs.sMat, p_dev, alpha_dev, sLoo,
@@ -532,6 +550,9 @@ int gpmi_loo_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas
                                sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpy2DAsync(p_out + t0 * c->n, sizeof(double) * c->n, p_dev, sizeof(double) * sLoo,
                                sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    if (mdiag_out)
+      HIPCHK(c, hipMemcpy2DAsync(mdiag_out + t0 * c->n, sizeof(double) * c->n, mdiag_dev, sizeof(double) * sLoo,
+                                 sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     for (int b = 0; b < B; ++b) {
       const int inf = c->h_bInfo[b];
@@ -543,6 +564,24 @@ int gpmi_loo_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas
     }
   }
   return GPMI_OK;
+}
+
+int gpmi_loo_grad_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int n_theta, const double* extra,
+                        const double* mus, const double* mu_const, double* alpha_out, double* ikdiag_out, double* p_out,
+                        double* grad_theta, double* trace_q, int* info) {
+  return loo_grad_batch_impl(c, kernel, T, thetas, n_theta, extra, mus, mu_const, nullptr, alpha_out, ikdiag_out, p_out,
+                             nullptr, grad_theta, trace_q, info);
+}
+
+int gpmi_loo_grad_batch_noise(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int n_theta, const double* extra,
+                              const double* mus, const double* mu_const, const double* noise_var, double* alpha_out,
+                              double* ikdiag_out, double* p_out, double* mdiag_out, double* grad_theta, double* trace_q,
+                              int* info) {
+  if (!c) return GPMI_ERR_ARG;
+  ARGCHK(c, noise_var && mdiag_out, "noise_var / mdiag is NULL");
+  ARGCHK(c, !c->ycov, "per-point noise hyper-parameters need diagonal data errors");
+  return loo_grad_batch_impl(c, kernel, T, thetas, n_theta, extra, mus, mu_const, noise_var, alpha_out, ikdiag_out, p_out,
+                             mdiag_out, grad_theta, trace_q, info);
 }
 
 int gpmi_predict(gpmi_ctx* c, const double* pts, int64_t m, double* mu_out, double* var_out) {

@@ -267,10 +267,10 @@ void launch_add_diag_vec(hipStream_t s, double* A, int64_t ld, const double* noi
                          int batch = 1, int64_t sA = 0, const double* extras = nullptr);
 void launch_vec_mul(hipStream_t s, const double* a, const double* b, double* out, int64_t n, int batch = 1,
                     int64_t sA = 0, int64_t sB = 0, int64_t sOut = 0);
-// h_i = sum_j (alpha_i alpha_j - iK_ij) Km_ij g_j  (iK, Km full n x n)
+// h_i = sum_j (1/2 (u_i alpha_j + alpha_i u_j) - iK_ij) Km_ij g_j  (iK, Km full n x n; u = nullptr: u = alpha, the LML form)
 void launch_mix_rowsum(hipStream_t s, const double* iK, const double* Km, int64_t ld, const double* alpha,
                        const double* g, double* h, int64_t n, int batch = 1, int64_t sMat = 0, int64_t sAlpha = 0,
-                       int64_t sG = 0);
+                       int64_t sG = 0, const double* u = nullptr, int64_t sU = 0);
 
 // gemm_f64.hip  (all dims multiples of 128, k multiple of 16)
 enum GemmTiles { TILES_RECT = 0, TILES_LOWER = 1 };

@@ -46,30 +46,33 @@ __global__ void vec_mul_kernel(const double* __restrict__ a, const double* __res
   if (i < n) out[i] = a[i] * b[i];
 }
 
-// one wave per row:  h_i = sum_j (alpha_i alpha_j - iK_ij) Km_ij g_j   (fixed order: bit-reproducible)
+// one wave per row:  h_i = sum_j (1/2 (u_i v_j + v_i u_j) - M_ij) Km_ij g_j   (fixed order: bit-reproducible).
+// LML gradient: u = v = alpha, M = K^-1 (1/2 (x + x) = x exactly: the same bits as alpha_i alpha_j); leave-one-out
+// gradient: u = p, v = alpha, M = K^-1 diag(c2) K^-1 (regression.py:509-514)
 __global__ __launch_bounds__(256) void mix_rowsum_kernel(const double* __restrict__ iK,
                                                          const double* __restrict__ Km, int64_t ld,
-                                                         const double* __restrict__ alpha,
+                                                         const double* __restrict__ u, const double* __restrict__ v,
                                                          const double* __restrict__ g,
                                                          double* __restrict__ h, int64_t n, int64_t sMat,
-                                                         int64_t sAlpha, int64_t sG) {
+                                                         int64_t sU, int64_t sV, int64_t sG) {
   iK += (int64_t)blockIdx.z * sMat;
   Km += (int64_t)blockIdx.z * sMat;
-  alpha += (int64_t)blockIdx.z * sAlpha;
+  u += (int64_t)blockIdx.z * sU;
+  v += (int64_t)blockIdx.z * sV;
   g += (int64_t)blockIdx.z * sG;
   h += (int64_t)blockIdx.z * sG;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
-  const double ai = alpha[row];
+  const double ui = u[row], vi = v[row];
   const double* q = iK + row * ld;
   const double* k = Km + row * ld;
   double s = 0.0;
   for (int64_t j = lane * 2; j < n; j += 128) {
     const d2_t qv = *reinterpret_cast<const d2_t*>(q + j);
     const d2_t kv = *reinterpret_cast<const d2_t*>(k + j);
-    s = fma((ai * alpha[j] - qv[0]) * kv[0], g[j], s);
-    if (j + 1 < n) s = fma((ai * alpha[j + 1] - qv[1]) * kv[1], g[j + 1], s);
+    s = fma((0.5 * (ui * v[j] + vi * u[j]) - qv[0]) * kv[0], g[j], s);
+    if (j + 1 < n) s = fma((0.5 * (ui * v[j + 1] + vi * u[j + 1]) - qv[1]) * kv[1], g[j + 1], s);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -99,7 +102,12 @@ void launch_vec_mul(hipStream_t s, const double* a, const double* b, double* out
 }
 
 void launch_mix_rowsum(hipStream_t s, const double* iK, const double* Km, int64_t ld, const double* alpha,
-                       const double* g, double* h, int64_t n, int batch, int64_t sMat, int64_t sAlpha, int64_t sG) {
+                       const double* g, double* h, int64_t n, int batch, int64_t sMat, int64_t sAlpha, int64_t sG,
+                       const double* u, int64_t sU) {
+  if (!u) {  // the LML form: u = v = alpha
+    u = alpha;
+    sU = sAlpha;
+  }
   hipLaunchKernelGGL(mix_rowsum_kernel, dim3((unsigned)((n + 3) / 4), 1, (unsigned)batch), dim3(256), 0, s, iK, Km, ld,
-                     alpha, g, h, n, sMat, sAlpha, sG);
+                     u, alpha, g, h, n, sMat, sU, sAlpha, sG);
 }

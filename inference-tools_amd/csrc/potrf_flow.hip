@@ -893,6 +893,52 @@ FlowLists flow_build(int m, int nwg) {
   return out;
 }
 
+// GPMI_FLOW_LISTS=<file prefix> (experiments, tools/sim/flow_sched.py --write): task lists built outside the library for
+// a tail of m tile rows, read from <prefix>_m<m>.bin = int32 {m, nwg, ntasks}, int32 off[nwg + 1], FlowTask[ntasks].  The
+// same tasks as flow_build's in another deal and order (checked: a permutation); a list order that is not admissible ends
+// in the kernel's bounded polls, not in a hang.
+void flow_lists_override(int m, int nwg, FlowLists& fl) {
+  static const char* prefix = std::getenv("GPMI_FLOW_LISTS");
+  if (!prefix) return;
+  char path[1024];
+  std::snprintf(path, sizeof(path), "%s_m%d.bin", prefix, m);
+  FILE* fp = std::fopen(path, "rb");
+  if (!fp) return;
+  int32_t hdr[3] = {0, 0, 0};
+  std::vector<int> off;
+  std::vector<FlowTask> tasks;
+  bool ok = std::fread(hdr, sizeof(hdr), 1, fp) == 1 && hdr[0] == m && hdr[1] == nwg &&
+            hdr[2] == (int32_t)fl.tasks.size();
+  if (ok) {
+    off.resize((size_t)nwg + 1);
+    tasks.resize((size_t)hdr[2]);
+    ok = std::fread(off.data(), sizeof(int), off.size(), fp) == off.size() &&
+         std::fread(tasks.data(), sizeof(FlowTask), tasks.size(), fp) == tasks.size() && off[0] == 0 &&
+         off[(size_t)nwg] == hdr[2];
+  }
+  std::fclose(fp);
+  if (ok) {  // a permutation of the library's own tasks
+    auto key = [](const FlowTask& t) {
+      return std::make_tuple((int)t.type, (int)t.i, (int)t.j, (int)t.k, (int)t.s, (int)t.fadd);
+    };
+    std::vector<std::tuple<int, int, int, int, int, int>> a, b;
+    for (auto& t : fl.tasks) a.push_back(key(t));
+    for (auto& t : tasks) b.push_back(key(t));
+    std::sort(a.begin(), a.end());
+    std::sort(b.begin(), b.end());
+    ok = a == b;
+  }
+  if (!ok) {
+    std::fprintf(stderr, "[flow] %s does not hold the task lists of m = %d, %d workgroups: ignored\n", path, m, nwg);
+    return;
+  }
+  fl.tasks.swap(tasks);
+  fl.off.swap(off);
+  static bool told = false;
+  if (!told) std::fprintf(stderr, "[flow] task lists from %s\n", path);
+  told = true;
+}
+
 }  // namespace
 
 // Host-only view of the task lists (no device call): what tests/test_flow_cpu.py replays with NumPy tile operations.
@@ -1017,7 +1063,8 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
   if (!flow_gate_try(c->device)) return false;
   if (lane.flow_m != m || lane.flow_nwg != nwg) {
     potrf_flow_free(lane);
-    const FlowLists fl = flow_build(m, nwg);
+    FlowLists fl = flow_build(m, nwg);
+    flow_lists_override(m, nwg, fl);
     const size_t total = fl.tasks.size();
     if (hipMalloc(&lane.flow_tasks, sizeof(FlowTask) * (total ? total : 1)) != hipSuccess ||
         hipMalloc(&lane.flow_off, sizeof(int) * fl.off.size()) != hipSuccess ||

@@ -218,6 +218,29 @@ class GpEngine(_DeviceCommMixin):
                     info.ctypes.data_as(ip))
         return lml, grad, hrows, alpha, qdiag, info
 
+    def loo_grad_batch_mix(self, kernels, thetas, weights, extra_diag=None, mus=None, mu_const=None):
+        """gpmi_loo_grad_batch_mix: T evaluations of the mixture's leave-one-out pieces in one call (lockstep sizes only).
+        Arguments as `lml_grad_batch_mix`.  Returns (alpha, ikdiag, pvec, mdiag (T, n each), grad (T, sum n_thetas),
+        hrows (T, nk, n), info (T,))."""
+        ks = np.ascontiguousarray(kernels, dtype=np.int32)
+        nk = len(ks)
+        T = len(thetas)
+        nts = np.ascontiguousarray([len(t) for t in thetas[0]], dtype=np.int32)
+        th = as_f64(np.array([np.concatenate([np.asarray(v, dtype=float) for v in row]) for row in thetas]))
+        g = as_f64(np.asarray(weights, dtype=float).reshape(T, nk, self.n))
+        ex = None if extra_diag is None else as_f64(extra_diag)
+        mus = None if mus is None else as_f64(mus)
+        mc = None if mu_const is None else as_f64(mu_const)
+        alpha, ikdiag, pvec, mdiag = (np.empty((T, self.n)) for _ in range(4))
+        grad = np.empty((T, int(nts.sum())))
+        hrows = np.empty((T, nk, self.n))
+        info = np.zeros(T, dtype=np.int32)
+        ip = C.POINTER(C.c_int)
+        self.h.call("gpmi_loo_grad_batch_mix", nk, ks.ctypes.data_as(ip), T, dptr(th), nts.ctypes.data_as(ip), dptr(g),
+                    dptr(ex), dptr(mus), dptr(mc), dptr(alpha), dptr(ikdiag), dptr(pvec), dptr(mdiag), dptr(grad),
+                    dptr(hrows), info.ctypes.data_as(ip))
+        return alpha, ikdiag, pvec, mdiag, grad, hrows, info
+
     def loo_terms_mix(self, kernels, thetas, weights, extra_diag, mu):
         nk, ks, kp, th, nts, ntp, g = self._mix_args(kernels, thetas, weights)
         mu = as_f64(mu)
@@ -406,9 +429,11 @@ class GpEngine(_DeviceCommMixin):
                     dptr(alpha), dptr(ikdiag), dptr(pvec), dptr(grad), C.byref(trq), C.byref(info))
         return alpha, ikdiag, pvec, grad, trq.value, info.value
 
-    def loo_grad_batch(self, kernel, thetas_cov, extra_diag, mus=None, mu_const=None):
+    def loo_grad_batch(self, kernel, thetas_cov, extra_diag, mus=None, mu_const=None, noise_var=None):
         """T evaluations of `loo_grad` in one call (gpmi_loo_grad_batch: lockstep for padded N <= 4096):
-        (alpha (T, n), ikdiag (T, n), pvec (T, n), grad (T, n_theta), trace_q (T,), info (T,))."""
+        (alpha (T, n), ikdiag (T, n), pvec (T, n), grad (T, n_theta), trace_q (T,), info (T,)).  With `noise_var`
+        (T, n: HeteroscedasticNoise, every evaluation its own data variances; gpmi_loo_grad_batch_noise) the tuple gains
+        mdiag (T, n) = diag(K^-1 diag(c2) K^-1) in front of info."""
         th = as_f64(np.atleast_2d(thetas_cov))
         T, nth = th.shape
         ex = as_f64(np.broadcast_to(np.asarray(extra_diag, dtype=float), (T,)))
@@ -417,6 +442,13 @@ class GpEngine(_DeviceCommMixin):
         info = np.zeros(T, dtype=np.int32)
         mus_p = dptr(as_f64(mus)) if mus is not None else None
         muc_p = dptr(as_f64(np.broadcast_to(np.asarray(mu_const, dtype=float), (T,)))) if mus is None else None
+        if noise_var is not None:
+            nv = as_f64(noise_var)
+            assert nv.shape == (T, self.n)
+            mdiag = np.empty((T, self.n))
+            self.h.call("gpmi_loo_grad_batch_noise", kernel, T, dptr(th), nth, dptr(ex), mus_p, muc_p, dptr(nv), dptr(alpha),
+                        dptr(ikdiag), dptr(pvec), dptr(mdiag), dptr(grad), dptr(trq), info.ctypes.data_as(C.POINTER(C.c_int)))
+            return alpha, ikdiag, pvec, grad, trq, mdiag, info
         self.h.call("gpmi_loo_grad_batch", kernel, T, dptr(th), nth, dptr(ex), mus_p, muc_p, dptr(alpha), dptr(ikdiag),
                     dptr(pvec), dptr(grad), dptr(trq), info.ctypes.data_as(C.POINTER(C.c_int)))
         return alpha, ikdiag, pvec, grad, trq, info

@@ -71,10 +71,12 @@ SIGNATURES = {
     "gpmi_loo_terms": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _ip]),
     "gpmi_loo_grad": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_loo_grad_batch": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_loo_grad_batch_noise": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_fit_mix": (C.c_int, [_vp, C.c_int, _ip, _dp, _ip, _dp, C.c_double, _dp, _dp, _dp, _ip]),
     "gpmi_lml_mix": (C.c_int, [_vp, C.c_int, _ip, _dp, _ip, _dp, C.c_double, _dp, _dp, _ip]),
     "gpmi_lml_grad_mix": (C.c_int, [_vp, C.c_int, _ip, _dp, _ip, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_lml_grad_batch_mix": (C.c_int, [_vp, C.c_int, _ip, _i64, _dp, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_loo_grad_batch_mix": (C.c_int, [_vp, C.c_int, _ip, _i64, _dp, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_loo_terms_mix": (C.c_int, [_vp, C.c_int, _ip, _dp, _ip, _dp, C.c_double, _dp, _dp, _dp, _ip]),
     "gpmi_predict_mix": (C.c_int, [_vp, _dp, _i64, _dp, _dp, _dp]),
     "gpmi_posterior_mix": (C.c_int, [_vp, _dp, _i64, _dp, _dp, _dp]),
@@ -204,8 +206,8 @@ class Handle:
                              "gpmi_lml_grad_batch", "gpmi_lml_mix", "gpmi_lml_grad_mix", "gpmi_lml_dense", "gpmi_loo_dense",
                              "gpmi_linv_lml", "gpmi_linv_lml_grad", "gpmi_linv_posterior", "gpmi_linv_lml_dense",
                              "gpmi_linv_lml_grad_dense", "gpmi_linv_posterior_dense", "gpmi_loo_terms", "gpmi_loo_grad",
-                             "gpmi_loo_terms_mix", "gpmi_dev_potrf", "gpmi_loo_grad_batch", "gpmi_lml_grad_batch_noise",
-                             "gpmi_lml_grad_batch_mix"))
+                             "gpmi_loo_terms_mix", "gpmi_dev_potrf", "gpmi_loo_grad_batch", "gpmi_loo_grad_batch_noise", "gpmi_lml_grad_batch_noise",
+                             "gpmi_lml_grad_batch_mix", "gpmi_loo_grad_batch_mix"))
 
     def call(self, name, *args):
         rc = getattr(self.lib, name)(self.ctx, *args)

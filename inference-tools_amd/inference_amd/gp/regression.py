@@ -482,18 +482,28 @@ class GpRegressor:
         multi-start search evaluates per round when the model selector is the cross-validation objective
         (regression.py:159-164)."""
         thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
-        if self._generic or self._het_slice is not None or self._mix is not None:
+        het_batch = (self._het_slice is not None and self._mix is None and not self._generic and self._y_cov is None
+                     and self.engine.capacity() <= 4096)  # (round 5: gpmi_loo_grad_batch_noise, lockstep sizes only)
+        if (self._mix is not None and not self._generic and self._mix.n_kernels == 2 and self._het_slice is None
+                and self._y_cov is None and self.engine.capacity() <= 4096):
+            return self._mixture_loo_gradient_batch(thetas)  # (round 5: gpmi_loo_grad_batch_mix)
+        if self._generic or self._mix is not None or (self._het_slice is not None and not het_batch):
             res = [self.loo_likelihood_gradient(t) for t in thetas]
             return np.array([r[0] for r in res]), np.array([r[1] for r in res])
         split = [self._split_cov_theta(t[self.cov_slice]) for t in thetas]
         th = np.array([s_[0] for s_ in split])
         ex = np.array([s_[1] for s_ in split])
         means = [self.mean.mean_and_gradients(t[self.mean_slice]) for t in thetas]
-        if isinstance(self.mean, ConstantMean):
-            out = self.engine.loo_grad_batch(self._kernel_id, th, ex, mu_const=thetas[:, 0])
+        mean_kw = (dict(mu_const=thetas[:, 0]) if isinstance(self.mean, ConstantMean)
+                   else dict(mus=np.array([m[0] for m in means])))
+        mdiag = None
+        if het_batch:
+            # HeteroscedasticNoise: every evaluation has noise variances of its own
+            noise = np.array([self._noise_total(t[self.cov_slice]) for t in thetas])
+            alpha, ikdiag, pvec, g_stat, trace_q, mdiag, info = self.engine.loo_grad_batch(self._kernel_id, th, ex,
+                                                                                           noise_var=noise, **mean_kw)
         else:
-            out = self.engine.loo_grad_batch(self._kernel_id, th, ex, mus=np.array([m[0] for m in means]))
-        alpha, ikdiag, pvec, g_stat, trace_q, info = out
+            alpha, ikdiag, pvec, g_stat, trace_q, info = self.engine.loo_grad_batch(self._kernel_id, th, ex, **mean_kw)
         if (info != 0).any():
             raise LinAlgError("Matrix is not positive definite")  # regression.py:501 has no guard
         values = np.empty(len(thetas))
@@ -506,6 +516,11 @@ class GpRegressor:
             g_cov[self._stat_slice] = g_stat[t]
             if self._wn_index is not None:
                 g_cov[self._wn_index] = 2.0 * ex[t] * trace_q[t]  # dK = 2 sigma^2 I (covariance.py:171-175)
+            if mdiag is not None:
+                # dK / d ln sigma_i = 2 sigma_i^2 e_i e_i^T (covariance.py:683-689): c1.(Z alpha) - c2.diag(Z K^-1) with
+                # Z = K^-1 dK collapses to 2 sigma_i^2 (p_i alpha_i - M_ii), M = K^-1 diag(c2) K^-1
+                g_cov[self._het_slice] = (2.0 * np.exp(2 * thetas[t][self.cov_slice][self._het_slice])
+                                          * (pvec[t] * alpha[t] - mdiag[t]))
             grads[t, self.cov_slice] = g_cov
         return values, grads
 
@@ -707,6 +722,43 @@ class GpRegressor:
                 g_cov[self._wn_index] = ex[t] * float(qdiag[t].sum())
             grads[t, self.cov_slice] = g_cov
         return lml, grads
+
+    def _mixture_loo_gradient_batch(self, thetas):
+        """`loo_likelihood_gradient` of a two-region ChangePoint model for T hyper-parameter vectors in one device call
+        (gpmi_loo_grad_batch_mix).  With Q = sym(p alpha^T) - K^-1 diag(c2) K^-1 the gradient of regression.py:509-514 is
+        sum Q o dK_j for every component: the sub-kernels' from the device contraction on the weight-scaled matrix, the
+        window parameters' from the device row sums h_m contracted here with d g_m / d phi as in `_mixture_gradient`
+        (doubled: the likelihood gradient carries a 1/2 that this one does not), WhiteNoise's 2 s^2 trace(Q)."""
+        cp = self._mix
+        T = len(thetas)
+        stat = [np.ascontiguousarray(t[self.cov_slice][self._stat_slice]) for t in thetas]
+        ex = np.array([float(np.exp(2 * t[self.cov_slice][self._wn_index])) if self._wn_index is not None else 0.0
+                       for t in thetas])
+        means = [self.mean.mean_and_gradients(t[self.mean_slice]) for t in thetas]
+        mean_kw = (dict(mu_const=thetas[:, 0]) if isinstance(self.mean, ConstantMean)
+                   else dict(mus=np.array([m[0] for m in means])))
+        args = [self._mix_args(s_) for s_ in stat]
+        alpha, ikdiag, pvec, mdiag, g_sub, hrows, info = self.engine.loo_grad_batch_mix(
+            args[0][0], [a[1] for a in args], np.array([a[2] for a in args]), ex, **mean_kw)
+        self._mix_fit_stale = True
+        if (info != 0).any():
+            raise LinAlgError("Matrix is not positive definite")  # regression.py:501 has no guard
+        values = np.empty(T)
+        grads = zeros((T, self.n_hyperpars))
+        for t in range(T):
+            var = 1.0 / ikdiag[t]
+            values[t] = float(-0.5 * (var * alpha[t] ** 2 + np.log(var)).sum())
+            g_cp = zeros(cp.n_params)
+            g_cp[: g_sub.shape[1]] = g_sub[t]
+            w, dws = cp.logistic_and_gradient(cp.x_cp, stat[t][cp.cp_slc[0]])
+            g_cp[cp.cp_slc[0]] = [2.0 * float((dw * (hrows[t, 1] - hrows[t, 0])).sum()) for dw in dws]
+            grads[t, self.mean_slice] = array([(pvec[t] * dmu).sum() for dmu in means[t][1]])
+            g_cov = zeros(self.cov.n_params)
+            g_cov[self._stat_slice] = g_cp
+            if self._wn_index is not None:
+                g_cov[self._wn_index] = 2.0 * ex[t] * float((pvec[t] * alpha[t] - mdiag[t]).sum())
+            grads[t, self.cov_slice] = g_cov
+        return values, grads
 
     # ---------------------------------------------------------------------------------
     # covariance functions that only implement the plugin ABC: the plugin's host methods make the dense
@@ -931,13 +983,14 @@ class GpRegressor:
         leave-one-out likelihood of a kernel with a fused device gradient and the problem is small enough for batched
         (lockstep) device evaluations; the values of a start are then those of `launch_bfgs` evaluated through the same
         batched kernels (`batch_independent_values`).  HeteroscedasticNoise - one variance per point and evaluation - rides
-        along for the marginal likelihood (gpmi_lml_grad_batch_noise), and so do two-region ChangePoint mixtures (window
-        weights per point and evaluation, gpmi_lml_grad_batch_mix).  Their leave-one-out gradients, mixtures over more
-        regions and mixtures with per-point noise have no batched kernels: those starts run one after another."""
+        along (gpmi_lml_grad_batch_noise; since round 5 also for the leave-one-out objective: gpmi_loo_grad_batch_noise), and
+        so do two-region ChangePoint mixtures (window weights per point and evaluation: gpmi_lml_grad_batch_mix, since
+        round 5 gpmi_loo_grad_batch_mix).  Mixtures over more regions and mixtures with per-point noise have no batched
+        kernels: those starts run one after another."""
         lml = self.model_selector_gradient == self.marginal_likelihood_gradient
         loo = self.model_selector_gradient == self.loo_likelihood_gradient
-        mix_ok = self._mix is None or (lml and self._mix.n_kernels == 2 and self._het_slice is None)
-        return ((lml or (loo and self._het_slice is None)) and not self._generic and mix_ok
+        mix_ok = self._mix is None or (self._mix.n_kernels == 2 and self._het_slice is None)
+        return ((lml or loo) and not self._generic and mix_ok
                 and self._y_cov is None and self.engine.capacity() <= 4096)
 
     def __str__(self):

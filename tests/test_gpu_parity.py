@@ -1694,6 +1694,57 @@ def test_gp_optimiser_reusing_hyperparameters(gp_mod):
     check_each(opt.gp.alpha, ref.alpha, 1e-9, what="alpha of the appended optimiser model")  # y_err = None: cond(K) ~ 1e10
 
 
+def test_change_point_loo_gradient_batch(golden, gp_mod):
+    """Round 5: the leave-one-out objective and gradient of two-region ChangePoint models (+ WhiteNoise) for a batch of
+    hyper-parameter vectors in lockstep (gpmi_loo_grad_batch_mix) against the reference (tests/golden/cpx.npz:
+    regression.py:489-526 with covariance.py:529-594) and against one-at-a-time evaluations through the dense path."""
+    g = golden("cpx")
+    x, y, e = g["x"], g["y"], g["y_err"]
+    rng = np.random.default_rng(13)
+    for tag, wn in (("sese", False), ("sesewn", True)):
+        cov = gp_mod.ChangePoint(kernels=[gp_mod.SquaredExponential, gp_mod.SquaredExponential])
+        if wn:
+            cov = cov + gp_mod.WhiteNoise()
+        th = g[f"{tag}_theta"]
+        gp2 = gp_mod.GpRegressor(x, y, y_err=e, kernel=cov, hyperpars=th)
+        thetas = np.vstack([th] + [th + 0.05 * rng.standard_normal(th.size) for _ in range(3)])
+        vals, grads = gp2.loo_likelihood_gradient_batch(thetas)
+        check(vals[0], g[f"{tag}_loo"], what="2-region loo, lockstep batch")
+        check_each(grads[0], g[f"{tag}_loo_grad"], what="2-region loo gradient, lockstep batch")
+        for t, v, gr in zip(thetas[1:], vals[1:], grads[1:]):
+            a, b = gp2.loo_likelihood_gradient(t)  # dense device path, one at a time
+            check(v, a, what="2-region loo: batch against single")
+            check_each(gr, b, what="2-region loo gradient: batch against single")
+        assert gp_mod.GpRegressor(x, y, y_err=e, kernel=cov, hyperpars=th, cross_val=True)._lockstep_search()
+
+
+def test_heteroscedastic_loo_gradient_batch(golden, gp_mod):
+    """Round 5: the leave-one-out objective and gradient of SE + HeteroscedasticNoise for a batch of hyper-parameter vectors in
+    lockstep (gpmi_loo_grad_batch_noise: every evaluation its own noise variances in the K-build, diag(K^-1 diag(c2) K^-1) back
+    for the per-point components) - against the reference's value and 99-component gradient (tests/golden/cpx.npz,
+    regression.py:489-526 with covariance.py:683-689) and against one-at-a-time evaluations through the dense path."""
+    g = golden("cpx")
+    xh, yh, eh = wl.synthetic_dataset(77, 96, 1)
+    thh = g["het_theta"]
+    gph = gp_mod.GpRegressor(xh, yh, y_err=eh, kernel=gp_mod.SquaredExponential() + gp_mod.HeteroscedasticNoise(), hyperpars=thh)
+    rng = np.random.default_rng(12)
+    thetas = np.vstack([thh] + [thh + 0.1 * rng.standard_normal(thh.size) for _ in range(4)])
+    vals, grads = gph.loo_likelihood_gradient_batch(thetas)
+    check(vals[0], g["het_loo"], what="heteroscedastic loo, lockstep batch")
+    check_each(grads[0], g["het_loo_grad"], what="heteroscedastic loo gradient, lockstep batch (99 components)")
+    for t, v, gr in zip(thetas[1:], vals[1:], grads[1:]):
+        a, b = gph.loo_likelihood_gradient(t)  # dense device path, one at a time
+        check(v, a, what="heteroscedastic loo: batch against single")
+        check_each(gr, b, what="heteroscedastic loo gradient: batch against single")
+    # a batch of one takes the same kernels
+    v1, g1 = gph.loo_likelihood_gradient_batch(thetas[2:3])
+    check(v1[0], vals[2], 1e-12, what="heteroscedastic loo: batch of one")
+    check(g1[0], grads[2], 1e-11, what="heteroscedastic loo gradient: batch of one")
+    # and the cross-validated search of such a model runs its starts in lockstep on it
+    assert gp_mod.GpRegressor(xh, yh, y_err=eh, kernel=gp_mod.SquaredExponential() + gp_mod.HeteroscedasticNoise(),
+                              hyperpars=thh, cross_val=True)._lockstep_search()
+
+
 # ---------------------------------------------------------------------------------------
 # gradients without a fused device kernel: dense device path + the objects' own derivative matrices
 # ---------------------------------------------------------------------------------------

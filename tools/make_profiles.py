@@ -29,6 +29,10 @@ rows = list(csv.DictReader(open(stats_of("bench"))))
 upd = next(r for r in rows if "gemm_dma_kernel<1, 0>" in r["Name"] or "gemm_nt_kernel<1, 0, 0, 128, 128>" in r["Name"])
 upd_us = float(upd["AverageNs"]) / 1e3
 
+for name, dst in (("pmc_stalls/summary.json", "pmc_stalls.json"), ("flow_trace_n8192.txt", "flow_trace_n8192.txt")):
+    src = os.path.join(go, name)
+    if os.path.exists(src) and os.path.getsize(src):
+        shutil.copy(src, os.path.join(pr, f"{tag}_{dst}"))
 for name in ("bench_kernel_stats_by_queue.csv",):
     src = os.path.join(go, name)
     if os.path.exists(src) and os.path.getsize(src):

@@ -8,7 +8,7 @@ rm -rf $GRAFT_REPO_ROOT/$out
 mkdir -p $GRAFT_REPO_ROOT/$out
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 # 1. headline: kernel trace + stats of the bench command, then the bench line itself (un-profiled)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-sharded > $out/bench_traced.json 2> $out/bench_traced.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-sharded --no-configs > $out/bench_traced.json 2> $out/bench_traced.err
 python3 tools/timeline_full.py $out/bench $out/bench_timeline.txt > /dev/null 2>&1
 python3 tools/by_queue.py $out/bench $out/bench_kernel_stats_by_queue.csv > /dev/null 2>&1
 timeout 300 python3 bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err
@@ -29,10 +29,15 @@ find $out -name "*kernel_trace.csv" -delete
 find $out -name "*agent_info.csv" -delete
 # 3. HBM traffic / MFMA counters: separate --pmc passes (tools/pmc_run.sh) of the headline command, of the LML gradient at
 #    N = 16384 (the fused contraction, the k-skipped SYRK) and of config 5's lockstep batches (potrf_diag, the batched updates)
-tools/pmc_run.sh $out/pmc_bench python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sharded > $out/pmc_bench.json 2> $out/pmc_bench.err
+tools/pmc_run.sh $out/pmc_bench python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sharded --no-configs > $out/pmc_bench.json 2> $out/pmc_bench.err
 tools/pmc_run.sh $out/pmc_grad python3 tools/grad_times.py 16384 > $out/pmc_grad.json 2> $out/pmc_grad.err
 tools/pmc_run.sh $out/pmc_cfg5 python3 tools/config5_bench.py 4 > $out/pmc_cfg5.json 2> $out/pmc_cfg5.err
 cp $out/pmc_bench/FETCH_SIZE.log $out/pmc_bench_line.txt 2>/dev/null
+# 4. where the dominant kernel's issue slots go: SQ wait / LDS / MFMA counters by queue (tools/pmc_stalls.sh)
+bash tools/pmc_stalls.sh $out/pmc_stalls > $out/pmc_stalls.log 2>&1
+# 5. the flag-ordered tail: chain step and task timings from in-kernel stamps (tools/flow_tr.sh)
+N=8192 bash tools/flow_tr.sh $out/flowt > $out/flow_trace_n8192.txt 2>&1
+rm -rf $out/flowt
 find $out -name "*counter_collection.csv" -delete
 find $out -name "*agent_info.csv" -delete
 ls -R $out | head -80

@@ -18,6 +18,9 @@ def lazy_panels(i, j, near=4):
     return max(e, 0)
 
 
+ZSPLIT = 1  # 4: every K = 512 chunk as four 64 x 64 quarter tasks (what-if)
+
+
 def build_tasks(m, near=4):
     """The decomposition of potrf_flow.hip: flow_build (which tasks exist is fixed: bit-identity with the stream-ordered
     factorisation).  Returns list of dicts."""
@@ -36,7 +39,13 @@ def build_tasks(m, near=4):
     for i in range(m):
         for j in range(i + 1):
             for q in range(lazy_panels(i, j, near)):
-                tasks.append(dict(t="Z", i=i, j=j, k=q, s=0, add=4 * OBT))
+                if ZSPLIT == 1:
+                    tasks.append(dict(t="Z", i=i, j=j, k=q, s=0, add=4 * OBT))
+                else:
+                    for s in range(4):
+                        if i == j and s == 1:
+                            continue
+                        tasks.append(dict(t="Z", i=i, j=j, k=q, s=s, add=(2 if (i == j and s == 0) else 1) * OBT))
     return tasks
 
 
@@ -77,7 +86,7 @@ def simulate(m, lists, mod=Model, near=4, verbose=False):
             return DD[0] >= k + 1 and F[i][k] == 4 * k
         if ty == "U":
             return Lcnt[i] >= 4 * (k + 1) and Lcnt[j] >= 4 * (k + 1) and F[i][j] >= 4 * k
-        return Lcnt[i] >= 4 * OBT * (k + 1) and Lcnt[j] >= 4 * OBT * (k + 1) and F[i][j] == 4 * OBT * k
+        return Lcnt[i] >= 4 * OBT * (k + 1) and Lcnt[j] >= 4 * OBT * (k + 1) and F[i][j] >= 4 * OBT * k
 
     pos = [0] * nw
     busy = [False] * nw
@@ -210,16 +219,6 @@ def shipped_lists(m, nwg=448, near_d=3, near_wgs=32, near=4):
     return lists
 
 
-if __name__ == "__main__":
-    m = int(sys.argv[1]) if len(sys.argv) > 1 else 48
-    lists = shipped_lists(m)
-    print("tasks", sum(len(l) for l in lists))
-    r = simulate(m, lists)
-    print(f"shipped: total {r['total']:.0f} us, chain stalls {r['stall']:.0f} us, workgroup utilisation {r['util']:.2f}")
-    ce = r["col_ends"]
-    print("panel periods:", [round(ce[k + 4] - ce[k]) for k in range(3, m - 4, 4)])
-
-
 # ---- dependency graph + list scheduling ("simulate, then freeze") ------------------------------------------------------
 def graph(m, tasks, near=4):
     """preds[n] = list of task indices / ('L', k) chain launch starts / ('D', k) potrf_diag ends that task n waits for;
@@ -227,6 +226,9 @@ def graph(m, tasks, near=4):
     idx = {}
     for n, x in enumerate(tasks):
         idx[(x["t"], x["i"], x["j"], x["k"], x["s"])] = n
+
+    def zq(i, j, q):
+        return [idx[("Z", i, j, q, s)] for s in range(4) if ("Z", i, j, q, s) in idx]
 
     def subs(i, j, k):  # the sub-updates of column k on tile (i, j)
         return [idx[("U", i, j, k, s)] for s in range(4) if not (i == j and s == 1)]
@@ -237,7 +239,7 @@ def graph(m, tasks, near=4):
         if upto - 1 >= OBT * lz and upto >= 1 and ("U", i, j, upto - 1, 0) in idx:
             return subs(i, j, upto - 1)
         if lz > 0 and upto >= OBT * lz:
-            return [idx[("Z", i, j, lz - 1, 0)]]
+            return zq(i, j, lz - 1)
         return []
 
     def row_col(i, k):  # L(i, k) final
@@ -255,7 +257,7 @@ def graph(m, tasks, near=4):
         else:
             p = row_col(i, OBT * k + OBT - 1) + row_col(j, OBT * k + OBT - 1)
             if k > 0:
-                p.append(idx[("Z", i, j, k - 1, 0)])
+                p += zq(i, j, k - 1)
         preds.append(p)
     chain_preds = []
     for k in range(m):
@@ -431,20 +433,46 @@ def heft_lists(m, nwg=448, short_wgs=64, mod=Model, near=4, zprio=1.0, verbose=F
     return lists
 
 
+def write_lists(path, m, lists):
+    """<prefix>_m<m>.bin for GPMI_FLOW_LISTS (potrf_flow.hip: flow_lists_override)"""
+    import struct
+
+    code = {"T": 0, "U": 1, "Z": 2}
+    off = [0]
+    body = b""
+    for l in lists:
+        for x in l:
+            body += struct.pack("<4B4H", code[x["t"]], x["s"], x["add"], 0, x["i"], x["j"] if x["t"] != "T" else 0, x["k"], 0)
+        off.append(off[-1] + len(l))
+    with open(path, "wb") as f:
+        f.write(struct.pack("<3i", m, len(lists), off[-1]))
+        f.write(struct.pack(f"<{len(off)}i", *off))
+        f.write(body)
+
+
 if __name__ == "__main__":
-    # slack of every chunk from the unlimited-workgroup schedule: ASAP start there against ALAP start (makespan - rank)
-    heft_lists(m, nwg=20000, short_wgs=10000)
-    info = heft_lists.last
-    slack = {}
-    for n, x in enumerate(info["tasks"]):
-        if x["t"] == "Z":
-            slack[(x["t"], x["i"], x["j"], x["k"], x["s"])] = info["makespan"] - info["rank"][n] - x["sim_start"]
-    import statistics
-    sl = sorted(slack.values())
-    print("chunk slack (us): min %.0f, 10%% %.0f, median %.0f, 90%% %.0f" % (sl[0], sl[len(sl)//10], statistics.median(sl), sl[9*len(sl)//10]))
-    for thr in (50, 150, 300):
-        urgent = {k for k, v in slack.items() if v < thr}
-        for sw, uw in ((32, 32), (32, 64), (32, 96), (64, 64)):
-            lists = heft_lists(m, short_wgs=sw, urgent_wgs=uw, urgent=urgent)
-            r = simulate(m, lists)
-            print(f"slack<{thr} ({len(urgent)} chunks) short_wgs={sw} urgent_wgs={uw}: total {r['total']:.0f} us, chain stalls {r['stall']:.0f}, util {r['util']:.2f}")
+    import argparse
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("m", type=int, nargs="?", default=48)
+    ap.add_argument("--policy", default="both", choices=["shipped", "heft", "both"])
+    ap.add_argument("--short", type=int, default=64, help="workgroups that never take a K = 512 chunk")
+    ap.add_argument("--nwg", type=int, default=448)
+    ap.add_argument("--write", help="file prefix: writes <prefix>_m<m>.bin (the heft lists) for GPMI_FLOW_LISTS")
+    a = ap.parse_args()
+    m = a.m
+    if a.policy in ("shipped", "both"):
+        lists = shipped_lists(m, a.nwg)
+        r = simulate(m, lists)
+        ce = r["col_ends"]
+        print(f"shipped: {sum(len(l) for l in lists)} tasks, total {r['total']:.0f} us, chain stalls {r['stall']:.0f} us, workgroup "
+              f"utilisation {r['util']:.2f}; panel periods {[round(ce[k + 4] - ce[k]) for k in range(3, m - 4, 4)]}")
+    if a.policy in ("heft", "both"):
+        lists = heft_lists(m, a.nwg, short_wgs=a.short, verbose=True)
+        r = simulate(m, lists)
+        ce = r["col_ends"]
+        print(f"heft (short-only workgroups {a.short}): total {r['total']:.0f} us, chain stalls {r['stall']:.0f} us, utilisation "
+              f"{r['util']:.2f}; panel periods {[round(ce[k + 4] - ce[k]) for k in range(3, m - 4, 4)]}")
+        if a.write:
+            write_lists(f"{a.write}_m{m}.bin", m, lists)
+            print("wrote", f"{a.write}_m{m}.bin")
