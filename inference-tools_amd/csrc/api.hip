@@ -387,8 +387,19 @@ int enqueue_inverse_factor(gpmi_ctx* c, Lane& L, Lane& F) {
 // workspace for `want` small problems advancing in lockstep (capped by a 6 GiB budget)
 int ensure_batch_ws(gpmi_ctx* c, int want) {
   const int64_t per = c->np * c->ld * (int64_t)sizeof(double);
-  int cap = (int)((6LL << 30) / per);
-  if (cap > 256) cap = 256;
+  // matrices of one lockstep chunk: GPMI_BATCH_GIB (GiB of them) and GPMI_BATCH_MAX (their number) bound the workspace
+  static const int64_t budget_gib = [] {
+    const char* e = std::getenv("GPMI_BATCH_GIB");
+    const int v = e ? std::atoi(e) : 6;
+    return (int64_t)(v >= 1 && v <= 200 ? v : 6);
+  }();
+  static const int max_chunk = [] {
+    const char* e = std::getenv("GPMI_BATCH_MAX");
+    const int v = e ? std::atoi(e) : 256;
+    return v >= 2 && v <= 4096 ? v : 256;
+  }();
+  int cap = (int)((budget_gib << 30) / per);
+  if (cap > max_chunk) cap = max_chunk;
   if (cap < 1) cap = 1;
   if (want > cap) want = cap;
   if (want <= c->bcap) return GPMI_OK;

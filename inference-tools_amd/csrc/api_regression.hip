@@ -75,7 +75,7 @@ int gpmi_lml_batch(gpmi_ctx* c, int kernel, int64_t T, const double* thetas, int
     // whole chunk (blockIdx.z), instead of one latency-bound launch sequence per evaluation
     ARGCHK(c, c->bpend[0] == 0 && c->bpend[1] == 0,
            "gpmi_lml_batch: an asynchronous batch is pending on this handle (gpmi_lml_batch_wait first)");
-    if (int rc = ensure_batch_ws(c, (int)(T < 256 ? (T < 2 ? 2 : T) : 256))) return rc;
+    if (int rc = ensure_batch_ws(c, (int)(T < 2 ? 2 : (T > 4096 ? 4096 : T)))) return rc;  // (capped by ensure_batch_ws)
     // A chunk runs as TWO half-batches on two streams (the chunk's workspace split in the middle): while one half is in
     // a latency-bound step - potrf_diag: one workgroup per matrix, 32 of 256 CUs for a half of 32 - the other half's
     // GEMM launches fill the chip.  A value does not depend on the batch it is evaluated in (§4.3), so the split is

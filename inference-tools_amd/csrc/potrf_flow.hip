@@ -1240,7 +1240,8 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
     std::fprintf(stderr,
                  "[flow] m=%d tasks=%llu polls=%llu | per workgroup: waiting %.1f us, in tasks %.1f us | chain waited: "
                  "Tc %.1f us, Uc %.1f us\n",
-                 m, h[3], h[2], h[0] * 0.01 / grid.x, h[1] * 0.01 / grid.x, h[4] * 0.01 / 4.0, h[5] * 0.01 / 3.0);
+                 m, h[3], h[2], h[0] * 0.01 / grid.x, h[1] * 0.01 / grid.x,
+                 h[4] * 0.01 / (env_int("GPMI_CHAIN_TILES", 3) == 3 ? (double)CC_WORKERS : 4.0), h[5] * 0.01 / 3.0);
   }
   return true;
 }

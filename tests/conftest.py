@@ -67,3 +67,11 @@ def pytest_terminal_summary(terminalreporter):
     tr.write_line(f"{len(worst)} quantities, {len(rows)} comparisons in all; the 30 closest to their tolerance, worst last:")
     for (test, what), (r, tol) in ranked[-30:]:
         tr.write_line(f"{r:9.2e}  (tol {tol:7.1e})  {test} :: {what}")
+    # GPMI_PARITY_TABLE=<file>: the whole table (profiles/rNN_parity_errors.txt is such a file)
+    path = os.environ.get("GPMI_PARITY_TABLE")
+    if path:
+        with open(path, "w") as f:
+            f.write(f"# achieved parity errors of one `pytest -m gpu` run: {len(worst)} quantities, {len(rows)} comparisons; "
+                    "max per test / quantity, closest to the tolerance last\n")
+            for (test, what), (r, tol) in ranked:
+                f.write(f"{r:9.2e}  (tol {tol:7.1e})  {test} :: {what}\n")
