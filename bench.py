@@ -450,7 +450,7 @@ def sharded_configs(args, wl, sharding, rank, world, local_rank, rdv, gather, en
         out = fn()
         dt = time.perf_counter() - t0
         if rdv is not None:
-            dt = max(float(v) for v in rdv.allgather_obj(dt))
+            dt = max(float(v) for v in rdv.allgather_obj(dt, tag="sharded seconds"))
         return dt, out
 
     res = {"gather": gather, "note": "measured after the timed headline region; one process per GPU, contiguous blocks of "
@@ -625,7 +625,7 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
         ident = _lib.device_identity(dev_index) or (
             f"index {dev_index} under HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')} "
             f"ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')}")
-        where = rdv.allgather_obj(f"{socket.gethostname()}:{ident}")
+        where = rdv.allgather_obj(f"{socket.gethostname()}:{ident}", tag="device identity")
         if len(set(where)) < world:
             ok, why = False, "ranks share a device (RCCL refuses duplicate devices)"
         else:
@@ -638,7 +638,7 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
             else:
                 ok, why = box.get("ok", False), box.get("why", "")
         # every rank must take the same path
-        oks = rdv.allgather_obj(ok)
+        oks = rdv.allgather_obj(ok, tag="rccl bootstrap")
         gather = "rccl" if all(oks) else f"file-fallback ({'; '.join(str(o) for o in oks)}{'' if ok else ' ' + why})"
         if gather == "rccl":
             # the start-up distribution of SURVEY section 8(e) on the live communicator: rank 0's data set to every rank by
@@ -663,14 +663,14 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                 STUCK.append(True)
                 RCCL_INFO["dataset_broadcast"] = "did not return within the time limit"
             # a rank whose collective never returned takes every rank off the communicator
-            if any(rdv.allgather_obj(alive)):
+            if any(rdv.allgather_obj(alive, tag="rccl start-up")):
                 gather = "file-fallback (the start-up broadcast over RCCL did not return on every rank)"
             RCCL_INFO["rccl_ranks_match"] = RCCL_INFO.get("rccl_ranks_seen") == world
 
     def allgather(vec):
         if gather == "rccl":
             return eng.comm_allgather(vec)  # RCCL over xGMI: the only collective of the path
-        return np.array(rdv.allgather_obj(np.asarray(vec, dtype=float)))
+        return np.array(rdv.allgather_obj(np.asarray(vec, dtype=float), tag=f"values {np.size(vec)}"))
 
     def step():
         gp.set_hyperparameters(theta)  # K-build + potrf + alpha
@@ -726,6 +726,11 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                                       eng if gather == "rccl" else None, _lib)
         except Exception as err:  # the headline line must not be lost to a failure behind the timed region
             sharded = {"error": f"{type(err).__name__}: {err}"}
+            print(f"bench.py rank {rank}: the sharded configurations failed: {type(err).__name__}: {err}", file=sys.stderr, flush=True)
+            # this rank skips the exchanges the others are in: tell them, or they wait for the time limit and then read this
+            # rank's closing barrier as the payload of the exchange it skipped
+            if rdv is not None and not getattr(rdv, "aborted", False):
+                rdv.abort(f"sharded configurations: {type(err).__name__}: {err}")
 
     if rank == 0:
         ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0

@@ -158,7 +158,8 @@ def _gather_rows(local, per, width, engine):
         out = [torch.empty_like(buf) for _ in range(size)]
         dist.all_gather(out, buf)
         return np.stack([t.cpu().numpy() for t in out])
-    return np.stack([np.asarray(a, dtype=float).reshape(per, width) for a in _default_rdv.allgather_obj(send)])
+    return np.stack([np.asarray(a, dtype=float).reshape(per, width)
+                     for a in _default_rdv.allgather_obj(send, tag=f"rows {per}x{width}")])
 
 
 def sharded_map(batch_fn, items, width: int = 1, engine=None):
@@ -289,6 +290,15 @@ def _decode(obj):
     return obj
 
 
+class RendezvousAborted(RuntimeError):
+    """Another rank left the job early (`FileRendezvous.abort`): every pending and later exchange raises this at once
+    instead of waiting for files that will never appear."""
+
+
+class RendezvousDesync(RuntimeError):
+    """The ranks are not in the same exchange: a payload arrived under another tag than the reader's own."""
+
+
 class FileRendezvous:
     """Torch-free bootstrap for the ranks of ONE node (what `torch.distributed.run --nnodes=1` or
     `bench.py --gpus N` launches): exchanges small JSON payloads through a per-job directory.  Used
@@ -317,6 +327,7 @@ class FileRendezvous:
         self._open_dir()
         self.round = 0
         self.closed = False
+        self.aborted = False
         # Generation handshake, robust against the files of a crashed job with the same key: every other rank
         # keeps (re)writing a `hello` file with a fresh random token until it finds a `gen` file that quotes
         # its token; rank 0 first removes whatever is in the directory, then waits for every rank's hello
@@ -374,8 +385,9 @@ class FileRendezvous:
             json.dump(_encode(obj), f)
         os.replace(path + ".tmp", path)
 
-    def _read(self, name, t0):
+    def _read(self, name, t0, watch_abort=True):
         path = os.path.join(self.dir, name)
+        polls = 0
         while True:
             try:
                 with open(path) as f:
@@ -383,21 +395,59 @@ class FileRendezvous:
             except (FileNotFoundError, ValueError):  # not there yet, half-written or not JSON at all
                 if time.time() - t0 > self.timeout:
                     raise TimeoutError(f"rendezvous file {name} did not appear within {self.timeout:.0f} s")
+                polls += 1
+                if watch_abort and polls % 25 == 0:
+                    self._check_abort()
                 time.sleep(0.002)
 
-    def allgather_obj(self, obj):
+    def _check_abort(self):
+        gen = getattr(self, "gen", None)
+        if gen is None:
+            return
+        for name in os.listdir(self.dir):
+            if name.startswith(f"{gen}.abort."):
+                try:
+                    with open(os.path.join(self.dir, name)) as f:
+                        why = json.load(f)
+                except (OSError, ValueError):
+                    why = "?"
+                self.aborted = True
+                raise RendezvousAborted(f"rank {name.rsplit('.', 1)[-1]} left the job: {why}")
+
+    def abort(self, reason=""):
+        """Tell every rank that this one will not take part in further exchanges (it failed): their pending and later
+        reads raise RendezvousAborted at once.  Without it a rank that skips an exchange leaves the others waiting for the
+        time limit - and its NEXT exchange (the closing barrier) is read by them as the payload of the one it skipped."""
+        self.aborted = True
+        try:
+            self._write(f"{self.gen}.abort.{self.rank}", str(reason)[:500])
+        except (OSError, AttributeError):
+            pass
+
+    def allgather_obj(self, obj, tag=""):
         """Every rank contributes a JSON-representable object (numbers, strings, bytes, lists, dicts,
-        float arrays); returns the list in rank order."""
+        float arrays); returns the list in rank order.  `tag` names the exchange: a payload written under another tag
+        means the ranks are out of step (one of them skipped or added an exchange) and raises RendezvousDesync instead
+        of being mistaken for this exchange's data."""
+        if getattr(self, "aborted", False):
+            raise RendezvousAborted("the job was aborted")
         self.round += 1
-        self._write(f"{self.gen}.r{self.round}.{self.rank}", obj)
+        self._write(f"{self.gen}.r{self.round}.{self.rank}", {"tag": str(tag), "v": obj})
         t0 = time.time()
-        return [self._read(f"{self.gen}.r{self.round}.{r}", t0) for r in range(self.world)]
+        out = []
+        for r in range(self.world):
+            got = self._read(f"{self.gen}.r{self.round}.{r}", t0)
+            if not isinstance(got, dict) or got.get("tag") != str(tag):
+                raise RendezvousDesync(f"exchange {self.round} ({tag!r}): rank {r} is in "
+                                       f"{got.get('tag') if isinstance(got, dict) else got!r}")
+            out.append(got["v"])
+        return out
 
     def broadcast_obj(self, obj, src=0):
-        return self.allgather_obj(obj if self.rank == src else None)[src]
+        return self.allgather_obj(obj if self.rank == src else None, tag="broadcast")[src]
 
     def barrier(self):
-        self.allgather_obj(0)
+        self.allgather_obj(0, tag="barrier")
 
     def close(self):
         """Leave the rendezvous.  Two rounds: after the first every rank has read everything it will
@@ -407,13 +457,20 @@ class FileRendezvous:
             return
         self.closed = True
         try:
-            self.barrier()
+            if not getattr(self, "aborted", False):
+                try:
+                    self.barrier()
+                except (RendezvousAborted, RendezvousDesync):
+                    pass
             self._write(f"{self.gen}.done.{self.rank}", 1)
             if self.rank == 0:
+                # (after an abort: a short wait, so that ranks still polling see the abort file before it is removed)
+                if getattr(self, "aborted", False):
+                    self.timeout = min(self.timeout, 20.0)
                 t0 = time.time()
                 for r in range(self.world):
-                    self._read(f"{self.gen}.done.{r}", t0)
-        except (TimeoutError, OSError):
+                    self._read(f"{self.gen}.done.{r}", t0, watch_abort=False)
+        except (TimeoutError, OSError, AttributeError):
             pass  # a peer died: clean up what we can
         if self.rank == 0:
             self._purge(everything=True)

@@ -50,6 +50,52 @@ def test_file_rendezvous_two_processes(tmp_path, late_rank):
     assert not any(n.startswith("gpmi_rdv_") for n in os.listdir(tmp_path))  # cleaned up
 
 
+def _worker_fail(rank, world, tmp, q, mode):
+    import time
+
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "inference-tools_amd")]
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_PORT="29998", GPMI_RDV_DIR=tmp, GPMI_RDV_KEY="t2")
+    from inference_amd.sharding import FileRendezvous, RendezvousAborted, RendezvousDesync
+
+    rdv = FileRendezvous(timeout=60.0)
+    t0 = time.time()
+    try:
+        rdv.allgather_obj(rank, tag="first")
+        if mode == "abort" and rank == 1:
+            rdv.abort("a failure of rank 1")       # skips the exchange the others enter next
+        elif mode == "desync" and rank == 1:
+            rdv.allgather_obj(0, tag="barrier")    # ... or enters ANOTHER exchange in its place
+        else:
+            rdv.allgather_obj([1.0, 2.0], tag="values")
+        q.put((rank, "ok", time.time() - t0))
+    except RendezvousAborted as err:
+        q.put((rank, "aborted: " + str(err), time.time() - t0))
+    except RendezvousDesync as err:
+        q.put((rank, "desync: " + str(err), time.time() - t0))
+    finally:
+        rdv.close()
+
+
+@pytest.mark.parametrize("mode", ["abort", "desync"])
+def test_rendezvous_abort_and_desync_are_detected_at_once(tmp_path, mode):
+    """Round 5 (what the first cold 8-rank bench run did): a rank that fails and skips an exchange no longer leaves the
+    others waiting for the time limit, and its next exchange is never read as the payload of the one it skipped -
+    `abort` ends the others' waits with RendezvousAborted, a payload under another tag raises RendezvousDesync."""
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_fail, args=(r, 3, str(tmp_path), q, mode)) for r in range(3)]
+    [p.start() for p in procs]
+    res = dict((r, (what, dt)) for r, what, dt in (q.get(timeout=50) for _ in range(3)))
+    [p.join(40) for p in procs]
+    assert [p.exitcode for p in procs] == [0, 0, 0]
+    assert all(dt < 10.0 for _, dt in res.values()), res  # nobody sat out the 60 s time limit
+    if mode == "abort":
+        assert res[1][0] == "ok" and res[0][0].startswith("aborted") and "a failure of rank 1" in res[2][0], res
+    else:
+        assert all(v[0].startswith("desync") for v in res.values()), res
+    assert not any(n.startswith("gpmi_rdv_") for n in os.listdir(tmp_path))  # cleaned up
+
+
 def test_rendezvous_refuses_foreign_or_open_directory(tmp_path, monkeypatch):
     from inference_amd.sharding import FileRendezvous
 
