@@ -726,7 +726,10 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                                       eng if gather == "rccl" else None, _lib)
         except Exception as err:  # the headline line must not be lost to a failure behind the timed region
             sharded = {"error": f"{type(err).__name__}: {err}"}
-            print(f"bench.py rank {rank}: the sharded configurations failed: {type(err).__name__}: {err}", file=sys.stderr, flush=True)
+            import traceback
+
+            print(f"bench.py rank {rank}: the sharded configurations failed: {type(err).__name__}: {err}\n"
+                  + "".join(traceback.format_exc(limit=8)), file=sys.stderr, flush=True)
             # this rank skips the exchanges the others are in: tell them, or they wait for the time limit and then read this
             # rank's closing barrier as the payload of the exchange it skipped
             if rdv is not None and not getattr(rdv, "aborted", False):

@@ -114,7 +114,7 @@ int lane_alloc(gpmi_ctx* c, Lane& L) {
   HIPCHK(c, hipMalloc(&L.invD, sizeof(double) * nt * GPMI_NB * GPMI_NB));
   // potrf_diag writes the block-lower part of an inverse only: the zeros above stay from here (round 4: zeroing them
   // in the kernel cost it 57 KB of stores per launch through one CU's memory path, as much as loading the block)
-  HIPCHK(c, hipMemset(L.invD, 0, sizeof(double) * nt * GPMI_NB * GPMI_NB));
+  ZERO_SYNC(c, L.invD, sizeof(double) * nt * GPMI_NB * GPMI_NB);
   HIPCHK(c, hipMalloc(&L.vec, sizeof(double) * 4 * c->np));
   HIPCHK(c, hipMalloc(&L.red, sizeof(double) * 2 * RED_SLOTS));
   HIPCHK(c, hipMalloc(&L.info, sizeof(int) * RED_SLOTS));
@@ -440,7 +440,7 @@ int ensure_batch_ws(gpmi_ctx* c, int want) {
   const int64_t nt = c->np / GPMI_NB;
   HIPCHK(c, hipMalloc(&c->bA, sizeof(double) * want * c->np * c->ld));
   HIPCHK(c, hipMalloc(&c->bInv, sizeof(double) * want * nt * GPMI_NB * GPMI_NB));
-  HIPCHK(c, hipMemset(c->bInv, 0, sizeof(double) * want * nt * GPMI_NB * GPMI_NB));  // see lane_alloc
+  ZERO_SYNC(c, c->bInv, sizeof(double) * want * nt * GPMI_NB * GPMI_NB);  // see lane_alloc
   HIPCHK(c, hipMalloc(&c->bVec, sizeof(double) * want * 4 * c->np));
   HIPCHK(c, hipMalloc(&c->bRed, sizeof(double) * 2 * want));
   HIPCHK(c, hipMalloc(&c->bMu, sizeof(double) * want * c->np));
@@ -667,9 +667,9 @@ int gpmi_set_data(gpmi_ctx* c, const double* x, const double* y, const double* n
   HIPCHK(c, hipMalloc(&c->y, sizeof(double) * c->np));
   HIPCHK(c, hipMalloc(&c->noise, sizeof(double) * c->np));
   HIPCHK(c, hipMalloc(&c->alpha, sizeof(double) * c->np));
-  HIPCHK(c, hipMemset(c->x, 0, sizeof(double) * c->np * d));
-  HIPCHK(c, hipMemset(c->y, 0, sizeof(double) * c->np));
-  HIPCHK(c, hipMemset(c->noise, 0, sizeof(double) * c->np));
+  ZERO_SYNC(c, c->x, sizeof(double) * c->np * d);
+  ZERO_SYNC(c, c->y, sizeof(double) * c->np);
+  ZERO_SYNC(c, c->noise, sizeof(double) * c->np);
   HIPCHK(c, hipMemcpy(c->x, x, sizeof(double) * n * d, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->y, y, sizeof(double) * n, hipMemcpyHostToDevice));
   if (y_cov) {
@@ -894,7 +894,7 @@ int gpmi_dev_potrf(gpmi_ctx* c, double* A, int64_t n, int64_t ld, int* info) {
   double* invD = nullptr;
   int* dinfo = nullptr;
   HIPCHK(c, hipMalloc(&invD, sizeof(double) * (n / GPMI_NB) * GPMI_NB * GPMI_NB));
-  HIPCHK(c, hipMemset(invD, 0, sizeof(double) * (n / GPMI_NB) * GPMI_NB * GPMI_NB));  // see lane_alloc
+  ZERO_SYNC(c, invD, sizeof(double) * (n / GPMI_NB) * GPMI_NB * GPMI_NB);  // see lane_alloc
   HIPCHK(c, hipMalloc(&dinfo, sizeof(int)));
   HIPCHK(c, hipMemsetAsync(dinfo, 0, sizeof(int), s));
   if (n == GPMI_NB && std::getenv("GPMI_DIAG_STAMPS")) {

@@ -31,11 +31,25 @@
     }                          \
   } while (0)
 
+// hipMemset on device memory returns once the fill is ENQUEUED in the null stream, and the library's streams are
+// non-blocking: they do not wait for the null stream.  A buffer whose zeros later kernels rely on (the upper 16-blocks
+// of the inverse diagonal blocks, the padding of x / y / noise, the zero vectors) is therefore zeroed AND waited for.
+// (Round 5: with eight processes time-slicing one device the fill of `invD` arrived milliseconds late and wiped inverse
+// blocks that potrf_diag had already written - pivot failures in the second or third diagonal block, a few per
+// thousand evaluations; with the device to itself the fill always won the race.)
+#define ZERO_SYNC(ctx, ptr, bytes)                          \
+  do {                                                      \
+    HIPCHK(ctx, hipMemset((ptr), 0, (bytes)));              \
+    HIPCHK(ctx, hipStreamSynchronize(nullptr));             \
+  } while (0)
+
 // a negative `info` is written by the flag-ordered kernels when a poll timed out: GPMI_INFO_FLOW_TIMEOUT by the tile-task
 // factorisation (potrf_flow.hip) - the one case the stream-ordered schedule (GPMI_OPT_NO_FLOW) cures, marked "[flow-tail]"
 // in the error text for the caller that wants to repeat the call -, GPMI_ERR_INTERNAL by the triangular sweeps
 #define INFOCHK(ctx, inf)                                                                                     \
   do {                                                                                                        \
+    if ((inf) != 0 && std::getenv("GPMI_DEBUG_INFO"))                                                         \
+      std::fprintf(stderr, "[gpmi] %s: info = %d (n = %lld)\n", __func__, (int)(inf), (long long)(ctx)->n);    \
     if ((inf) < 0) {                                                                                          \
       (ctx)->err = (inf) == GPMI_INFO_FLOW_TIMEOUT                                                            \
                        ? "internal error: the tile-task factorisation timed out [flow-tail]"                  \

@@ -26,7 +26,7 @@ __global__ void linv_add_diag_kernel(double* __restrict__ J, int64_t ld, const d
 int linv_alloc(gpmi_ctx* c, double** p, int64_t doubles) {
   if (*p) return GPMI_OK;
   HIPCHK(c, hipMalloc(p, sizeof(double) * doubles));
-  HIPCHK(c, hipMemset(*p, 0, sizeof(double) * doubles));  // (the inverses' upper 16-blocks rely on it, see lane_alloc)
+  ZERO_SYNC(c, *p, sizeof(double) * doubles);  // (the inverses' upper 16-blocks rely on it, see lane_alloc)
   return GPMI_OK;
 }
 
@@ -99,10 +99,10 @@ int gpmi_linv_set(gpmi_ctx* c, const double* A, int64_t m, const double* y, cons
   if (int rc = linv_alloc(c, &S.J, mp * ldm)) return rc;
   if (int rc = linv_alloc(c, &S.invD, (mp / GPMI_NB) * GPMI_NB * GPMI_NB)) return rc;
   if (int rc = linv_alloc(c, &S.vec, 8 * vmax)) return rc;
-  HIPCHK(c, hipMemset(S.A, 0, sizeof(double) * mp * ld));
-  HIPCHK(c, hipMemset(S.At, 0, sizeof(double) * np * ldm));
-  HIPCHK(c, hipMemset(S.y, 0, sizeof(double) * mp));
-  HIPCHK(c, hipMemset(S.zero, 0, sizeof(double) * np));
+  ZERO_SYNC(c, S.A, sizeof(double) * mp * ld);
+  ZERO_SYNC(c, S.At, sizeof(double) * np * ldm);
+  ZERO_SYNC(c, S.y, sizeof(double) * mp);
+  ZERO_SYNC(c, S.zero, sizeof(double) * np);
   HIPCHK(c, hipMemcpy2D(S.A, sizeof(double) * ld, A, sizeof(double) * n, sizeof(double) * n, m,
                         hipMemcpyHostToDevice));
   std::vector<double> at((size_t)n * m), s2((size_t)mp, 1.0);

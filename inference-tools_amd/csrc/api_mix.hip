@@ -22,7 +22,7 @@ int mix_prepare(gpmi_ctx* c, int nk, const int* kernels, const double* thetas, c
   if (!c->mix_scratch) HIPCHK(c, hipMalloc(&c->mix_scratch, sizeof(double) * c->np * c->ld));
   if (!c->mix_zero) {
     HIPCHK(c, hipMalloc(&c->mix_zero, sizeof(double) * c->np));
-    HIPCHK(c, hipMemset(c->mix_zero, 0, sizeof(double) * c->np));
+    ZERO_SYNC(c, c->mix_zero, sizeof(double) * c->np);
   }
   if (int rc = gpmi_sync(c)) return rc;  // nothing may still be reading the previous weights
   std::vector<double> g((size_t)nk * c->np);
@@ -241,7 +241,7 @@ int gpmi_lml_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
   if (int rc = ensure_batch_grad_ws(c, c->bcap, nk * W - 1)) return rc;
   if (!c->mix_zero) {
     HIPCHK(c, hipMalloc(&c->mix_zero, sizeof(double) * c->np));
-    HIPCHK(c, hipMemset(c->mix_zero, 0, sizeof(double) * c->np));
+    ZERO_SYNC(c, c->mix_zero, sizeof(double) * c->np);
   }
   const int cap = c->bgrad_cap;
   if (c->bMix_cap < cap) {
@@ -406,7 +406,7 @@ int gpmi_loo_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
   if (int rc = ensure_batch_grad_ws(c, c->bcap, nk * W - 1)) return rc;
   if (!c->mix_zero) {
     HIPCHK(c, hipMalloc(&c->mix_zero, sizeof(double) * c->np));
-    HIPCHK(c, hipMemset(c->mix_zero, 0, sizeof(double) * c->np));
+    ZERO_SYNC(c, c->mix_zero, sizeof(double) * c->np);
   }
   const int cap = c->bgrad_cap;
   if (c->bMix_cap < cap) {

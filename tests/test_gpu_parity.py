@@ -739,7 +739,7 @@ def test_bench_eight_ranks_on_one_device(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
     env.update(BENCH_CFG3_POINTS="8", BENCH_CFG5_LADDERS="8", BENCH_CFG5_STEPS="4", BENCH_CFG3_N="4096",
-               GPMI_RDV_DIR=str(tmp_path), MASTER_PORT="29533")
+               GPMI_RDV_DIR=str(tmp_path), MASTER_PORT="29533", GPMI_DEBUG_INFO="1")
     run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
                           "--n", "4096", "--m", "256"], env=env, capture_output=True, text=True, timeout=900)
     assert run.returncode == 0, run.stderr[-3000:]
@@ -751,7 +751,7 @@ def test_bench_eight_ranks_on_one_device(tmp_path):
     assert line["config"]["gather_schedule"] == "once_at_end"
     assert line["config"]["rank_cpu"]["cores_per_rank"] >= 1
     sh = line["sharded"]
-    assert "error" not in sh and sh["config3"]["lml_evals_per_s"] > 0 and sh["config5"]["lml_evals_per_s"] > 0, (sh, run.stderr[-3000:])
+    assert "error" not in sh and sh["config3"]["lml_evals_per_s"] > 0 and sh["config5"]["lml_evals_per_s"] > 0, (sh, [l for l in run.stderr.splitlines() if "[gpmi]" in l or "Error" in l or "line " in l][-40:])
     assert np.isfinite(line["value"]) and line["value"] > 0
     assert glob.glob(str(tmp_path / "*")) == [], "the rendezvous directory is removed at the end"
 
