@@ -323,18 +323,35 @@ void potrf_lower_batched(gpmi_ctx* c, hipStream_t s, double* A, int64_t np, int6
   GemmBatch inplace{bs.count, bs.sMat, bs.sMat, bs.sInv};
   inplace.b_lower_tri = true;
   const GemmBatch upd{bs.count, bs.sMat, bs.sMat, bs.sMat};
+  // Inside an outer panel the columns are brought up to date LEFT-looking (round 5): before column j is factored it
+  // takes the panel's earlier columns in ONE launch with K = 128 (j - J), instead of every column pushing a K = 128 update
+  // into the rest of the panel right behind its TRSM.  The batch is far beyond the caches, so these steps stream the
+  // panel's tiles through HBM (~3 TB/s, tools/cfg5_trace.sh): the left-looking form touches a tile of the panel once per
+  // column it belongs to, not once per column before it, at two to three times the K per pass.  Every element still takes
+  // the panel's columns in ascending order on the ring kernels' accumulators: the same bits.  GPMI_BATCH_LEFT=0: the
+  // right-looking form (A/B).
+  static const bool left = [] {
+    const char* e = std::getenv("GPMI_BATCH_LEFT");
+    return !e || std::atoi(e) != 0;
+  }();
   for (int J = 0; J < nt; J += OBT) {
     const int Je = (J + OBT < nt) ? J + OBT : nt;
     for (int j = J; j < Je; ++j) {
       double* Ajj = A + (int64_t)j * NB * ld + (int64_t)j * NB;
       double* invDj = invD + (int64_t)j * NB * NB;
       const int below = nt - j - 1;
+      if (left && j > J) {
+        // tiles (i, j), i >= j: -= A(i, J..j-1) A(j, J..j-1)^T
+        const double* P = A + (int64_t)j * NB * ld + (int64_t)J * NB;
+        launch_gemm_nt(s, TILES_LOWER, OP_SUB, Ajj, ld, P, ld, P, ld, nt - j, 1, (j - J) * NB, nullptr, upd);
+      }
       launch_potrf_diag(s, Ajj, ld, invDj, info, j * NB, nullptr, bs);
       if (below > 0) {
         double* A21 = Ajj + (int64_t)NB * ld;
         launch_gemm_nt(s, TILES_RECT, OP_ASSIGN, A21, ld, A21, ld, invDj, NB, below, 1, NB, nullptr, inplace);
         const int pc = Je - j - 1;  // remaining tile columns of the outer panel
-        if (pc > 0) launch_gemm_nt(s, TILES_LOWER, OP_SUB, A21 + NB, ld, A21, ld, A21, ld, below, pc, NB, nullptr, upd);
+        if (!left && pc > 0)
+          launch_gemm_nt(s, TILES_LOWER, OP_SUB, A21 + NB, ld, A21, ld, A21, ld, below, pc, NB, nullptr, upd);
       }
     }
     const int rest = nt - Je;
