@@ -18,7 +18,7 @@ def lazy_panels(i, j, near=4):
     return max(e, 0)
 
 
-ZSPLIT = 1  # 4: every K = 512 chunk as four 64 x 64 quarter tasks (what-if)
+ZSPLIT = 1  # 4: every K = 512 chunk as four 64 x 64 quarter tasks (what-if); "last": only a tile's last chunk (ZS tasks)
 
 
 def build_tasks(m, near=4):
@@ -39,13 +39,13 @@ def build_tasks(m, near=4):
     for i in range(m):
         for j in range(i + 1):
             for q in range(lazy_panels(i, j, near)):
-                if ZSPLIT == 1:
+                if ZSPLIT == 1 or (ZSPLIT == "last" and q != j // OBT - 1):
                     tasks.append(dict(t="Z", i=i, j=j, k=q, s=0, add=4 * OBT))
                 else:
                     for s in range(4):
                         if i == j and s == 1:
                             continue
-                        tasks.append(dict(t="Z", i=i, j=j, k=q, s=s, add=(2 if (i == j and s == 0) else 1) * OBT))
+                        tasks.append(dict(t="Z", i=i, j=j, k=q, s=s, add=(2 if (i == j and s == 0) else 1) * OBT, quarter=True))
     return tasks
 
 
@@ -57,6 +57,8 @@ class Model:
     cU = 7.2
     cZ2 = 124.0
     cZ1 = 76.0
+    cQ2 = 37.0  # a 64 x 64 quarter of a chunk beside a busy neighbour (measured: 35 - 39) / alone (23 - 26)
+    cQ1 = 25.0
     hop = 1.8
     vis = 0.4
     cD = 21.5
@@ -104,7 +106,10 @@ def simulate(m, lists, mod=Model, near=4, verbose=False):
         busy[b] = True
         if x["t"] == "Z":
             mate = (b + half) % nw
-            dur = mod.cZ2 if zrun[mate] else mod.cZ1
+            if x.get("quarter"):
+                dur = mod.cQ2 if zrun[mate] else mod.cQ1
+            else:
+                dur = mod.cZ2 if zrun[mate] else mod.cZ1
             # (a chunk that starts beside a running one slows that one too; the model prices only the newcomer, and the
             # mate's remaining time is stretched in proportion)
             zrun[b] = True
@@ -476,3 +481,140 @@ if __name__ == "__main__":
         if a.write:
             write_lists(f"{a.write}_m{m}.bin", m, lists)
             print("wrote", f"{a.write}_m{m}.bin")
+
+
+# ---- a DYNAMIC scheduler (what-if, round 5): no per-workgroup lists - every free workgroup claims the first READY task in
+# priority order among the first `window` unclaimed ones of the classes it serves ---------------------------------------
+def simulate_dynamic(m, short_wgs=96, window=64, nwg=448, mod=Model, near=4, hop=None, short_takes_q=True, any_takes_short=False,
+                     zwindow=None):
+    tasks = build_tasks(m, near)
+    for x in tasks:
+        if x["t"] == "T":
+            x["key"] = (4 * x["k"], x["i"], 0, x["s"])
+        elif x["t"] == "U":
+            x["key"] = (4 * x["k"] + 2, x["i"], x["j"], x["s"])
+        else:
+            x["key"] = (4 * (OBT * x["k"] + OBT - 1) + 1, x["i"] - (1 << 20) if x.get("quarter") else x["i"], x["j"], x["s"])
+    is_short = lambda x: x["t"] != "Z" or (short_takes_q and x.get("quarter"))
+    qs = sorted([x for x in tasks if is_short(x)], key=lambda x: x["key"])
+    qz = sorted([x for x in tasks if not is_short(x)], key=lambda x: x["key"])
+    hop = mod.hop if hop is None else hop
+    zwindow = window if zwindow is None else zwindow
+    half = nwg // 2
+    Lcnt = [0] * m
+    F = [[0] * m for _ in range(m)]
+    DD = [0]
+    t = [0.0]
+    ev = []
+    seq = [0]
+
+    def at(time, fn, *a):
+        seq[0] += 1
+        heapq.heappush(ev, (time, seq[0], fn, a))
+
+    def ready(x):
+        ty, i, j, k = x["t"], x["i"], x["j"], x["k"]
+        if ty == "T":
+            return DD[0] >= k + 1 and F[i][k] == 4 * k
+        if ty == "U":
+            return Lcnt[i] >= 4 * (k + 1) and Lcnt[j] >= 4 * (k + 1) and F[i][j] >= 4 * k
+        return Lcnt[i] >= 4 * OBT * (k + 1) and Lcnt[j] >= 4 * OBT * (k + 1) and F[i][j] >= 4 * OBT * k
+
+    free_s = list(range(short_wgs))
+    free_z = list(range(short_wgs, nwg))
+    zrun = [False] * nwg
+    busy_us = [0.0]
+    stall = [0.0]
+
+    def take(queue, w):
+        for n, x in enumerate(queue[:w]):
+            if ready(x):
+                del queue[n]
+                return x
+        return None
+
+    def dispatch():
+        while free_s:
+            x = take(qs, window)
+            if x is None:
+                break
+            start(free_s.pop(), x)
+        while free_z:
+            x = take(qs, window) if any_takes_short else None
+            if x is None:
+                x = take(qz, zwindow)
+            if x is None:
+                break
+            start(free_z.pop(), x)
+
+    def start(b, x):
+        if x["t"] == "Z":
+            mate = (b + half) % nwg
+            if x.get("quarter"):
+                dur = mod.cQ2 if zrun[mate] else mod.cQ1
+            else:
+                dur = mod.cZ2 if zrun[mate] else mod.cZ1
+            zrun[b] = True
+        else:
+            dur = mod.cT
+        busy_us[0] += dur
+        at(t[0] + hop + dur, done, b, x)
+
+    def done(b, x):
+        zrun[b] = False
+        (free_s if b < short_wgs else free_z).append(b)
+        at(t[0] + mod.vis, publish, x)
+        dispatch()
+
+    def publish(x):
+        if x["t"] == "T":
+            Lcnt[x["i"]] += x["add"]
+        else:
+            F[x["i"]][x["j"]] += x["add"]
+        wake()
+
+    ch = dict(k=0, dend=None, waiting=False, ends=[])
+
+    def launch(k):
+        ch["k"] = k
+        if k > 0:
+            Lcnt[k] = 4 * k
+        ch["dend"] = t[0] + mod.cD
+        at(ch["dend"] + 0.5, ddone, k)
+        ch["waiting"] = True
+        wake()
+
+    def ddone(k):
+        DD[0] = k + 1
+        wake()
+
+    def chain_check():
+        if not ch["waiting"]:
+            return
+        k = ch["k"]
+        if k + 1 >= m:
+            ch["waiting"] = False
+            at(max(ch["dend"], t[0]) + 1.0, finish_launch, k)
+            return
+        if F[k + 1][k] >= 4 * k and F[k + 1][k + 1] >= 4 * k:
+            ch["waiting"] = False
+            flags_seen = t[0] + 1.0
+            stall[0] += max(0.0, flags_seen + mod.cLoad - ch["dend"])
+            at(max(ch["dend"], flags_seen + mod.cLoad) + mod.cTail, finish_launch, k)
+
+    def finish_launch(k):
+        ch["ends"].append(t[0])
+        if k + 1 < m:
+            F[k + 1][k + 1] = 4 * (k + 1)
+            at(t[0] + mod.cB, launch, k + 1)
+
+    def wake():
+        chain_check()
+        dispatch()
+
+    at(0.0, launch, 0)
+    while ev:
+        t[0], _, fn, a = heapq.heappop(ev)
+        fn(*a)
+    assert not qs and not qz and len(ch["ends"]) == m
+    return dict(total=t[0], stall=stall[0], util=busy_us[0] / (nwg * t[0]), col_ends=ch["ends"])
