@@ -11,7 +11,6 @@ for n in [int(a) for a in sys.argv[1:]] or [16384, 8192]:
     x, y, e = wl.synthetic_dataset(1, n, 8)
     th = wl.timing_theta(wl.SE, y, 8)
     gp = GpRegressor(x, y, y_err=e, hyperpars=th)
-    gp.marginal_likelihood(th)  # (a second lane exists from here on)
     out = []
     for m in (256, 1024, 2048):
         pts = wl.query_points(1, m, 8)
