@@ -1,5 +1,6 @@
-"""Randomised parity sweep against the CPU oracle (debug aid, not part of the suites): random sizes, dimensions,
-kernels, noise levels; fit, LML, LML gradient, predict."""
+"""Randomised parity sweep against the CPU oracle: random sizes, dimensions, kernels, noise levels; fit, LML and LOO with
+gradients, predict, posterior, and (SquaredExponential) the spatial gradients.  tests/test_gpu_parity.py runs a seeded
+sweep of it (`sweep`); from the command line: python tools/fuzz_parity.py [seed] [cases] [max N]."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "inference-tools_amd")]
@@ -12,22 +13,43 @@ def rel(a, b):
     a, b = np.asarray(a, float), np.asarray(b, float)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
-rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-worst = 0.0
-for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 16):
-    n = int(rng.integers(2, 2600)); d = int(rng.integers(1, 12)); kid = int(rng.integers(0, 2)); wn = bool(rng.integers(0, 2))
-    x, y, e = wl.synthetic_dataset(1000 + case, n, d)
-    e = e * float(rng.uniform(0.5, 3.0))
-    th = wl.timing_theta(kid, y, d) + 0.2 * rng.standard_normal(wl.timing_theta(kid, y, d).size)
-    cov = (SquaredExponential if kid == wl.SE else RationalQuadratic)()
-    if wn:
-        cov = cov + WhiteNoise(); th = np.append(th, np.log(0.05))
-    gp = GpRegressor(x, y, y_err=e, hyperpars=th, kernel=cov)
-    ref = orc.OracleGp(x, y, e, kernel=kid, hyperpars=th, white_noise=wn)
-    pts = wl.query_points(case, 33, d)
-    mu, sig = gp(pts); rmu, rsig = ref(pts)
-    l, g = gp.marginal_likelihood_gradient(th); rl, rg = ref.marginal_likelihood_gradient(th)
-    errs = dict(alpha=rel(gp.alpha, ref.alpha), mu=rel(mu, rmu), sig=rel(sig, rsig), lml=rel(l, rl), grad=rel(g, rg))
-    w = max(errs.values()); worst = max(worst, w)
-    print(f"n={n:5d} d={d:2d} kernel={'SE' if kid == 0 else 'RQ'}{'+WN' if wn else '   '}  worst {w:.2e}  " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
-print("overall worst relative error", worst)
+def sweep(seed=0, cases=16, nmax=2600, verbose=True):
+    """-> list of (description, {quantity: relative error}) for `cases` random problems."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for case in range(cases):
+        n = int(rng.integers(2, nmax)); d = int(rng.integers(1, 12)); kid = int(rng.integers(0, 2)); wn = bool(rng.integers(0, 2))
+        x, y, e = wl.synthetic_dataset(1000 * seed + case, n, d)
+        e = e * float(rng.uniform(0.5, 3.0))
+        th = wl.timing_theta(kid, y, d) + 0.2 * rng.standard_normal(wl.timing_theta(kid, y, d).size)
+        cov = (SquaredExponential if kid == wl.SE else RationalQuadratic)()
+        if wn:
+            cov = cov + WhiteNoise(); th = np.append(th, np.log(0.05))
+        gp = GpRegressor(x, y, y_err=e, hyperpars=th, kernel=cov)
+        ref = orc.OracleGp(x, y, e, kernel=kid, hyperpars=th, white_noise=wn)
+        m = int(rng.integers(1, 70))
+        pts = wl.query_points(case, m, d)
+        mu, sig = gp(pts); rmu, rsig = ref(pts)
+        l, g = gp.marginal_likelihood_gradient(th); rl, rg = ref.marginal_likelihood_gradient(th)
+        lo, go = gp.loo_likelihood_gradient(th); rlo, rgo = ref.loo_likelihood_gradient(th)
+        pm, pc = gp.build_posterior(pts); rpm, rpc = ref.build_posterior(pts)
+        errs = dict(alpha=rel(gp.alpha, ref.alpha), mu=rel(mu, rmu), sig=rel(sig, rsig), lml=rel(l, rl), grad=rel(g, rg),
+                    loo=rel(lo, rlo), loo_grad=rel(go, rgo), post_mean=rel(pm, rpm), post_cov=rel(pc, rpc))
+        if kid == wl.SE:
+            dm, dv = gp.spatial_derivatives(pts); rdm, rdv = ref.spatial_derivatives(pts)
+            errs.update(dmu=rel(dm, rdm), dvar=rel(dv, rdv))
+        desc = f"n={n:5d} d={d:2d} m={m:2d} kernel={'SE' if kid == 0 else 'RQ'}{'+WN' if wn else '   '}"
+        out.append((desc, errs))
+        if verbose:
+            print(f"{desc}  worst {max(errs.values()):.2e}  " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()), flush=True)
+    return out
+
+
+if __name__ == "__main__":
+    res = sweep(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 16,
+                int(sys.argv[3]) if len(sys.argv) > 3 else 2600)
+    worst = {}
+    for _, errs in res:
+        for k, v in errs.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+    print("worst relative error per quantity:", " ".join(f"{k}={v:.1e}" for k, v in worst.items()))
