@@ -261,33 +261,40 @@ int gpmi_fit_mix(gpmi_ctx* ctx, int nk, const int* kernels, const double* thetas
 int gpmi_lml_mix(gpmi_ctx* ctx, int nk, const int* kernels, const double* thetas, const int* n_thetas,
                  const double* g_host, double extra_diag, const double* mu_host, double* lml, int* info);
 /* LML and the gradient pieces (covariance.py:561-594 + regression.py:544-567): grad_thetas = the sub-kernels'
- * parameter gradients, concatenated; hrows (nk x n): h_m(i) = sum_j Q_ij K_m,ij g_m(j), Q = alpha alpha^T - K^-1,
- * from which the host forms the window-parameter gradients sum_m sum_i (d g_m / d phi)(i) h_m(i);
+ * parameter gradients, concatenated; hrows: the window row sums, Q = alpha alpha^T - K^-1, from which the host forms the
+ * window-parameter gradients.  hw_host == NULL: hrows is nk x n, h_m(i) = sum_j Q_ij K_m,ij g_m(j) (two regions: the host
+ * contracts sum_i dw_i (h_1 - h_0)_i).  hw_host != NULL (nk x 2 x n, round 5): the caller's own row-sum weights, two per
+ * sub-kernel, hrows nk x 2 x n with h_{m,r}(i) = sum_j Q_ij K_m,ij hw_{m,r}(j) - covariance.py:588-593 differentiates
+ * change-point c through the factors (1 - f_c) of K_c and f_c of K_{c+1} ONLY, whatever other windows multiply them, so
+ * for any number of regions the host passes hw_{m,0} = f_{m-1}, hw_{m,1} = 1 - f_m and contracts
+ * sum_i df_c(i) (h_{c+1,0} - h_{c,1})(i); the same expression as hw == NULL when nk = 2.
  * q_i for additive noise terms comes from gpmi_lml_grad_qdiag as usual. */
 int gpmi_lml_grad_mix(gpmi_ctx* ctx, int nk, const int* kernels, const double* thetas, const int* n_thetas,
-                      const double* g_host, double extra_diag, const double* mu_host, double* lml,
+                      const double* g_host, const double* hw_host, double extra_diag, const double* mu_host, double* lml,
                       double* grad_thetas, double* hrows_host, double* alpha_host, int* info);
 
 /* gpmi_lml_grad_mix for T hyper-parameter vectors in one call (round 4; regression.py:544-567 with a ChangePoint kernel,
  * covariance.py:529-594, for the T starts of multistart_bfgs, regression.py:585-605).  N <= 4096: the evaluations advance
  * in lockstep, every launch carrying all of them.  thetas: T rows, each the sub-kernels' parameters back to back
- * (sum of n_thetas values); g: T x nk x n window weights; extra: T WhiteNoise variances (or NULL); one of mus (T x n) /
- * mu_const (T).  Out: lml[T], grad_thetas[T x sum n_thetas], hrows[T x nk x n] (h_m(i) = sum_j Q_ij K_m,ij g_m(j), which
- * the caller contracts with d g_m / d phi), optional alpha_out[T x n], qdiag_out[T x n] (diag(alpha alpha^T - K^-1)),
- * info[T]. */
+ * (sum of n_thetas values); g: T x nk x n window weights; hw: NULL or T x nk x 2 x n row-sum weights (see
+ * gpmi_lml_grad_mix); extra: T WhiteNoise variances (or NULL); one of mus (T x n) / mu_const (T).  Out: lml[T],
+ * grad_thetas[T x sum n_thetas], hrows[T x nk x n] (hw == NULL: h_m(i) = sum_j Q_ij K_m,ij g_m(j)) or [T x nk x 2 x n],
+ * optional alpha_out[T x n], qdiag_out[T x n] (diag(alpha alpha^T - K^-1)), info[T]. */
 int gpmi_lml_grad_batch_mix(gpmi_ctx* ctx, int nk, const int* kernels, int64_t T, const double* thetas,
-                            const int* n_thetas, const double* g, const double* extra, const double* mus,
-                            const double* mu_const, double* lml, double* grad_thetas, double* hrows,
+                            const int* n_thetas, const double* g, const double* hw, const double* extra,
+                            const double* mus, const double* mu_const, double* lml, double* grad_thetas, double* hrows,
                             double* alpha_out, double* qdiag_out, int* info);
 /* The leave-one-out counterpart (regression.py:489-526 with covariance.py:529-594) for T hyper-parameter vectors in lockstep:
  * alpha, diag(K^-1), p = K^-1 (alpha / diag) and diag(M), M = K^-1 diag(c2) K^-1, per evaluation (T x n each); the
  * sub-kernels' gradient components (T x sum n_thetas) and the window row sums h_m(i) = sum_j (sym(p alpha^T) - M)_ij K_m,ij g_m(j)
- * (T x nk x n; window parameters: 2 sum_i dw_i (h_1 - h_0)_i on the host; WhiteNoise: 2 s^2 sum(p o alpha - diag M)).
+ * (T x nk x n; window parameters: 2 sum_i dw_i (h_1 - h_0)_i on the host; WhiteNoise: 2 s^2 sum(p o alpha - diag M)); with
+ * hw_host (T x nk x 2 x n, see gpmi_lml_grad_mix) the row sums use the caller's weights, T x nk x 2 x n: any number of regions.
  * Lockstep sizes only (n <= 4096, diagonal data errors). */
 int gpmi_loo_grad_batch_mix(gpmi_ctx* ctx, int nk, const int* kernels, int64_t T, const double* thetas_host,
-                            const int* n_thetas, const double* g_host, const double* extra_diag_host,
-                            const double* mus_host, const double* mu_const_host, double* alpha_host, double* ikdiag_host,
-                            double* p_host, double* mdiag_host, double* grad_thetas_host, double* hrows_host, int* info);
+                            const int* n_thetas, const double* g_host, const double* hw_host,
+                            const double* extra_diag_host, const double* mus_host, const double* mu_const_host,
+                            double* alpha_host, double* ikdiag_host, double* p_host, double* mdiag_host,
+                            double* grad_thetas_host, double* hrows_host, int* info);
 /* alpha and diag(K^-1) at arbitrary hyper-parameters: the O(n^3) part of loo_likelihood (regression.py:468-487) */
 int gpmi_loo_terms_mix(gpmi_ctx* ctx, int nk, const int* kernels, const double* thetas, const int* n_thetas,
                        const double* g_host, double extra_diag, const double* mu_host, double* alpha_host,

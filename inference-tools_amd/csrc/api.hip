@@ -224,6 +224,7 @@ void free_data(gpmi_ctx* c) {
   fr(c->bNoise);
   fr(c->bMixG);
   fr(c->bMixH);
+  fr(c->bMixW);
   fr(c->bMixExtra);
   if (c->bMixP) (void)hipFree(c->bMixP);
   c->bMixP = nullptr;
@@ -421,6 +422,7 @@ int ensure_batch_ws(gpmi_ctx* c, int want) {
   fr(c->bNoise);
   fr(c->bMixG);
   fr(c->bMixH);
+  fr(c->bMixW);
   fr(c->bMixExtra);
   if (c->bMixP) (void)hipFree(c->bMixP);
   c->bMixP = nullptr;

@@ -110,7 +110,7 @@ int gpmi_lml_mix(gpmi_ctx* c, int nk, const int* kernels, const double* thetas, 
 }
 
 int gpmi_lml_grad_mix(gpmi_ctx* c, int nk, const int* kernels, const double* thetas, const int* n_thetas,
-                      const double* g_host, double extra_diag, const double* mu, double* lml,
+                      const double* g_host, const double* hw_host, double extra_diag, const double* mu, double* lml,
                       double* grad_thetas, double* hrows, double* alpha_out, int* info) {
   if (!c) return GPMI_ERR_ARG;
   KParams ps[GPMI_MAX_MIX];
@@ -138,10 +138,19 @@ int gpmi_lml_grad_mix(gpmi_ctx* c, int nk, const int* kernels, const double* the
   double* alpha_dev = L.vec + c->np;
   double* ua = L.vec + 2 * c->np;  // g_m o alpha
   double* gout = L.red + 16;       // (n_theta_m + 1) values per sub-kernel, consecutive
-  double* hdev = c->mix_scratch;   // nk x np row sums: the scratch matrix is free once K is factorised
+  // row sums (nk x np, or nk x 2 x np with the caller's own weights hw behind them): the scratch matrix is free once
+  // K is factorised
+  const int nrow = hw_host ? 2 : 1;
+  double* hdev = c->mix_scratch;
+  double* wdev = c->mix_scratch + (int64_t)2 * GPMI_MAX_MIX * c->np;
   const MixEval mx{nk, ps, c->mix_g, extra_diag, c->mix_scratch, c->mix_zero};
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
   if (int rc = enqueue_factor_and_forward(c, L, ps[0], mu_dev, 0.0, 0, true, &mx)) return rc;
+  if (hw_host) {
+    HIPCHK(c, hipMemsetAsync(wdev, 0, sizeof(double) * 2 * nk * c->np, s));
+    HIPCHK(c, hipMemcpy2DAsync(wdev, sizeof(double) * c->np, hw_host, sizeof(double) * c->n, sizeof(double) * c->n,
+                               (size_t)2 * nk, hipMemcpyHostToDevice, s));
+  }
   trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, alpha_dev, L.info);
   // K^-1 = L^-T L^-1, lower tiles over L, then both triangles (it is read row-wise below)
   if (int rc = enqueue_inverse_factor(c, L, L)) return rc;
@@ -161,14 +170,17 @@ int gpmi_lml_grad_mix(gpmi_ctx* c, int nk, const int* kernels, const double* the
     KParams pm = ps[m];
     pm.extra_diag = 0.0;
     launch_kbuild_square(s, pm, c->x, c->n, c->np, c->mix_zero, L.B2, c->ld, false);
-    launch_mix_rowsum(s, L.A, L.B2, c->ld, alpha_dev, gm, hdev + (int64_t)m * c->np, c->n);
+    for (int r = 0; r < nrow; ++r) {
+      const int64_t row = (int64_t)m * nrow + r;
+      launch_mix_rowsum(s, L.A, L.B2, c->ld, alpha_dev, hw_host ? wdev + row * c->np : gm, hdev + row * c->np, c->n);
+    }
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(L.h_red + 16, gout, sizeof(double) * goff, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));
-  for (int m = 0; m < nk; ++m)
-    HIPCHK(c, hipMemcpyAsync(hrows + (int64_t)m * c->n, hdev + (int64_t)m * c->np, sizeof(double) * c->n,
+  for (int row = 0; row < nk * nrow; ++row)
+    HIPCHK(c, hipMemcpyAsync(hrows + (int64_t)row * c->n, hdev + (int64_t)row * c->np, sizeof(double) * c->n,
                              hipMemcpyDeviceToHost, s));
   if (alpha_out) HIPCHK(c, hipMemcpyAsync(alpha_out, alpha_dev, sizeof(double) * c->n, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
@@ -191,8 +203,8 @@ int gpmi_lml_grad_mix(gpmi_ctx* c, int nk, const int* kernels, const double* the
 // the sub-kernels' parameters back to back (sum n_thetas each); g_host: T x nk x n window weights; hrows: T x nk x n;
 // qdiag_out (optional, T x n): diag(alpha alpha^T - K^-1) for the WhiteNoise term.  Larger problems: one at a time.
 int gpmi_lml_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, const double* thetas,
-                            const int* n_thetas, const double* g_host, const double* extra, const double* mus,
-                            const double* mu_const, double* lml, double* grad_thetas, double* hrows,
+                            const int* n_thetas, const double* g_host, const double* hw_host, const double* extra,
+                            const double* mus, const double* mu_const, double* lml, double* grad_thetas, double* hrows,
                             double* alpha_out, double* qdiag_out, int* info) {
   if (!c) return GPMI_ERR_ARG;
   ARGCHK(c, c->n > 0, "gpmi_set_data has not been called");
@@ -213,9 +225,11 @@ int gpmi_lml_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
       const double* mu_t = mus ? mus + t * c->n : mu_row.data();
       if (!mus) std::fill(mu_row.begin(), mu_row.end(), mu_const[t]);
       int inf = 0;
+      const int nrow1 = hw_host ? 2 : 1;
       const int rc = gpmi_lml_grad_mix(c, nk, kernels, thetas + t * tot_nt, n_thetas, g_host + t * nk * c->n,
-                                       extra ? extra[t] : 0.0, mu_t, lml + t, grad_thetas + t * tot_nt,
-                                       hrows + t * nk * c->n, alpha_out ? alpha_out + t * c->n : nullptr, &inf);
+                                       hw_host ? hw_host + t * nk * 2 * c->n : nullptr, extra ? extra[t] : 0.0, mu_t,
+                                       lml + t, grad_thetas + t * tot_nt, hrows + t * nk * nrow1 * c->n,
+                                       alpha_out ? alpha_out + t * c->n : nullptr, &inf);
       if (info) info[t] = inf;
       if (rc != GPMI_OK) return rc;
       if (qdiag_out)
@@ -251,12 +265,15 @@ int gpmi_lml_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
     };
     fr(c->bMixG);
     fr(c->bMixH);
+    fr(c->bMixW);
     fr(c->bMixExtra);
     if (c->bMixP) (void)hipFree(c->bMixP);
     c->bMixP = nullptr;
     c->bMix_cap = 0;
     HIPCHK(c, hipMalloc(&c->bMixG, sizeof(double) * cap * GPMI_MAX_MIX * c->np));
-    HIPCHK(c, hipMalloc(&c->bMixH, sizeof(double) * cap * GPMI_MAX_MIX * c->np));
+    // (row sums and the caller's row-sum weights: up to two per sub-kernel)
+    HIPCHK(c, hipMalloc(&c->bMixH, sizeof(double) * cap * 2 * GPMI_MAX_MIX * c->np));
+    HIPCHK(c, hipMalloc(&c->bMixW, sizeof(double) * cap * 2 * GPMI_MAX_MIX * c->np));
     HIPCHK(c, hipMalloc(&c->bMixExtra, sizeof(double) * cap));
     HIPCHK(c, hipMalloc(&c->bMixP, sizeof(KParams) * cap * GPMI_MAX_MIX));
     c->bMix_cap = cap;
@@ -271,8 +288,12 @@ int gpmi_lml_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
   hipStream_t s = c->lanes[1].stream;
   const int nt = (int)(c->np / GPMI_NB);
   const BatchShape shape0{1, c->np * c->ld, (c->np / GPMI_NB) * GPMI_NB * GPMI_NB, 4 * c->np};
-  const int64_t sG = (int64_t)GPMI_MAX_MIX * c->np;  // between the problems' weight (and row-sum) sets
-  std::vector<double> gpad, ex;
+  const int64_t sG = (int64_t)GPMI_MAX_MIX * c->np;  // between the problems' weight sets
+  // row sums per sub-kernel: one with the sub-kernel's own weights, or two with the caller's (hw); stride between the
+  // problems' row-sum (and row-sum weight) sets
+  const int nrow = hw_host ? 2 : 1;
+  const int64_t sW = (int64_t)nrow * GPMI_MAX_MIX * c->np;
+  std::vector<double> gpad, ex, wpad;
   for (int64_t t0 = 0; t0 < T; t0 += cap) {
     const int B = (int)((T - t0 < cap) ? T - t0 : cap);
     BatchShape bs = shape0;
@@ -289,6 +310,14 @@ int gpmi_lml_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
     if (extra)
       for (int b = 0; b < B; ++b) ex[(size_t)b] = extra[t0 + b];
     HIPCHK(c, hipMemcpyAsync(c->bMixG, gpad.data(), sizeof(double) * B * sG, hipMemcpyHostToDevice, s));
+    if (hw_host) {
+      wpad.assign((size_t)B * sW, 0.0);
+      for (int b = 0; b < B; ++b)
+        for (int row = 0; row < 2 * nk; ++row)
+          std::copy(hw_host + ((t0 + b) * 2 * nk + row) * c->n, hw_host + ((t0 + b) * 2 * nk + row + 1) * c->n,
+                    wpad.data() + (size_t)b * sW + (size_t)row * c->np);
+      HIPCHK(c, hipMemcpyAsync(c->bMixW, wpad.data(), sizeof(double) * B * sW, hipMemcpyHostToDevice, s));
+    }
     HIPCHK(c, hipMemcpyAsync(c->bMixExtra, ex.data(), sizeof(double) * B, hipMemcpyHostToDevice, s));
     for (int m = 0; m < nk; ++m)
       HIPCHK(c, hipMemcpyAsync(c->bMixP + (int64_t)m * cap, ps.data() + (size_t)m * T + t0, sizeof(KParams) * B,
@@ -333,16 +362,24 @@ int gpmi_lml_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
       launch_kbuild_square_batched(s, kernels[m], pm, B, c->x, c->n, c->np, c->mix_zero, c->bB2, c->ld, bs.sMat,
                                    (int)c->d, 0);
       launch_mirror_lower(s, c->bB2, c->ld, c->np, B, bs.sMat);
-      launch_mix_rowsum(s, c->bA, c->bB2, c->ld, alpha_dev, gm, c->bMixH + (int64_t)m * c->np, c->n, B, bs.sMat,
-                        bs.sVec, sG);
+      if (!hw_host) {
+        launch_mix_rowsum(s, c->bA, c->bB2, c->ld, alpha_dev, gm, c->bMixH + (int64_t)m * c->np, c->n, B, bs.sMat,
+                          bs.sVec, sG);
+      } else {
+        // (one launch per row: weights and rows share the stride, bMixG's differs)
+        for (int r = 0; r < 2; ++r)
+          launch_mix_rowsum(s, c->bA, c->bB2, c->ld, alpha_dev, c->bMixW + (int64_t)(2 * m + r) * c->np,
+                            c->bMixH + (int64_t)(2 * m + r) * c->np, c->n, B, bs.sMat, bs.sVec, sW);
+      }
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_bRed, c->bRed, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(c->h_bGout, c->bGout, sizeof(double) * nk * cap * W, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(c->h_bInfo, c->bInfo, sizeof(int) * B, hipMemcpyDeviceToHost, s));
-    for (int m = 0; m < nk; ++m)
-      HIPCHK(c, hipMemcpy2DAsync(hrows + (t0 * nk + m) * c->n, sizeof(double) * nk * c->n, c->bMixH + (int64_t)m * c->np,
-                                 sizeof(double) * sG, sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    for (int row = 0; row < nk * nrow; ++row)
+      HIPCHK(c, hipMemcpy2DAsync(hrows + (t0 * nk * nrow + row) * c->n, sizeof(double) * nk * nrow * c->n,
+                                 c->bMixH + (int64_t)row * c->np, sizeof(double) * sW, sizeof(double) * c->n, B,
+                                 hipMemcpyDeviceToHost, s));
     if (alpha_out)
       HIPCHK(c, hipMemcpy2DAsync(alpha_out + t0 * c->n, sizeof(double) * c->n, alpha_dev, sizeof(double) * bs.sVec,
                                  sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
@@ -371,9 +408,9 @@ int gpmi_lml_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
 // alpha, diag(K^-1), p = K^-1 c1, diag(M) (WhiteNoise: 2 s^2 sum(p o alpha - diag M)), the sub-kernels' gradients and the
 // row sums (window parameters: 2 sum_i dw_i (h_1 - h_0)_i, contracted on the host).  Lockstep sizes only.
 int gpmi_loo_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, const double* thetas,
-                            const int* n_thetas, const double* g_host, const double* extra, const double* mus,
-                            const double* mu_const, double* alpha_out, double* ikdiag_out, double* p_out,
-                            double* mdiag_out, double* grad_thetas, double* hrows, int* info) {
+                            const int* n_thetas, const double* g_host, const double* hw_host, const double* extra,
+                            const double* mus, const double* mu_const, double* alpha_out, double* ikdiag_out,
+                            double* p_out, double* mdiag_out, double* grad_thetas, double* hrows, int* info) {
   if (!c) return GPMI_ERR_ARG;
   ARGCHK(c, c->n > 0, "gpmi_set_data has not been called");
   ARGCHK(c, T >= 1 && T <= RED_SLOTS, "T out of range");
@@ -416,12 +453,15 @@ int gpmi_loo_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
     };
     fr(c->bMixG);
     fr(c->bMixH);
+    fr(c->bMixW);
     fr(c->bMixExtra);
     if (c->bMixP) (void)hipFree(c->bMixP);
     c->bMixP = nullptr;
     c->bMix_cap = 0;
     HIPCHK(c, hipMalloc(&c->bMixG, sizeof(double) * cap * GPMI_MAX_MIX * c->np));
-    HIPCHK(c, hipMalloc(&c->bMixH, sizeof(double) * cap * GPMI_MAX_MIX * c->np));
+    // (row sums and the caller's row-sum weights: up to two per sub-kernel)
+    HIPCHK(c, hipMalloc(&c->bMixH, sizeof(double) * cap * 2 * GPMI_MAX_MIX * c->np));
+    HIPCHK(c, hipMalloc(&c->bMixW, sizeof(double) * cap * 2 * GPMI_MAX_MIX * c->np));
     HIPCHK(c, hipMalloc(&c->bMixExtra, sizeof(double) * cap));
     HIPCHK(c, hipMalloc(&c->bMixP, sizeof(KParams) * cap * GPMI_MAX_MIX));
     c->bMix_cap = cap;
@@ -439,8 +479,12 @@ int gpmi_loo_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
   hipStream_t s = c->lanes[1].stream;
   const int nt = (int)(c->np / GPMI_NB);
   const BatchShape shape0{1, c->np * c->ld, (c->np / GPMI_NB) * GPMI_NB * GPMI_NB, 4 * c->np};
-  const int64_t sG = (int64_t)GPMI_MAX_MIX * c->np;  // between the problems' weight (and row-sum) sets
-  std::vector<double> gpad, ex;
+  const int64_t sG = (int64_t)GPMI_MAX_MIX * c->np;  // between the problems' weight sets
+  // row sums per sub-kernel: one with the sub-kernel's own weights, or two with the caller's (hw); stride between the
+  // problems' row-sum (and row-sum weight) sets
+  const int nrow = hw_host ? 2 : 1;
+  const int64_t sW = (int64_t)nrow * GPMI_MAX_MIX * c->np;
+  std::vector<double> gpad, ex, wpad;
   for (int64_t t0 = 0; t0 < T; t0 += cap) {
     const int B = (int)((T - t0 < cap) ? T - t0 : cap);
     BatchShape bs = shape0;
@@ -457,6 +501,14 @@ int gpmi_loo_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
     if (extra)
       for (int b = 0; b < B; ++b) ex[(size_t)b] = extra[t0 + b];
     HIPCHK(c, hipMemcpyAsync(c->bMixG, gpad.data(), sizeof(double) * B * sG, hipMemcpyHostToDevice, s));
+    if (hw_host) {
+      wpad.assign((size_t)B * sW, 0.0);
+      for (int b = 0; b < B; ++b)
+        for (int row = 0; row < 2 * nk; ++row)
+          std::copy(hw_host + ((t0 + b) * 2 * nk + row) * c->n, hw_host + ((t0 + b) * 2 * nk + row + 1) * c->n,
+                    wpad.data() + (size_t)b * sW + (size_t)row * c->np);
+      HIPCHK(c, hipMemcpyAsync(c->bMixW, wpad.data(), sizeof(double) * B * sW, hipMemcpyHostToDevice, s));
+    }
     HIPCHK(c, hipMemcpyAsync(c->bMixExtra, ex.data(), sizeof(double) * B, hipMemcpyHostToDevice, s));
     for (int m = 0; m < nk; ++m)
       HIPCHK(c, hipMemcpyAsync(c->bMixP + (int64_t)m * cap, ps.data() + (size_t)m * T + t0, sizeof(KParams) * B,
@@ -517,15 +569,22 @@ int gpmi_loo_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
       launch_kbuild_square_batched(s, kernels[m], pm, B, c->x, c->n, c->np, c->mix_zero, c->bB2, c->ld, bs.sMat,
                                    (int)c->d, 0);
       launch_mirror_lower(s, c->bB2, c->ld, c->np, B, bs.sMat);
-      launch_mix_rowsum(s, c->bA, c->bB2, c->ld, alpha_dev, gm, c->bMixH + (int64_t)m * c->np, c->n, B, bs.sMat,
-                        bs.sVec, sG, p_dev, sLoo);
+      if (!hw_host) {
+        launch_mix_rowsum(s, c->bA, c->bB2, c->ld, alpha_dev, gm, c->bMixH + (int64_t)m * c->np, c->n, B, bs.sMat,
+                          bs.sVec, sG, p_dev, sLoo);
+      } else {
+        for (int r = 0; r < 2; ++r)
+          launch_mix_rowsum(s, c->bA, c->bB2, c->ld, alpha_dev, c->bMixW + (int64_t)(2 * m + r) * c->np,
+                            c->bMixH + (int64_t)(2 * m + r) * c->np, c->n, B, bs.sMat, bs.sVec, sW, p_dev, sLoo);
+      }
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_bGout, c->bGout, sizeof(double) * nk * cap * W, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(c->h_bInfo, c->bInfo, sizeof(int) * B, hipMemcpyDeviceToHost, s));
-    for (int m = 0; m < nk; ++m)
-      HIPCHK(c, hipMemcpy2DAsync(hrows + (t0 * nk + m) * c->n, sizeof(double) * nk * c->n, c->bMixH + (int64_t)m * c->np,
-                                 sizeof(double) * sG, sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    for (int row = 0; row < nk * nrow; ++row)
+      HIPCHK(c, hipMemcpy2DAsync(hrows + (t0 * nk * nrow + row) * c->n, sizeof(double) * nk * nrow * c->n,
+                                 c->bMixH + (int64_t)row * c->np, sizeof(double) * sW, sizeof(double) * c->n, B,
+                                 hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpy2DAsync(alpha_out + t0 * c->n, sizeof(double) * c->n, alpha_dev, sizeof(double) * bs.sVec,
                                sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpy2DAsync(ikdiag_out + t0 * c->n, sizeof(double) * c->n, diag_dev, sizeof(double) * sLoo,

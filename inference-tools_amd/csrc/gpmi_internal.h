@@ -135,6 +135,7 @@ struct gpmi_ctx {
   // sub-kernels' parameters (GPMI_MAX_MIX arrays of bcap KParams) and the WhiteNoise variances
   double* bMixG = nullptr;
   double* bMixH = nullptr;
+  double* bMixW = nullptr;  // the caller's row-sum weights (gpmi_*_grad_batch_mix: hw)
   KParams* bMixP = nullptr;
   double* bMixExtra = nullptr;
   int bMix_cap = 0;

@@ -182,21 +182,26 @@ class GpEngine(_DeviceCommMixin):
                     C.byref(info))
         return out.value, info.value
 
-    def lml_grad_mix(self, kernels, thetas, weights, extra_diag, mu):
+    def lml_grad_mix(self, kernels, thetas, weights, extra_diag, mu, row_weights=None):
+        """row_weights (nk, 2, n): the caller's own row-sum weights (include/gpmi.h: hw); hrows then is (nk, 2, n)."""
         nk, ks, kp, th, nts, ntp, g = self._mix_args(kernels, thetas, weights)
         mu = as_f64(mu)
         lml, info = C.c_double(0.0), C.c_int(0)
         grad = np.empty(th.size)
-        hrows = np.empty((nk, self.n))
+        hw = None if row_weights is None else as_f64(np.asarray(row_weights, dtype=float).reshape(nk, 2, self.n))
+        hrows = np.empty((nk, self.n) if hw is None else (nk, 2, self.n))
         alpha = np.empty(self.n)
-        self.h.call("gpmi_lml_grad_mix", nk, kp, dptr(th), ntp, dptr(g), float(extra_diag), dptr(mu),
+        self.h.call("gpmi_lml_grad_mix", nk, kp, dptr(th), ntp, dptr(g), dptr(hw), float(extra_diag), dptr(mu),
                     C.byref(lml), dptr(grad), dptr(hrows), dptr(alpha), C.byref(info))
         return lml.value, grad, hrows, alpha, info.value
 
-    def lml_grad_batch_mix(self, kernels, thetas, weights, extra_diag=None, mus=None, mu_const=None, want_qdiag=False):
+    def lml_grad_batch_mix(self, kernels, thetas, weights, extra_diag=None, mus=None, mu_const=None, want_qdiag=False,
+                           row_weights=None):
         """gpmi_lml_grad_batch_mix: T evaluations of the mixture likelihood and its gradient pieces in one call.
-        kernels: the nk sub-kernel ids; thetas: T lists of nk parameter vectors; weights: (T, nk, n) window weights.
-        Returns (lml (T,), grad (T, sum n_thetas), hrows (T, nk, n), alpha (T, n), qdiag (T, n) or None, info (T,))."""
+        kernels: the nk sub-kernel ids; thetas: T lists of nk parameter vectors; weights: (T, nk, n) window weights;
+        row_weights: None or (T, nk, 2, n) (include/gpmi.h: hw).
+        Returns (lml (T,), grad (T, sum n_thetas), hrows (T, nk, n) - (T, nk, 2, n) with row_weights -, alpha (T, n),
+        qdiag (T, n) or None, info (T,))."""
         ks = np.ascontiguousarray(kernels, dtype=np.int32)
         nk = len(ks)
         T = len(thetas)
@@ -208,20 +213,21 @@ class GpEngine(_DeviceCommMixin):
         mc = None if mu_const is None else as_f64(mu_const)
         lml = np.empty(T)
         grad = np.empty((T, int(nts.sum())))
-        hrows = np.empty((T, nk, self.n))
+        hw = None if row_weights is None else as_f64(np.asarray(row_weights, dtype=float).reshape(T, nk, 2, self.n))
+        hrows = np.empty((T, nk, self.n) if hw is None else (T, nk, 2, self.n))
         alpha = np.empty((T, self.n))
         qdiag = np.empty((T, self.n)) if want_qdiag else None
         info = np.zeros(T, dtype=np.int32)
         ip = C.POINTER(C.c_int)
         self.h.call("gpmi_lml_grad_batch_mix", nk, ks.ctypes.data_as(ip), T, dptr(th), nts.ctypes.data_as(ip), dptr(g),
-                    dptr(ex), dptr(mus), dptr(mc), dptr(lml), dptr(grad), dptr(hrows), dptr(alpha), dptr(qdiag),
+                    dptr(hw), dptr(ex), dptr(mus), dptr(mc), dptr(lml), dptr(grad), dptr(hrows), dptr(alpha), dptr(qdiag),
                     info.ctypes.data_as(ip))
         return lml, grad, hrows, alpha, qdiag, info
 
-    def loo_grad_batch_mix(self, kernels, thetas, weights, extra_diag=None, mus=None, mu_const=None):
+    def loo_grad_batch_mix(self, kernels, thetas, weights, extra_diag=None, mus=None, mu_const=None, row_weights=None):
         """gpmi_loo_grad_batch_mix: T evaluations of the mixture's leave-one-out pieces in one call (lockstep sizes only).
         Arguments as `lml_grad_batch_mix`.  Returns (alpha, ikdiag, pvec, mdiag (T, n each), grad (T, sum n_thetas),
-        hrows (T, nk, n), info (T,))."""
+        hrows (T, nk, n) - (T, nk, 2, n) with row_weights -, info (T,))."""
         ks = np.ascontiguousarray(kernels, dtype=np.int32)
         nk = len(ks)
         T = len(thetas)
@@ -233,11 +239,12 @@ class GpEngine(_DeviceCommMixin):
         mc = None if mu_const is None else as_f64(mu_const)
         alpha, ikdiag, pvec, mdiag = (np.empty((T, self.n)) for _ in range(4))
         grad = np.empty((T, int(nts.sum())))
-        hrows = np.empty((T, nk, self.n))
+        hw = None if row_weights is None else as_f64(np.asarray(row_weights, dtype=float).reshape(T, nk, 2, self.n))
+        hrows = np.empty((T, nk, self.n) if hw is None else (T, nk, 2, self.n))
         info = np.zeros(T, dtype=np.int32)
         ip = C.POINTER(C.c_int)
         self.h.call("gpmi_loo_grad_batch_mix", nk, ks.ctypes.data_as(ip), T, dptr(th), nts.ctypes.data_as(ip), dptr(g),
-                    dptr(ex), dptr(mus), dptr(mc), dptr(alpha), dptr(ikdiag), dptr(pvec), dptr(mdiag), dptr(grad),
+                    dptr(hw), dptr(ex), dptr(mus), dptr(mc), dptr(alpha), dptr(ikdiag), dptr(pvec), dptr(mdiag), dptr(grad),
                     dptr(hrows), info.ctypes.data_as(ip))
         return alpha, ikdiag, pvec, mdiag, grad, hrows, info
 

@@ -74,9 +74,9 @@ SIGNATURES = {
     "gpmi_loo_grad_batch_noise": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_fit_mix": (C.c_int, [_vp, C.c_int, _ip, _dp, _ip, _dp, C.c_double, _dp, _dp, _dp, _ip]),
     "gpmi_lml_mix": (C.c_int, [_vp, C.c_int, _ip, _dp, _ip, _dp, C.c_double, _dp, _dp, _ip]),
-    "gpmi_lml_grad_mix": (C.c_int, [_vp, C.c_int, _ip, _dp, _ip, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp, _ip]),
-    "gpmi_lml_grad_batch_mix": (C.c_int, [_vp, C.c_int, _ip, _i64, _dp, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
-    "gpmi_loo_grad_batch_mix": (C.c_int, [_vp, C.c_int, _ip, _i64, _dp, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_lml_grad_mix": (C.c_int, [_vp, C.c_int, _ip, _dp, _ip, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_lml_grad_batch_mix": (C.c_int, [_vp, C.c_int, _ip, _i64, _dp, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "gpmi_loo_grad_batch_mix": (C.c_int, [_vp, C.c_int, _ip, _i64, _dp, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     "gpmi_loo_terms_mix": (C.c_int, [_vp, C.c_int, _ip, _dp, _ip, _dp, C.c_double, _dp, _dp, _dp, _ip]),
     "gpmi_predict_mix": (C.c_int, [_vp, _dp, _i64, _dp, _dp, _dp]),
     "gpmi_posterior_mix": (C.c_int, [_vp, _dp, _i64, _dp, _dp, _dp]),

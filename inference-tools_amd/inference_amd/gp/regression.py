@@ -192,6 +192,31 @@ class GpRegressor:
         kernels, thetas = self._mix.device_terms(theta_cp)
         return kernels, thetas, self._mix.weights(self._mix.x_cp, theta_cp)
 
+    def _mix_window_terms(self, theta_cp):
+        """Row-sum weights and window derivatives of a ChangePoint block with any number of regions.  The reference
+        differentiates change-point c through the factor (1 - f_c) of K_c and the factor f_c of K_{c+1} only
+        (covariance.py:588-593: `K_vals[i] * (A + A.T) + K_vals[i + 1] * (B + B.T)` with the BARE sub-kernel matrices),
+        so 1/2 sum Q o dK/dphi_c = sum_i dphi f_c(i) (h_{c+1,0} - h_{c,1})(i) with the device row sums
+        h_{m,0}(i) = sum_j Q_ij K_m,ij f_{m-1}(j),  h_{m,1}(i) = sum_j Q_ij K_m,ij (1 - f_m)(j).
+        Returns (hw (nk, 2, n), [(dws of change-point c) ...])."""
+        cp = self._mix
+        nk = cp.n_kernels
+        hw = zeros((nk, 2, cp.x_cp.size))
+        dws = []
+        for c_, slc in enumerate(cp.cp_slc):
+            w, dw = cp.logistic_and_gradient(cp.x_cp, theta_cp[slc])
+            hw[c_, 1] = 1.0 - w
+            hw[c_ + 1, 0] = w
+            dws.append(dw)
+        return hw, dws
+
+    @staticmethod
+    def _mix_window_gradient(cp, dws, hrows, grad, scale=1.0):
+        """grad[cp.cp_slc[c]] = scale * sum_i dphi f_c(i) (h_{c+1,0} - h_{c,1})(i) for every change-point c."""
+        for c_, slc in enumerate(cp.cp_slc):
+            dh = hrows[c_ + 1, 0] - hrows[c_, 1]
+            grad[slc] = [scale * float((dw * dh).sum()) for dw in dws[c_]]
+
     def _refit_mixture_if_stale(self):
         # the fitted mixture's weights share a device buffer with the likelihood evaluations
         if self._mix is not None and getattr(self, "_mix_fit_stale", False):
@@ -484,7 +509,7 @@ class GpRegressor:
         thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
         het_batch = (self._het_slice is not None and self._mix is None and not self._generic and self._y_cov is None
                      and self.engine.capacity() <= 4096)  # (round 5: gpmi_loo_grad_batch_noise, lockstep sizes only)
-        if (self._mix is not None and not self._generic and self._mix.n_kernels == 2 and self._het_slice is None
+        if (self._mix is not None and not self._generic and self._het_slice is None
                 and self._y_cov is None and self.engine.capacity() <= 4096):
             return self._mixture_loo_gradient_batch(thetas)  # (round 5: gpmi_loo_grad_batch_mix)
         if self._generic or self._mix is not None or (self._het_slice is not None and not het_batch):
@@ -610,10 +635,6 @@ class GpRegressor:
             return self._generic_lml_gradient(theta)
         theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
         mu, grad_mu = self.mean.mean_and_gradients(theta[self.mean_slice])
-        if self._mix is not None and self._mix.n_kernels != 2:
-            # the fused window-parameter row sums cover two regions (the case in which the reference's expression,
-            # covariance.py:588-593, is exact); more regions take the dense device path with the plugin's own dK
-            return self._dense_lml_gradient(theta)
         if self._mix is not None:
             lml, g_stat, alpha, trace_q, info = self._mixture_gradient(theta_stat, extra, mu)
         else:
@@ -637,9 +658,9 @@ class GpRegressor:
         (gpmi_lml_grad_batch: for N <= 4096 the evaluations advance in lockstep, every launch carrying all of them):
         returns (lml (T,), grad (T, P)).  What the lockstep multi-start search evaluates per round."""
         thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
-        if self._mix is not None and not self._generic and self._mix.n_kernels == 2 and self._het_slice is None:
-            return self._mixture_gradient_batch(thetas)  # (round 4: gpmi_lml_grad_batch_mix)
-        # more than two regions, or per-point noise on top, or per-point noise beside a dense y_cov (gpmi_lml_grad_batch_noise
+        if self._mix is not None and not self._generic and self._het_slice is None:
+            return self._mixture_gradient_batch(thetas)  # (round 4: gpmi_lml_grad_batch_mix; any number of regions: round 5)
+        # a mixture with per-point noise on top, or per-point noise beside a dense y_cov (gpmi_lml_grad_batch_noise
         # carries diagonals only - the condition of _lockstep_search): one at a time
         if self._generic or self._mix is not None or (self._het_slice is not None and self._y_cov is not None):
             res = [self.marginal_likelihood_gradient(t) for t in thetas]
@@ -678,18 +699,18 @@ class GpRegressor:
         sums h_m(i) = sum_j Q_ij K_m,ij g_m(j) contracted here with d g_m / d phi."""
         cp = self._mix
         kernels, thetas, g = self._mix_args(theta_cp)
-        lml, g_sub, hrows, alpha, info = self.engine.lml_grad_mix(kernels, thetas, g, extra, mu)
+        hw, dws = self._mix_window_terms(theta_cp)
+        lml, g_sub, hrows, alpha, info = self.engine.lml_grad_mix(kernels, thetas, g, extra, mu, row_weights=hw)
         self._mix_fit_stale = True
         grad = zeros(cp.n_params)
         grad[: g_sub.size] = g_sub
-        w, dws = cp.logistic_and_gradient(cp.x_cp, theta_cp[cp.cp_slc[0]])
-        # 1/2 sum Q o (K_0 o (A + A^T) + K_1 o (B + B^T)), A = -dw (1 - w)^T, B = dw w^T  =  sum_i dw_i (h_1 - h_0)_i
-        grad[cp.cp_slc[0]] = [float((dw * (hrows[1] - hrows[0])).sum()) for dw in dws]
+        # 1/2 sum Q o (K_c o (A + A^T) + K_{c+1} o (B + B^T)), A = -dw (1 - w)^T, B = dw w^T  =  sum_i dw_i (h_{c+1,0} - h_{c,1})_i
+        self._mix_window_gradient(cp, dws, hrows, grad)
         trace_q = float(self.engine.lml_grad_qdiag().sum()) if self._wn_index is not None else 0.0
         return lml, grad, alpha, trace_q, info
 
     def _mixture_gradient_batch(self, thetas):
-        """`marginal_likelihood_gradient` of a two-region ChangePoint model for T hyper-parameter vectors in one device
+        """`marginal_likelihood_gradient` of a ChangePoint model (any number of regions) for T hyper-parameter vectors in one device
         call: per evaluation the window weights (O(N) on the host) go along with the sub-kernels' parameters, the device
         returns the sub-kernel gradients and the row sums h_m, and the window parameters' gradient is contracted here
         as in `_mixture_gradient` (covariance.py:561-594)."""
@@ -703,9 +724,10 @@ class GpRegressor:
                    else dict(mus=np.array([m[0] for m in means])))
         args = [self._mix_args(s_) for s_ in stat]
         kernels = args[0][0]
+        win = [self._mix_window_terms(s_) for s_ in stat]
         lml, g_sub, hrows, alpha, qdiag, info = self.engine.lml_grad_batch_mix(
             kernels, [a[1] for a in args], np.array([a[2] for a in args]), ex, want_qdiag=self._wn_index is not None,
-            **mean_kw)
+            row_weights=np.array([w_[0] for w_ in win]), **mean_kw)
         self._mix_fit_stale = True
         if (info != 0).any():
             raise LinAlgError("Matrix is not positive definite")  # regression.py:555 has no guard
@@ -713,8 +735,7 @@ class GpRegressor:
         for t in range(T):
             g_cp = zeros(cp.n_params)
             g_cp[: g_sub.shape[1]] = g_sub[t]
-            w, dws = cp.logistic_and_gradient(cp.x_cp, stat[t][cp.cp_slc[0]])
-            g_cp[cp.cp_slc[0]] = [float((dw * (hrows[t, 1] - hrows[t, 0])).sum()) for dw in dws]
+            self._mix_window_gradient(cp, win[t][1], hrows[t], g_cp)
             grads[t, self.mean_slice] = array([(alpha[t] * dmu).sum() for dmu in means[t][1]])
             g_cov = zeros(self.cov.n_params)
             g_cov[self._stat_slice] = g_cp
@@ -724,7 +745,7 @@ class GpRegressor:
         return lml, grads
 
     def _mixture_loo_gradient_batch(self, thetas):
-        """`loo_likelihood_gradient` of a two-region ChangePoint model for T hyper-parameter vectors in one device call
+        """`loo_likelihood_gradient` of a ChangePoint model (any number of regions) for T hyper-parameter vectors in one device call
         (gpmi_loo_grad_batch_mix).  With Q = sym(p alpha^T) - K^-1 diag(c2) K^-1 the gradient of regression.py:509-514 is
         sum Q o dK_j for every component: the sub-kernels' from the device contraction on the weight-scaled matrix, the
         window parameters' from the device row sums h_m contracted here with d g_m / d phi as in `_mixture_gradient`
@@ -738,8 +759,10 @@ class GpRegressor:
         mean_kw = (dict(mu_const=thetas[:, 0]) if isinstance(self.mean, ConstantMean)
                    else dict(mus=np.array([m[0] for m in means])))
         args = [self._mix_args(s_) for s_ in stat]
+        win = [self._mix_window_terms(s_) for s_ in stat]
         alpha, ikdiag, pvec, mdiag, g_sub, hrows, info = self.engine.loo_grad_batch_mix(
-            args[0][0], [a[1] for a in args], np.array([a[2] for a in args]), ex, **mean_kw)
+            args[0][0], [a[1] for a in args], np.array([a[2] for a in args]), ex,
+            row_weights=np.array([w_[0] for w_ in win]), **mean_kw)
         self._mix_fit_stale = True
         if (info != 0).any():
             raise LinAlgError("Matrix is not positive definite")  # regression.py:501 has no guard
@@ -750,8 +773,7 @@ class GpRegressor:
             values[t] = float(-0.5 * (var * alpha[t] ** 2 + np.log(var)).sum())
             g_cp = zeros(cp.n_params)
             g_cp[: g_sub.shape[1]] = g_sub[t]
-            w, dws = cp.logistic_and_gradient(cp.x_cp, stat[t][cp.cp_slc[0]])
-            g_cp[cp.cp_slc[0]] = [2.0 * float((dw * (hrows[t, 1] - hrows[t, 0])).sum()) for dw in dws]
+            self._mix_window_gradient(cp, win[t][1], hrows[t], g_cp, scale=2.0)
             grads[t, self.mean_slice] = array([(pvec[t] * dmu).sum() for dmu in means[t][1]])
             g_cov = zeros(self.cov.n_params)
             g_cov[self._stat_slice] = g_cp
@@ -984,12 +1006,12 @@ class GpRegressor:
         (lockstep) device evaluations; the values of a start are then those of `launch_bfgs` evaluated through the same
         batched kernels (`batch_independent_values`).  HeteroscedasticNoise - one variance per point and evaluation - rides
         along (gpmi_lml_grad_batch_noise; since round 5 also for the leave-one-out objective: gpmi_loo_grad_batch_noise), and
-        so do two-region ChangePoint mixtures (window weights per point and evaluation: gpmi_lml_grad_batch_mix, since
-        round 5 gpmi_loo_grad_batch_mix).  Mixtures over more regions and mixtures with per-point noise have no batched
-        kernels: those starts run one after another."""
+        so do ChangePoint mixtures (window weights per point and evaluation: gpmi_lml_grad_batch_mix, since round 5
+        gpmi_loo_grad_batch_mix and any number of regions: the row-sum weights of `_mix_window_terms`).  Mixtures with
+        per-point noise on top have no batched kernels: those starts run one after another."""
         lml = self.model_selector_gradient == self.marginal_likelihood_gradient
         loo = self.model_selector_gradient == self.loo_likelihood_gradient
-        mix_ok = self._mix is None or (self._mix.n_kernels == 2 and self._het_slice is None)
+        mix_ok = self._mix is None or self._het_slice is None
         return ((lml or loo) and not self._generic and mix_ok
                 and self._y_cov is None and self.engine.capacity() <= 4096)
 

@@ -1064,7 +1064,7 @@ def test_change_point_batched_gradient(golden, gp_mod, tag, subs, wn):
 
 def test_change_point_search_and_limits(gp_mod):
     """Hyper-parameter search through the mixture path (L-BFGS-B with the analytic gradient); three regions
-    work for fit / predict / LML / gradient (dense device path); sub-kernels without device code take the dense path."""
+    work for fit / predict / LML / gradient; sub-kernels without device code take the dense path."""
     rng = np.random.default_rng(11)
     x = np.sort(rng.uniform(0, 1, 120)).reshape(-1, 1)
     y = np.where(x[:, 0] < 0.5, np.sin(4 * x[:, 0]), np.sin(40 * x[:, 0])) + 0.05 * rng.normal(size=120)
@@ -1080,8 +1080,8 @@ def test_change_point_search_and_limits(gp_mod):
     th3 = np.array([0.0, 0.0, np.log(0.3), 0.0, np.log(0.05), 0.0, np.log(0.3), 0.35, 0.03, 0.7, 0.03])
     gp3 = gp_mod.GpRegressor(x, y, y_err=e, kernel=cp3, hyperpars=th3)
     assert np.isfinite(gp3.marginal_likelihood(th3)) and np.isfinite(gp3(x[:5])[0]).all()
-    # three regions: the gradient comes from the dense device path; its sub-kernel components are exact (finite
-    # differences), the window components follow the reference's expression (tests/golden/cpx.npz pins them)
+    # three regions: the sub-kernel components of the gradient are exact (finite differences), the window components
+    # follow the reference's expression (tests/golden/cpx.npz pins them)
     _, g3 = gp3.marginal_likelihood_gradient(th3)
     for i in (1, 2, 4, 6):
         h = 1e-6
@@ -1785,12 +1785,33 @@ def test_three_region_change_point_and_loo_gradients_vs_reference(golden, gp_mod
     gp = gp_mod.GpRegressor(x, y, y_err=e, kernel=cov3, hyperpars=th3[0])
     assert list(g["cp3_labels"]) == gp.hyperpar_labels
     for t, v, gr, lv, lg in zip(th3, g["cp3_lml"], g["cp3_grad"], g["cp3_loo"], g["cp3_loo_grad"]):
-        a, b = gp.marginal_likelihood_gradient(t)
+        a, b = gp.marginal_likelihood_gradient(t)  # (round 5: the fused mixture path with the caller's row-sum weights)
         check(a, v, what="3-region lml")
         check_each(b, gr, what="3-region lml gradient")
         a, b = gp.loo_likelihood_gradient(t)
         check(a, lv, what="3-region loo")
         check_each(b, lg, what="3-region loo gradient")
+    # round 5: three regions in lockstep batches too (gpmi_lml_grad_batch_mix / gpmi_loo_grad_batch_mix with hw: the
+    # reference differentiates a change-point through ONE window factor of each neighbouring sub-kernel, covariance.py:588-593)
+    rng = np.random.default_rng(14)
+    more = np.vstack([th3, th3[0] + 0.03 * rng.standard_normal((2, th3.shape[1]))])
+    for b_ in (len(more), 1):
+        f, gr = gp.marginal_likelihood_gradient_batch(more[:b_])
+        lf, lgr = gp.loo_likelihood_gradient_batch(more[:b_])
+        for k in range(min(b_, len(th3))):
+            check(f[k], g["cp3_lml"][k], what=f"3-region lml, lockstep batch of {b_}")
+            check_each(gr[k], g["cp3_grad"][k], what=f"3-region lml gradient, lockstep batch of {b_}")
+            check(lf[k], g["cp3_loo"][k], what=f"3-region loo, lockstep batch of {b_}")
+            check_each(lgr[k], g["cp3_loo_grad"][k], what=f"3-region loo gradient, lockstep batch of {b_}")
+        for k in range(len(th3), b_):
+            a, b = gp.marginal_likelihood_gradient(more[k])
+            check(f[k], a, 1e-12, "3-region lml: batch against single")
+            check_each(gr[k], b, 1e-11, what="3-region lml gradient: batch against single")
+            a, b = gp.loo_likelihood_gradient(more[k])  # dense device path, one at a time
+            check(lf[k], a, what="3-region loo: batch against single")
+            check_each(lgr[k], b, what="3-region loo gradient: batch against single")
+    assert gp._lockstep_search()
+    assert gp_mod.GpRegressor(x, y, y_err=e, kernel=cov3, hyperpars=th3[0], cross_val=True)._lockstep_search()
     for tag, wn in (("sese", False), ("sesewn", True)):
         cov = gp_mod.ChangePoint(kernels=[gp_mod.SquaredExponential, gp_mod.SquaredExponential])
         if wn:
