@@ -481,8 +481,13 @@ class GpRegressor:
         if self._generic:
             return self._generic_loo(theta, want_gradient=True)
         if self._mix is not None or self._het_slice is not None:
-            # no fused contraction for these: the device factorises / inverts the dense K (gpmi_loo_dense) and each
-            # component of the gradient is an O(N^2) contraction with that component's own derivative
+            if self._loo_batch_ok():
+                # (round 5) the lockstep kernels take a batch of one: gpmi_loo_grad_batch_mix / gpmi_loo_grad_batch_noise
+                vals, grads = self.loo_likelihood_gradient_batch(theta[None, :])
+                return float(vals[0]), grads[0]
+            # beyond the lockstep sizes, or a mixture with per-point noise on top: the device factorises / inverts the
+            # dense K (gpmi_loo_dense) and each component of the gradient is an O(N^2) contraction with that component's
+            # own derivative
             return self._dense_loo_gradient(theta)
         theta_stat, extra = self._split_cov_theta(theta[self.cov_slice])
         mu, grad_mu = self.mean.mean_and_gradients(theta[self.mean_slice])
@@ -501,16 +506,20 @@ class GpRegressor:
         grad[self.cov_slice] = g_cov
         return LOO, grad
 
+    def _loo_batch_ok(self):
+        """A ChangePoint mixture or a HeteroscedasticNoise model (not both) whose leave-one-out gradient the lockstep
+        kernels serve: lockstep sizes, diagonal data errors."""
+        return ((self._mix is None) != (self._het_slice is None) and not self._generic and self._y_cov is None
+                and self.engine.capacity() <= 4096)
+
     def loo_likelihood_gradient_batch(self, thetas: ndarray):
         """(extension) `loo_likelihood_gradient` for T hyper-parameter vectors in one device call (gpmi_loo_grad_batch:
         for N <= 4096 the evaluations advance in lockstep): returns (LOO (T,), grad (T, P)).  What the lockstep
         multi-start search evaluates per round when the model selector is the cross-validation objective
         (regression.py:159-164)."""
         thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
-        het_batch = (self._het_slice is not None and self._mix is None and not self._generic and self._y_cov is None
-                     and self.engine.capacity() <= 4096)  # (round 5: gpmi_loo_grad_batch_noise, lockstep sizes only)
-        if (self._mix is not None and not self._generic and self._het_slice is None
-                and self._y_cov is None and self.engine.capacity() <= 4096):
+        het_batch = self._het_slice is not None and self._loo_batch_ok()  # (round 5: gpmi_loo_grad_batch_noise)
+        if self._mix is not None and self._loo_batch_ok():
             return self._mixture_loo_gradient_batch(thetas)  # (round 5: gpmi_loo_grad_batch_mix)
         if self._generic or self._mix is not None or (self._het_slice is not None and not het_batch):
             res = [self.loo_likelihood_gradient(t) for t in thetas]

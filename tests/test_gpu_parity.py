@@ -1738,7 +1738,7 @@ def test_change_point_loo_gradient_batch(golden, gp_mod):
         check(vals[0], g[f"{tag}_loo"], what="2-region loo, lockstep batch")
         check_each(grads[0], g[f"{tag}_loo_grad"], what="2-region loo gradient, lockstep batch")
         for t, v, gr in zip(thetas[1:], vals[1:], grads[1:]):
-            a, b = gp2.loo_likelihood_gradient(t)  # dense device path, one at a time
+            a, b = gp2._dense_loo_gradient(t)  # dense device path, one at a time
             check(v, a, what="2-region loo: batch against single")
             check_each(gr, b, what="2-region loo gradient: batch against single")
         assert gp_mod.GpRegressor(x, y, y_err=e, kernel=cov, hyperpars=th, cross_val=True)._lockstep_search()
@@ -1759,7 +1759,7 @@ def test_heteroscedastic_loo_gradient_batch(golden, gp_mod):
     check(vals[0], g["het_loo"], what="heteroscedastic loo, lockstep batch")
     check_each(grads[0], g["het_loo_grad"], what="heteroscedastic loo gradient, lockstep batch (99 components)")
     for t, v, gr in zip(thetas[1:], vals[1:], grads[1:]):
-        a, b = gph.loo_likelihood_gradient(t)  # dense device path, one at a time
+        a, b = gph._dense_loo_gradient(t)  # dense device path, one at a time
         check(v, a, what="heteroscedastic loo: batch against single")
         check_each(gr, b, what="heteroscedastic loo gradient: batch against single")
     # a batch of one takes the same kernels
@@ -1776,8 +1776,10 @@ def test_heteroscedastic_loo_gradient_batch(golden, gp_mod):
 # ---------------------------------------------------------------------------------------
 def test_three_region_change_point_and_loo_gradients_vs_reference(golden, gp_mod):
     """ChangePoint over three regions (LML and LOO gradients), LOO gradients of two-region ChangePoint (+ WhiteNoise)
-    and of SE + HeteroscedasticNoise: K^-1, alpha, p, W from the device (gpmi_lml_dense / gpmi_loo_dense), the
-    contraction with each component's own dK on the host - against the reference (tests/golden/cpx.npz)."""
+    and of SE + HeteroscedasticNoise against the reference (tests/golden/cpx.npz) - through the fused mixture / per-point
+    noise kernels (round 5: any number of regions; single evaluations are lockstep batches of one) AND through the dense
+    device path they replaced (K^-1, alpha, p, W from gpmi_lml_dense / gpmi_loo_dense, the contraction with each
+    component's own dK on the host), which still serves sizes beyond the lockstep limit."""
     g = golden("cpx")
     x, y, e = g["x"], g["y"], g["y_err"]
     cov3 = gp_mod.ChangePoint(kernels=[gp_mod.SquaredExponential, gp_mod.SquaredExponential, gp_mod.RationalQuadratic])
@@ -1807,7 +1809,7 @@ def test_three_region_change_point_and_loo_gradients_vs_reference(golden, gp_mod
             a, b = gp.marginal_likelihood_gradient(more[k])
             check(f[k], a, 1e-12, "3-region lml: batch against single")
             check_each(gr[k], b, 1e-11, what="3-region lml gradient: batch against single")
-            a, b = gp.loo_likelihood_gradient(more[k])  # dense device path, one at a time
+            a, b = gp._dense_loo_gradient(more[k])  # dense device path, one at a time
             check(lf[k], a, what="3-region loo: batch against single")
             check_each(lgr[k], b, what="3-region loo gradient: batch against single")
     assert gp._lockstep_search()
@@ -1818,15 +1820,23 @@ def test_three_region_change_point_and_loo_gradients_vs_reference(golden, gp_mod
             cov = cov + gp_mod.WhiteNoise()
         th = g[f"{tag}_theta"]
         gp2 = gp_mod.GpRegressor(x, y, y_err=e, kernel=cov, hyperpars=th)
-        a, b = gp2.loo_likelihood_gradient(th)
-        check(a, g[f"{tag}_loo"], what="2-region loo")
-        check_each(b, g[f"{tag}_loo_grad"], what="2-region loo gradient")
+        for fn, how in ((gp2.loo_likelihood_gradient, "lockstep batch of one"), (gp2._dense_loo_gradient, "dense path")):
+            a, b = fn(th)
+            check(a, g[f"{tag}_loo"], what=f"2-region loo ({how})")
+            check_each(b, g[f"{tag}_loo_grad"], what=f"2-region loo gradient ({how})")
+    a, b = gp._dense_loo_gradient(th3[0])
+    check(a, g["cp3_loo"][0], what="3-region loo (dense path)")
+    check_each(b, g["cp3_loo_grad"][0], what="3-region loo gradient (dense path)")
+    a, b = gp._dense_lml_gradient(th3[0])
+    check(a, g["cp3_lml"][0], what="3-region lml (dense path)")
+    check_each(b, g["cp3_grad"][0], what="3-region lml gradient (dense path)")
     xh, yh, eh = wl.synthetic_dataset(77, 96, 1)
     thh = g["het_theta"]
     gph = gp_mod.GpRegressor(xh, yh, y_err=eh, kernel=gp_mod.SquaredExponential() + gp_mod.HeteroscedasticNoise(), hyperpars=thh)
-    a, b = gph.loo_likelihood_gradient(thh)
-    check(a, g["het_loo"], what="heteroscedastic loo")
-    check_each(b, g["het_loo_grad"], what="heteroscedastic loo gradient (99 components)")
+    for fn, how in ((gph.loo_likelihood_gradient, "lockstep batch of one"), (gph._dense_loo_gradient, "dense path")):
+        a, b = fn(thh)
+        check(a, g["het_loo"], what=f"heteroscedastic loo ({how})")
+        check_each(b, g["het_loo_grad"], what=f"heteroscedastic loo gradient, 99 components ({how})")
     # cross_val=True search now works for these kernels too
     np.random.seed(6)
     gcv = gp_mod.GpRegressor(xh, yh, y_err=eh, kernel=gp_mod.SquaredExponential() + gp_mod.WhiteNoise(), cross_val=True, n_starts=2)
