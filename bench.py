@@ -26,8 +26,9 @@ Extra objects on the JSON line:
                 s_memrealtime stamps (first workgroups' start -> last workgroup's end behind its epilogue stores;
                 HIP events on the look-ahead streams would perturb the overlap).  `all_trailing` adds the launches
                 that run other tile shapes (64 x 64 remainders, launches below 384 tiles); `clock_ghz` is the shader
-                clock held during those launches (s_memtime / s_memrealtime): the update is bound by the chip's
-                power budget, `frac_at_clock` is the fraction of the MFMA peak AT THAT CLOCK.  `traffic` is HBM
+                clock held during those launches (s_memtime / s_memrealtime; it needs tens of milliseconds of
+                sustained load to reach its plateau, which the timed loop provides), `frac_at_clock` is the fraction of
+                the MFMA peak AT THAT CLOCK.  `traffic` is HBM
                 bytes per launch from the PMC passes of the same command committed under profiles/ (separate
                 rocprofv3 --pmc runs cannot be part of this run); `kernels` lists the other kernels of a step
                 (K-build, the two triangular sweeps, the predict TRSM) from an extra, un-timed pass with events.
@@ -207,13 +208,23 @@ def cpu_at_metric_size(n, d, m):
     }
 
 
-def _timeit(fn, reps=3, warm=1):
-    for _ in range(warm):
-        fn()
+def _timeit(fn, reps=3, warm=1, steady=0.1):
+    """Mean wall time of a call in STEADY STATE: the shader clock needs tens of milliseconds of sustained load to reach
+    its plateau (tools/clock_ramp.py: an N = 8192 prediction takes 1.82 ms in the first calls after an idle spell and 1.62
+    from the twentieth on; tools/bench_gemm.py: the trailing update 59 TFLOP/s over 5 launches, 66 over 40) - the headline's
+    timed loop runs there, so do these: calls for at least `steady` seconds before the clock is read, and at least `reps`
+    calls and `steady` seconds inside it."""
     t0 = time.perf_counter()
-    for _ in range(reps):
+    n = 0
+    while n < warm or time.perf_counter() - t0 < steady:
+        fn()
+        n += 1
+    t0 = time.perf_counter()
+    n = 0
+    while n < reps or (time.perf_counter() - t0 < steady and n < 500):
         out = fn()
-    return (time.perf_counter() - t0) / reps, out
+        n += 1
+    return (time.perf_counter() - t0) / n, out
 
 
 def _rate(flops, seconds):
@@ -223,7 +234,7 @@ def _rate(flops, seconds):
 
 def device_configs(wl, dev, head_gp, head_theta, N):
     """The BASELINE.json configurations the headline does not cover, timed on the device AFTER the timed region through
-    the public classes (median-free: warm-up + mean of 3 calls, host wall clock around synchronous calls):
+    the public classes (steady state - see _timeit: warm-up and timed loop of at least 0.1 s each -, host wall clock around synchronous calls):
     config 2 (SE N = 8192 d = 8: fit, predict of 1024 points, LML, LML + gradient - regression.py:218-244,188-216,528-567),
     config 4 (SE N = 4096 d = 4: EI and -ln EI with gradient at 1000 candidates, one GpOptimiser.propose_evaluation -
     acquisition.py:76-125, optimisation.py:202-249) and the LML gradient at the metric's own size.  FLOP counts: potrf
@@ -237,7 +248,7 @@ def device_configs(wl, dev, head_gp, head_theta, N):
     pts = wl.query_points(2, m2, d2)
     gp = GpRegressor(x, y, y_err=e, hyperpars=th, device=dev)
     gp.prepare_gradient()
-    fit, _ = _timeit(lambda: gp.set_hyperparameters(th), reps=5)
+    fit, _ = _timeit(lambda: gp.set_hyperparameters(th))
     pred, _ = _timeit(lambda: gp(pts))
     lml, _ = _timeit(lambda: gp.marginal_likelihood(th))
     grad, _ = _timeit(lambda: gp.marginal_likelihood_gradient(th))
@@ -262,7 +273,7 @@ def device_configs(wl, dev, head_gp, head_theta, N):
         np.random.seed(1)
         return opt.propose_evaluation()
 
-    prop, where = _timeit(propose, reps=1)
+    prop, where = _timeit(propose, reps=1, steady=0.0)
     out["config4"] = {
         "workload": f"GpOptimiser / ExpectedImprovement on SquaredExponential N={n4} d={d4}, fixed theta: 1000 candidates per "
                     f"call; one propose_evaluation = {n4} x 20 probes for the starting positions + {n4} L-BFGS-B runs in lockstep",

@@ -164,7 +164,7 @@ void update_slice(gpmi_ctx* c, hipStream_t s, double* A, int64_t ld, int nt, int
 // 32), the chain 146 + 6.1 us per trailing tile row (re-fitted in round 4; 200 + 7.6 before); the slice takes GPMI_SLICE_PCT % (default 100; 0: none) of the
 // balance point, rounded down to whole rounds of the reserved CUs.  Measured: 36.4 -> 35.9 ms per step at 100 and 130 %,
 // 37.0 at 160 % (the next update then waits for the slice); the 32 extra CUs lower the clock of the other 224 from
-// 2.364 to 2.352 GHz (the update runs at the chip's power limit), which is why the gain is a third of the idle time.
+// 2.364 to 2.352 GHz, and the chain's own launches wait behind them: the gain is a third of the idle time.
 int64_t slice_tiles(int rem, int64_t tiles_la, int64_t tiles_main, int kw, int ncu_main, int ncu_panel) {
   static const int PCT = [] {
     const char* e = std::getenv("GPMI_SLICE_PCT");
@@ -233,9 +233,10 @@ void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, dou
   // other 224.  Below GPMI_LOOKAHEAD_MIN (52) trailing tile rows the update is shorter than the panel chain on its 32 CUs
   // and everything runs in order on the full-chip stream - and so does the very first panel (nothing to overlap
   // it with: 0.49 instead of 0.92 ms).
-  // Measured and dropped: a second pair with 16 | 240 CUs for the early panels (the
-  // update is bound by the chip's power budget: 224, 240 and 256 CUs deliver the same FLOP/s, in-kernel clock
-  // 2.05 / 1.97 GHz); trailing updates applied lazily with K = 1024 .. 2048 (in place the launches are already
+  // Measured and dropped: fewer CUs for the panel chain (sustained headline step with
+  // GPMI_PANEL_CUS = 32 / 24 / 16 / 8: 32.2 / 34.2 / 38.6 / 55.4 ms: the chain becomes the longer of the two; the "equal
+  // FLOP/s on 224, 240 and 256 CUs" of rounds 2-4 was the shader clock's ramp in short measurements, not a power
+  // limit); trailing updates applied lazily with K = 1024 .. 2048 (in place the launches are already
   // split at round boundaries, which leaves +1 % for the larger K, and the narrower launches cost more).
   hipStream_t sf = lane.stream;
   const int nt = (int)(np / NB);

@@ -9,12 +9,18 @@ from inference_amd.gp import GpRegressor, RationalQuadratic, ExpectedImprovement
 
 which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4", "cfg5"]
 
-def t(fn, reps=3):
-    fn()
+def t(fn, reps=3, steady=0.1):
+    """mean wall time of a call in steady state (bench.py: _timeit - the shader clock needs tens of milliseconds of load)"""
     t0 = time.perf_counter()
-    for _ in range(reps):
+    fn()
+    while time.perf_counter() - t0 < steady:
+        fn()
+    t0 = time.perf_counter()
+    n = 0
+    while n < reps or (time.perf_counter() - t0 < steady and n < 500):
         out = fn()
-    return (time.perf_counter() - t0) / reps, out
+        n += 1
+    return (time.perf_counter() - t0) / n, out
 
 if "cfg2" in which:
     x, y, e = wl.synthetic_dataset(2, 8192, 8)
