@@ -23,9 +23,10 @@ Cases
   linv       GpLinearInverter: 1-D deconvolution (32 x 64) and 2-D tomography (300 x 400), SE / RQ / SE+WhiteNoise
   search     the stochastic callers under numpy.random.seed: multistart_bfgs (start positions, theta*, LML(theta*); LML and
              LOO objectives), differential_evo, AcquisitionFunction.starting_positions, GpOptimiser.propose_evaluation
-  cpx        the gradients the fused device paths do not cover, served by the dense device path: ChangePoint over THREE
-             regions (LML and LOO gradients), LOO gradients of two-region ChangePoint (+ WhiteNoise) and of
-             SE + HeteroscedasticNoise
+  cpx        gradients beyond the two-region LML case: ChangePoint over THREE regions (LML and LOO gradients), LOO gradients of
+             two-region ChangePoint (+ WhiteNoise) and of SE + HeteroscedasticNoise (until round 5 served by the dense device
+             path only; since then also by the fused mixture / per-point-noise kernels)
+  cp4        ChangePoint over FOUR regions [SE, RQ, SE, SE] + WhiteNoise, N=180 d=1: fit, predict, LML and LOO gradients
   plugin     a user-defined covariance function written against the plugin ABC only (Matern-3/2, workloads.Matern32Math):
              every public GpRegressor method, the seeded hyper-parameter search and an EI proposal
   linvp      GpLinearInverter with a prior that has no device kernel: the plugin Matern-3/2 (ABC only) on the tomography
@@ -605,6 +606,35 @@ def case_cpx():
     return out
 
 
+def case_cp4():
+    """ChangePoint over FOUR regions (the most the fused mixture path carries) + WhiteNoise: fit, prediction, LML and LOO
+    with their gradients at two hyper-parameter vectors (round 5: the window row sums with the caller's weights)."""
+    out = {}
+    n = 180
+    rng = np.random.default_rng(4343)
+    x = np.sort(rng.uniform(0, 1, n)).reshape(-1, 1)
+    xx = x[:, 0]
+    y = np.select([xx < 0.25, xx < 0.5, xx < 0.75], [np.sin(6 * xx), 0.5 * np.sin(40 * xx), 0.3 * xx], np.cos(18 * xx))
+    y = y + 0.04 * rng.normal(size=n)
+    e = np.full(n, 0.04)
+    pts = np.linspace(0.02, 0.98, 37).reshape(-1, 1)
+    out.update(x=x, y=y, y_err=e, pts=pts)
+    cov = ChangePoint(kernels=[SquaredExponential, RationalQuadratic, SquaredExponential, SquaredExponential]) + WhiteNoise()
+    th = np.array([[0.02 * k, -0.3, np.log(0.2), -0.5, 0.2, np.log(0.03), -0.9, np.log(0.5), -0.4, np.log(0.06 + 0.01 * k),
+                    0.25, 0.02, 0.5 + 0.01 * k, 0.03, 0.75, 0.025, np.log(0.02)] for k in range(2)])
+    gp = GpRegressor(x, y, y_err=e, kernel=cov, hyperpars=th[0])
+    out["thetas"] = th
+    out["labels"] = np.array(gp.hyperpar_labels)
+    out["alpha"] = gp.alpha
+    out["mu"], out["sig"] = gp(pts)
+    out["lml"] = np.array([gp.marginal_likelihood(t) for t in th])
+    res = [gp.marginal_likelihood_gradient(t) for t in th]
+    out["lml2"], out["grad"] = np.array([r[0] for r in res]), np.array([r[1] for r in res])
+    res = [gp.loo_likelihood_gradient(t) for t in th]
+    out["loo"], out["loo_grad"] = np.array([r[0] for r in res]), np.array([r[1] for r in res])
+    return out
+
+
 def case_plugin():
     """A covariance function that only implements the ABC (covariance.py:8-44) through the reference's classes."""
     from inference.gp import GpOptimiser
@@ -859,6 +889,7 @@ IDX_TOMO = np.arange(0, 400, 7)  # 58 rows / columns of the 400 x 400 posterior 
 CASES = {
     "search": case_search,
     "cpx": case_cpx,
+    "cp4": case_cp4,
     "plugin": case_plugin,
     "means": case_means,
     "cp": case_cp,

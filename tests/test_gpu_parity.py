@@ -1843,6 +1843,44 @@ def test_three_region_change_point_and_loo_gradients_vs_reference(golden, gp_mod
     assert np.isfinite(gcv.loo_likelihood(gcv.hyperpars))
 
 
+def test_four_region_change_point_vs_reference(golden, gp_mod):
+    """ChangePoint over FOUR regions [SE, RQ, SE, SE] + WhiteNoise - as many sub-kernels as the fused mixture path carries -
+    against the reference (tests/golden/cp4.npz: covariance.py:529-594 in regression.py:218-244, 188-216, 489-567): fit,
+    prediction, LML and leave-one-out values with their 17-component gradients, one evaluation at a time and in lockstep
+    batches (the window row sums with the caller's weights, include/gpmi.h: hw)."""
+    g = golden("cp4")
+    x, y, e, pts, th = g["x"], g["y"], g["y_err"], g["pts"], g["thetas"]
+    cov = gp_mod.ChangePoint(kernels=[gp_mod.SquaredExponential, gp_mod.RationalQuadratic, gp_mod.SquaredExponential,
+                                      gp_mod.SquaredExponential]) + gp_mod.WhiteNoise()
+    gp = gp_mod.GpRegressor(x, y, y_err=e, kernel=cov, hyperpars=th[0])
+    assert list(g["labels"]) == gp.hyperpar_labels and gp._mix is not None and gp._mix.n_kernels == 4
+    check_each(gp.alpha, g["alpha"], what="4-region alpha")
+    mu, sig = gp(pts)
+    check(mu, g["mu"], what="4-region mu")
+    check(sig, g["sig"], what="4-region sig")
+    check([gp.marginal_likelihood(t) for t in th], g["lml"], what="4-region lml")
+    for t, v, gr, lv, lg in zip(th, g["lml2"], g["grad"], g["loo"], g["loo_grad"]):
+        a, b = gp.marginal_likelihood_gradient(t)
+        check(a, v, what="4-region lml (gradient call)")
+        check_each(b, gr, what="4-region lml gradient")
+        a, b = gp.loo_likelihood_gradient(t)
+        check(a, lv, what="4-region loo")
+        check_each(b, lg, what="4-region loo gradient")
+    f, gr = gp.marginal_likelihood_gradient_batch(th)
+    lf, lgr = gp.loo_likelihood_gradient_batch(th)
+    check(f, g["lml2"], what="4-region lml, lockstep batch")
+    check(lf, g["loo"], what="4-region loo, lockstep batch")
+    for k in range(len(th)):
+        check_each(gr[k], g["grad"][k], what="4-region lml gradient, lockstep batch")
+        check_each(lgr[k], g["loo_grad"][k], what="4-region loo gradient, lockstep batch")
+    a, b = gp._dense_lml_gradient(th[1])  # the path these replaced, still serving sizes beyond the lockstep limit
+    check(a, g["lml2"][1], what="4-region lml (dense path)")
+    check_each(b, g["grad"][1], what="4-region lml gradient (dense path)")
+    assert gp._lockstep_search()
+    mu2, _ = gp(pts)  # the likelihood evaluations used the shared weight buffers: the fit is restored lazily
+    check(mu2, g["mu"], what="4-region mu after the likelihood evaluations")
+
+
 def test_kernel_call_reuses_its_device_context(gp_mod):
     """`cov(u, v, theta)` keeps one device context per point set instead of creating one per call."""
     x, y, e = wl.synthetic_dataset(3, 200, 2)
