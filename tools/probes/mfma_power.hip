@@ -8,6 +8,7 @@
 //   mode 4  both + the global loads streaming from a buffer far larger than L2 + Infinity Cache (HBM)
 //   mode 8  one global load in four from that buffer (about the kernel's 1 TB/s of fabric traffic), the others from L2
 //   mode 16 a workgroup barrier every 64 MFMAs (the ring's stage barrier)
+//   mode 32 twice the global loads (what wave-private operand slabs - a ring without barriers - would fetch)
 //   hipcc --offload-arch=gfx950 -O3 -o tools/probes/mfma_power tools/probes/mfma_power.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -60,6 +61,12 @@ __global__ __launch_bounds__(256, 2) void burn(double* out, const double* __rest
         goff += (MODE & 4) ? (size_t)gridDim.x * 65536 / 8 : 2048;  // (HBM: a fresh stripe every time; L2: 16 KiB steps in a small window)
       }
     }
+    if (MODE & 32) {  // (the second copy of the slabs: two more 16 B loads per lane from the L2 window)
+      const d2 g2 = *reinterpret_cast<const d2*>(src + ((goff * 5 + 512) & ((size_t)(2 << 20) / 8 - 1)));
+      const d2 g3 = *reinterpret_cast<const d2*>(src + ((goff * 11 + 1536) & ((size_t)(2 << 20) / 8 - 1)));
+      g0[1] += g2[0];
+      g1[0] += g3[1];
+    }
     if ((MODE & 16) && (it & 3) == 3) __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i)
@@ -96,7 +103,7 @@ void run(const char* what, int grid, double* out, const double* src, size_t mask
   unsigned long long h[2];
   hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
   const double flop = (double)grid * 4 * iters * 16.0 * 2048.0;
-  const double gbytes = (MODE & 2) ? (double)grid * 256 * iters * 32.0 : 0.0;
+  const double gbytes = (MODE & 2) ? (double)grid * 256 * iters * ((MODE & 32) ? 64.0 : 32.0) : 0.0;
   std::printf("%-46s %8.2f ms  %6.2f TFLOP/s (%.3f of 78.6)  clock %.3f GHz  global loads %.2f TB/s\n", what, ms,
               flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 78.6e12, (double)h[0] / (double)h[1] * 0.1,
               gbytes / (ms * 1e-3) / 1e12);
@@ -125,6 +132,10 @@ int main(int argc, char** argv) {
   run<11>("+ LDS reads + global loads (1 in 4 from HBM)", grid, out, big, big_bytes / 8 - 1, iters / 2, clk);
   run<19>("+ LDS reads + global loads (L2) + stage barriers", grid, out, small, small_bytes / 8 - 1, iters, clk);
   run<27>("+ LDS + loads (1 in 4 HBM) + stage barriers", grid, out, big, big_bytes / 8 - 1, iters / 2, clk);
+  run<3 + 32>("+ LDS + 2 x global loads (L2), no barrier", grid, out, small, small_bytes / 8 - 1, iters, clk);
+  run<3 + 32>("  the same, ONE workgroup per CU", ncu, out, small, small_bytes / 8 - 1, iters, clk);
+  run<3>("+ LDS + global loads (L2), ONE workgroup per CU", ncu, out, small, small_bytes / 8 - 1, iters, clk);
+  run<19>("+ LDS + loads (L2) + barriers, ONE workgroup/CU", ncu, out, small, small_bytes / 8 - 1, iters, clk);
   run<0>("registers only (again)", grid, out, small, small_bytes / 8 - 1, iters, clk);
   return 0;
 }
