@@ -1796,7 +1796,7 @@ def test_three_region_change_point_and_loo_gradients_vs_reference(golden, gp_mod
     # round 5: three regions in lockstep batches too (gpmi_lml_grad_batch_mix / gpmi_loo_grad_batch_mix with hw: the
     # reference differentiates a change-point through ONE window factor of each neighbouring sub-kernel, covariance.py:588-593)
     rng = np.random.default_rng(14)
-    more = np.vstack([th3, th3[0] + 0.03 * rng.standard_normal((2, th3.shape[1]))])
+    more = np.vstack([th3, th3[0] + 0.008 * rng.standard_normal((2, th3.shape[1]))])  # (the window widths are 0.04 - 0.05)
     for b_ in (len(more), 1):
         f, gr = gp.marginal_likelihood_gradient_batch(more[:b_])
         lf, lgr = gp.loo_likelihood_gradient_batch(more[:b_])
