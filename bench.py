@@ -818,6 +818,17 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                 "clock_ghz": clock,
                 "peak_at_clock": peak_at_clock,
                 "frac_at_clock": (ach / peak_at_clock) if peak_at_clock else None,
+                # context for `peak` (builder-run probes, NOT measured in this run): what the chip sustains
+                "reference_rates": {
+                    "source": "profiles/r05_clock_and_sustained_rates.txt (tools/probes/mfma_sustained.hip, mfma_power.hip, "
+                              "tools/bench_gemm.py; not part of this run)",
+                    "fp64_mfma_from_registers_sustained_tflops": 77.8,
+                    "same_loop_with_lds_reads_l2_loads_and_stage_barriers_tflops": 65.0,
+                    "this_kernel_alone_on_256_cus_sustained_tflops": 66.3,
+                    "this_kernel_alone_first_launches_after_idle_tflops": 59.4,
+                    "note": "the shader clock needs tens of milliseconds of sustained load to reach its plateau; inside the "
+                            "factorisation the kernel has the update stream's 224 CUs (32 run the panel chain)",
+                },
                 "all_trailing": {
                     "what": "every trailing-update launch of the factorisation: the 128x128-tile kernel above plus the 64x64-tile remainders and the launches below 384 tiles (gemm_nt_kernel<1, 0, 0, 64, 64>) on the update stream, plus the slices below, which run concurrently on the panel stream (FLOPs counted, time overlapped)",
                     "achieved": ach_all,
