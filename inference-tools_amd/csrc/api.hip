@@ -10,6 +10,7 @@
 //   api_dense.hip       plugin covariance functions (dense path), rank-one append
 // api_internal.h declares what they share.
 #include "api_internal.h"
+#include <malloc.h>
 
 
 thread_local std::string g_create_err;  // gpmi_create has no handle to keep its error text in
@@ -590,9 +591,31 @@ int gpmi_device_pci_bus_id(int device, char* buf, int cap) {
   return GPMI_OK;
 }
 
+// The GPU queues of a process stall for 15 - 30 ms whenever glibc hands the top of the heap back to the kernel (brk
+// shrink -> MMU notifier -> the driver stops the process's queues until the invalidation is through; ROCm 7.2, MI355X).
+// A host loop that allocates and frees a few hundred KB per call (NumPy result arrays around every entry point) trims
+// and re-grows the heap EVERY call once its peak exceeds M_TRIM_THRESHOLD (128 KiB by default, raised dynamically only
+// if the application happens to free an mmapped block first - which made it a per-process lottery): every lockstep batch
+// of the ChangePoint search at N = 2048 then took 28 ms instead of 4 (0.4 -> 2.6 s; profiles/r05_search.json,
+// profiles/r06_search_regression.txt: MALLOC_TRIM_THRESHOLD_ alone cures it, munmap of mmapped blocks is harmless,
+// AMD_DIRECT_DISPATCH=0 hides it).  The first handle of a process therefore keeps up to 1 GiB of freed heap top in the
+// process (mallopt; a process-wide setting, like the MALLOC_TRIM_THRESHOLD_ environment variable).  GPMI_MALLOC_TRIM=keep
+// leaves the allocator alone, and so does an application that has set MALLOC_TRIM_THRESHOLD_ / MALLOC_TOP_PAD_ itself.
+static void keep_heap_top_once() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* e = std::getenv("GPMI_MALLOC_TRIM");
+    if (e && std::strcmp(e, "keep") == 0) return;
+    if (std::getenv("MALLOC_TRIM_THRESHOLD_") || std::getenv("MALLOC_TOP_PAD_")) return;
+    (void)mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    (void)mallopt(M_TOP_PAD, 16 << 20);  // grow in 16 MiB steps (growing does not stall anything; fewer brk calls)
+  });
+}
+
 int gpmi_create(int device, gpmi_ctx** out) {
   if (!out) return GPMI_ERR_ARG;
   *out = nullptr;
+  keep_heap_top_once();
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
     g_create_err = "no HIP device visible";

@@ -72,6 +72,85 @@ struct MixEval {
 
 extern thread_local std::string g_create_err;
 
+// Inputs and outputs of a lockstep chunk between the CALLER's (pageable) host arrays and the device: everything is laid
+// out in the handle's pinned, device-mapped staging buffer (allocated once per handle) and moved by a copy kernel that
+// reads / writes that buffer over the bus - strided rows packed on the fly, no hipMemcpy2DAsync, no pageable memory handed
+// to the runtime, and no per-call host allocation (the std::vector pads of round 5 were 0.4 - 0.8 MB of malloc / free per
+// call: part of the heap churn behind the 28 ms batch calls of profiles/r06_search_regression.txt; the cure of that
+// stall itself is keep_heap_top_once() in api.hip).
+// Usage: reserve() the bytes of a chunk; host() + put() / put_copy() / up() for inputs; down() for outputs;
+// hipStreamSynchronize; finish() (pinned -> caller).
+struct RowStage {
+  gpmi_ctx* c;
+  hipStream_t s;
+  size_t used = 0;
+  struct Item {
+    char* dst;
+    size_t dpitch, off, width, height;
+  };
+  std::vector<Item> items;
+  RowStage(gpmi_ctx* ctx, hipStream_t stream) : c(ctx), s(stream) {}
+  // capacity for everything staged until the next finish(); only while nothing is staged
+  int reserve(size_t bytes) {
+    if ((int64_t)bytes <= c->h_stage_bytes) return GPMI_OK;
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr;
+    c->h_stage_bytes = 0;
+    HIPCHK(c, hipHostMalloc(&c->h_stage, bytes, hipHostMallocMapped | hipHostMallocPortable));
+    c->h_stage_bytes = (int64_t)bytes;
+    return GPMI_OK;
+  }
+  size_t take(size_t bytes) {
+    const size_t off = used;
+    used += (bytes + 255) & ~(size_t)255;
+    return off;
+  }
+  // pinned scratch of `bytes` (a multiple of 8) the caller fills in place, then put()
+  double* host(size_t bytes) { return reinterpret_cast<double*>(reinterpret_cast<char*>(c->h_stage) + take(bytes)); }
+  int put(void* dst_dev, const double* pinned, size_t bytes) {
+    ARGCHK(c, used <= (size_t)c->h_stage_bytes && bytes % 8 == 0, "internal: staging buffer too small");
+    launch_copy_rows(s, pinned, 0, static_cast<double*>(dst_dev), 0, (int64_t)(bytes / 8), 1);
+    return GPMI_OK;
+  }
+  // a contiguous caller array -> device
+  int put_copy(void* dst_dev, const void* src, size_t bytes) {
+    const size_t padded = (bytes + 7) & ~(size_t)7;
+    ARGCHK(c, used + padded + 256 <= (size_t)c->h_stage_bytes, "internal: staging buffer too small");
+    double* p = host(padded);
+    std::memcpy(p, src, bytes);
+    return put(dst_dev, p, padded);
+  }
+  // caller rows (pitch `spitch` bytes) -> device rows (pitch `dpitch` bytes)
+  int up(void* dst_dev, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height) {
+    ARGCHK(c, used + width * height + 256 <= (size_t)c->h_stage_bytes, "internal: staging buffer too small");
+    double* p = host(width * height);
+    for (size_t r = 0; r < height; ++r)
+      std::memcpy(reinterpret_cast<char*>(p) + r * width, static_cast<const char*>(src) + r * spitch, width);
+    launch_copy_rows(s, p, (int64_t)(width / 8), static_cast<double*>(dst_dev), (int64_t)(dpitch / 8), (int64_t)(width / 8),
+                     (int64_t)height);
+    return GPMI_OK;
+  }
+  // `height` device rows of `width` bytes (pitch `spitch`) -> caller rows (pitch `dpitch`), after the sync and finish()
+  int down(void* dst, size_t dpitch, const void* src_dev, size_t spitch, size_t width, size_t height) {
+    ARGCHK(c, used + width * height + 256 <= (size_t)c->h_stage_bytes, "internal: staging buffer too small");
+    const size_t off = take(width * height);
+    launch_copy_rows(s, static_cast<const double*>(src_dev), (int64_t)(spitch / 8),
+                     reinterpret_cast<double*>(reinterpret_cast<char*>(c->h_stage) + off), (int64_t)(width / 8),
+                     (int64_t)(width / 8), (int64_t)height);
+    items.push_back({static_cast<char*>(dst), dpitch, off, width, height});
+    return GPMI_OK;
+  }
+  int flush() { return GPMI_OK; }
+  // after the stream has been synchronised
+  void finish() {
+    const char* base = reinterpret_cast<const char*>(c->h_stage);
+    for (const Item& it : items)
+      for (size_t r = 0; r < it.height; ++r) std::memcpy(it.dst + r * it.dpitch, base + it.off + r * it.width, it.width);
+    items.clear();
+    used = 0;
+  }
+};
+
 // api.hip
 int lane_streams(gpmi_ctx* c, Lane& L);
 bool ensure_masked_pair(gpmi_ctx* c, Lane& L, int k);

@@ -170,10 +170,12 @@ int gpmi_lml_grad_mix(gpmi_ctx* c, int nk, const int* kernels, const double* the
     KParams pm = ps[m];
     pm.extra_diag = 0.0;
     launch_kbuild_square(s, pm, c->x, c->n, c->np, c->mix_zero, L.B2, c->ld, false);
-    for (int r = 0; r < nrow; ++r) {
-      const int64_t row = (int64_t)m * nrow + r;
-      launch_mix_rowsum(s, L.A, L.B2, c->ld, alpha_dev, hw_host ? wdev + row * c->np : gm, hdev + row * c->np, c->n);
-    }
+    // (the caller's two window factors of a sub-kernel - rows 2 m, 2 m + 1, np apart - in one pass)
+    if (hw_host)
+      launch_mix_rowsum(s, L.A, L.B2, c->ld, alpha_dev, wdev + (int64_t)m * 2 * c->np, hdev + (int64_t)m * 2 * c->np, c->n, 1, 0,
+                        0, 0, nullptr, 0, c->np);
+    else
+      launch_mix_rowsum(s, L.A, L.B2, c->ld, alpha_dev, gm, hdev + (int64_t)m * c->np, c->n);
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -293,39 +295,46 @@ int gpmi_lml_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
   // problems' row-sum (and row-sum weight) sets
   const int nrow = hw_host ? 2 : 1;
   const int64_t sW = (int64_t)nrow * GPMI_MAX_MIX * c->np;
-  std::vector<double> gpad, ex, wpad;
+  static const bool stage_times = std::getenv("GPMI_DEBUG_STAGES") != nullptr;  // debugging aid: host time per stage
+  RowStage stage(c, s);  // strided outputs reach the caller's arrays through pinned memory (api_internal.h)
+  if (int rc = stage.reserve((size_t)cap * (sizeof(double) * (3 * GPMI_MAX_MIX * c->np + c->n) + GPMI_MAX_MIX * sizeof(KParams) + 4096) +
+                             (size_t)(2 * GPMI_MAX_MIX + 2) * cap * (sizeof(double) * c->n + 256)))
+    return rc;
   for (int64_t t0 = 0; t0 < T; t0 += cap) {
+    const auto h0 = std::chrono::steady_clock::now();
     const int B = (int)((T - t0 < cap) ? T - t0 : cap);
     BatchShape bs = shape0;
     bs.count = B;
-    // weights, padded like mix_prepare does (the identity in the padding belongs to sub-kernel 0)
-    gpad.assign((size_t)B * sG, 0.0);
+    // weights, padded like mix_prepare does (the identity in the padding belongs to sub-kernel 0); every input of the
+    // chunk is laid out in the pinned staging buffer and leaves from there (RowStage, api_internal.h)
+    double* gpad = stage.host(sizeof(double) * B * sG);
+    std::fill(gpad, gpad + (size_t)B * sG, 0.0);
     for (int b = 0; b < B; ++b)
       for (int m = 0; m < nk; ++m) {
-        double* dst = gpad.data() + (size_t)b * sG + (size_t)m * c->np;
+        double* dst = gpad + (size_t)b * sG + (size_t)m * c->np;
         const double* src = g_host + ((t0 + b) * nk + m) * c->n;
         for (int64_t i = 0; i < c->np; ++i) dst[i] = i < c->n ? src[i] : (m == 0 ? 1.0 : 0.0);
       }
-    ex.assign((size_t)B, 0.0);
-    if (extra)
-      for (int b = 0; b < B; ++b) ex[(size_t)b] = extra[t0 + b];
-    HIPCHK(c, hipMemcpyAsync(c->bMixG, gpad.data(), sizeof(double) * B * sG, hipMemcpyHostToDevice, s));
+    if (int rc = stage.put(c->bMixG, gpad, sizeof(double) * B * sG)) return rc;
     if (hw_host) {
-      wpad.assign((size_t)B * sW, 0.0);
+      double* wpad = stage.host(sizeof(double) * B * sW);
+      std::fill(wpad, wpad + (size_t)B * sW, 0.0);
       for (int b = 0; b < B; ++b)
         for (int row = 0; row < 2 * nk; ++row)
           std::copy(hw_host + ((t0 + b) * 2 * nk + row) * c->n, hw_host + ((t0 + b) * 2 * nk + row + 1) * c->n,
-                    wpad.data() + (size_t)b * sW + (size_t)row * c->np);
-      HIPCHK(c, hipMemcpyAsync(c->bMixW, wpad.data(), sizeof(double) * B * sW, hipMemcpyHostToDevice, s));
+                    wpad + (size_t)b * sW + (size_t)row * c->np);
+      if (int rc = stage.put(c->bMixW, wpad, sizeof(double) * B * sW)) return rc;
     }
-    HIPCHK(c, hipMemcpyAsync(c->bMixExtra, ex.data(), sizeof(double) * B, hipMemcpyHostToDevice, s));
+    double* ex = stage.host(sizeof(double) * B);
+    for (int b = 0; b < B; ++b) ex[b] = extra ? extra[t0 + b] : 0.0;
+    if (int rc = stage.put(c->bMixExtra, ex, sizeof(double) * B)) return rc;
     for (int m = 0; m < nk; ++m)
-      HIPCHK(c, hipMemcpyAsync(c->bMixP + (int64_t)m * cap, ps.data() + (size_t)m * T + t0, sizeof(KParams) * B,
-                               hipMemcpyHostToDevice, s));
-    if (mus)
-      HIPCHK(c, hipMemcpyAsync(c->bMu, mus + t0 * c->n, sizeof(double) * B * c->n, hipMemcpyHostToDevice, s));
-    else
-      HIPCHK(c, hipMemcpyAsync(c->bMu, mu_const + t0, sizeof(double) * B, hipMemcpyHostToDevice, s));
+      if (int rc = stage.put_copy(c->bMixP + (int64_t)m * cap, ps.data() + (size_t)m * T + t0, sizeof(KParams) * B)) return rc;
+    if (mus) {
+      if (int rc = stage.put_copy(c->bMu, mus + t0 * c->n, sizeof(double) * B * c->n)) return rc;
+    } else {
+      if (int rc = stage.put_copy(c->bMu, mu_const + t0, sizeof(double) * B)) return rc;
+    }
     HIPCHK(c, hipMemsetAsync(c->bInfo, 0, sizeof(int) * B, s));
     // K = sum_m D_m K_m D_m + noise + extra: the sub-kernels' lower tiles into the second matrix, folded into the first
     // (the upper triangle of the sum is never read before the mirror below)
@@ -366,27 +375,35 @@ int gpmi_lml_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
         launch_mix_rowsum(s, c->bA, c->bB2, c->ld, alpha_dev, gm, c->bMixH + (int64_t)m * c->np, c->n, B, bs.sMat,
                           bs.sVec, sG);
       } else {
-        // (one launch per row: weights and rows share the stride, bMixG's differs)
-        for (int r = 0; r < 2; ++r)
-          launch_mix_rowsum(s, c->bA, c->bB2, c->ld, alpha_dev, c->bMixW + (int64_t)(2 * m + r) * c->np,
-                            c->bMixH + (int64_t)(2 * m + r) * c->np, c->n, B, bs.sMat, bs.sVec, sW);
+        // (weights and rows share the stride, bMixG's differs; the sub-kernel's two window factors in one pass)
+        launch_mix_rowsum(s, c->bA, c->bB2, c->ld, alpha_dev, c->bMixW + (int64_t)(2 * m) * c->np,
+                          c->bMixH + (int64_t)(2 * m) * c->np, c->n, B, bs.sMat, bs.sVec, sW, nullptr, 0, c->np);
       }
     }
     HIPCHK(c, hipGetLastError());
+    const auto h1 = std::chrono::steady_clock::now();
     HIPCHK(c, hipMemcpyAsync(c->h_bRed, c->bRed, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(c->h_bGout, c->bGout, sizeof(double) * nk * cap * W, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(c->h_bInfo, c->bInfo, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    const size_t rowb = sizeof(double) * c->n;
     for (int row = 0; row < nk * nrow; ++row)
-      HIPCHK(c, hipMemcpy2DAsync(hrows + (t0 * nk * nrow + row) * c->n, sizeof(double) * nk * nrow * c->n,
-                                 c->bMixH + (int64_t)row * c->np, sizeof(double) * sW, sizeof(double) * c->n, B,
-                                 hipMemcpyDeviceToHost, s));
+      if (int rc = stage.down(hrows + (t0 * nk * nrow + row) * c->n, rowb * nk * nrow, c->bMixH + (int64_t)row * c->np,
+                              sizeof(double) * sW, rowb, B))
+        return rc;
     if (alpha_out)
-      HIPCHK(c, hipMemcpy2DAsync(alpha_out + t0 * c->n, sizeof(double) * c->n, alpha_dev, sizeof(double) * bs.sVec,
-                                 sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+      if (int rc = stage.down(alpha_out + t0 * c->n, rowb, alpha_dev, sizeof(double) * bs.sVec, rowb, B)) return rc;
     if (qdiag_out)
-      HIPCHK(c, hipMemcpy2DAsync(qdiag_out + t0 * c->n, sizeof(double) * c->n, c->bNoise, sizeof(double) * c->np,
-                                 sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+      if (int rc = stage.down(qdiag_out + t0 * c->n, rowb, c->bNoise, sizeof(double) * c->np, rowb, B)) return rc;
+    const auto h2 = std::chrono::steady_clock::now();
+    if (int rc = stage.flush()) return rc;
     HIPCHK(c, hipStreamSynchronize(s));
+    stage.finish();
+    if (stage_times) {
+      const auto h3 = std::chrono::steady_clock::now();
+      auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+      std::fprintf(stderr, "[gpmi stages] lml_grad_batch_mix B=%d: uploads+launches %.2f ms, download enqueue %.2f ms, wait %.2f ms\n", B,
+                   ms(h0, h1), ms(h1, h2), ms(h2, h3));
+    }
     for (int b = 0; b < B; ++b) {
       const int inf = c->h_bInfo[b];
       INFOCHK(c, inf);
@@ -484,39 +501,44 @@ int gpmi_loo_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
   // problems' row-sum (and row-sum weight) sets
   const int nrow = hw_host ? 2 : 1;
   const int64_t sW = (int64_t)nrow * GPMI_MAX_MIX * c->np;
-  std::vector<double> gpad, ex, wpad;
+  RowStage stage(c, s);  // strided outputs reach the caller's arrays through pinned memory (api_internal.h)
+  if (int rc = stage.reserve((size_t)cap * (sizeof(double) * (3 * GPMI_MAX_MIX * c->np + c->n) + GPMI_MAX_MIX * sizeof(KParams) + 4096) +
+                             (size_t)(2 * GPMI_MAX_MIX + 4) * cap * (sizeof(double) * c->n + 256)))
+    return rc;
   for (int64_t t0 = 0; t0 < T; t0 += cap) {
     const int B = (int)((T - t0 < cap) ? T - t0 : cap);
     BatchShape bs = shape0;
     bs.count = B;
-    // weights, padded like mix_prepare does (the identity in the padding belongs to sub-kernel 0)
-    gpad.assign((size_t)B * sG, 0.0);
+    // weights, padded like mix_prepare does (the identity in the padding belongs to sub-kernel 0); every input of the
+    // chunk is laid out in the pinned staging buffer and leaves from there (RowStage, api_internal.h)
+    double* gpad = stage.host(sizeof(double) * B * sG);
+    std::fill(gpad, gpad + (size_t)B * sG, 0.0);
     for (int b = 0; b < B; ++b)
       for (int m = 0; m < nk; ++m) {
-        double* dst = gpad.data() + (size_t)b * sG + (size_t)m * c->np;
+        double* dst = gpad + (size_t)b * sG + (size_t)m * c->np;
         const double* src = g_host + ((t0 + b) * nk + m) * c->n;
         for (int64_t i = 0; i < c->np; ++i) dst[i] = i < c->n ? src[i] : (m == 0 ? 1.0 : 0.0);
       }
-    ex.assign((size_t)B, 0.0);
-    if (extra)
-      for (int b = 0; b < B; ++b) ex[(size_t)b] = extra[t0 + b];
-    HIPCHK(c, hipMemcpyAsync(c->bMixG, gpad.data(), sizeof(double) * B * sG, hipMemcpyHostToDevice, s));
+    if (int rc = stage.put(c->bMixG, gpad, sizeof(double) * B * sG)) return rc;
     if (hw_host) {
-      wpad.assign((size_t)B * sW, 0.0);
+      double* wpad = stage.host(sizeof(double) * B * sW);
+      std::fill(wpad, wpad + (size_t)B * sW, 0.0);
       for (int b = 0; b < B; ++b)
         for (int row = 0; row < 2 * nk; ++row)
           std::copy(hw_host + ((t0 + b) * 2 * nk + row) * c->n, hw_host + ((t0 + b) * 2 * nk + row + 1) * c->n,
-                    wpad.data() + (size_t)b * sW + (size_t)row * c->np);
-      HIPCHK(c, hipMemcpyAsync(c->bMixW, wpad.data(), sizeof(double) * B * sW, hipMemcpyHostToDevice, s));
+                    wpad + (size_t)b * sW + (size_t)row * c->np);
+      if (int rc = stage.put(c->bMixW, wpad, sizeof(double) * B * sW)) return rc;
     }
-    HIPCHK(c, hipMemcpyAsync(c->bMixExtra, ex.data(), sizeof(double) * B, hipMemcpyHostToDevice, s));
+    double* ex = stage.host(sizeof(double) * B);
+    for (int b = 0; b < B; ++b) ex[b] = extra ? extra[t0 + b] : 0.0;
+    if (int rc = stage.put(c->bMixExtra, ex, sizeof(double) * B)) return rc;
     for (int m = 0; m < nk; ++m)
-      HIPCHK(c, hipMemcpyAsync(c->bMixP + (int64_t)m * cap, ps.data() + (size_t)m * T + t0, sizeof(KParams) * B,
-                               hipMemcpyHostToDevice, s));
-    if (mus)
-      HIPCHK(c, hipMemcpyAsync(c->bMu, mus + t0 * c->n, sizeof(double) * B * c->n, hipMemcpyHostToDevice, s));
-    else
-      HIPCHK(c, hipMemcpyAsync(c->bMu, mu_const + t0, sizeof(double) * B, hipMemcpyHostToDevice, s));
+      if (int rc = stage.put_copy(c->bMixP + (int64_t)m * cap, ps.data() + (size_t)m * T + t0, sizeof(KParams) * B)) return rc;
+    if (mus) {
+      if (int rc = stage.put_copy(c->bMu, mus + t0 * c->n, sizeof(double) * B * c->n)) return rc;
+    } else {
+      if (int rc = stage.put_copy(c->bMu, mu_const + t0, sizeof(double) * B)) return rc;
+    }
     HIPCHK(c, hipMemsetAsync(c->bInfo, 0, sizeof(int) * B, s));
     // K = sum_m D_m K_m D_m + noise + extra: the sub-kernels' lower tiles into the second matrix, folded into the first
     // (the upper triangle of the sum is never read before the mirror below)
@@ -573,27 +595,25 @@ int gpmi_loo_grad_batch_mix(gpmi_ctx* c, int nk, const int* kernels, int64_t T, 
         launch_mix_rowsum(s, c->bA, c->bB2, c->ld, alpha_dev, gm, c->bMixH + (int64_t)m * c->np, c->n, B, bs.sMat,
                           bs.sVec, sG, p_dev, sLoo);
       } else {
-        for (int r = 0; r < 2; ++r)
-          launch_mix_rowsum(s, c->bA, c->bB2, c->ld, alpha_dev, c->bMixW + (int64_t)(2 * m + r) * c->np,
-                            c->bMixH + (int64_t)(2 * m + r) * c->np, c->n, B, bs.sMat, bs.sVec, sW, p_dev, sLoo);
+        launch_mix_rowsum(s, c->bA, c->bB2, c->ld, alpha_dev, c->bMixW + (int64_t)(2 * m) * c->np,
+                          c->bMixH + (int64_t)(2 * m) * c->np, c->n, B, bs.sMat, bs.sVec, sW, p_dev, sLoo, c->np);
       }
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_bGout, c->bGout, sizeof(double) * nk * cap * W, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(c->h_bInfo, c->bInfo, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    const size_t rowb = sizeof(double) * c->n;
     for (int row = 0; row < nk * nrow; ++row)
-      HIPCHK(c, hipMemcpy2DAsync(hrows + (t0 * nk * nrow + row) * c->n, sizeof(double) * nk * nrow * c->n,
-                                 c->bMixH + (int64_t)row * c->np, sizeof(double) * sW, sizeof(double) * c->n, B,
-                                 hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpy2DAsync(alpha_out + t0 * c->n, sizeof(double) * c->n, alpha_dev, sizeof(double) * bs.sVec,
-                               sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpy2DAsync(ikdiag_out + t0 * c->n, sizeof(double) * c->n, diag_dev, sizeof(double) * sLoo,
-                               sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpy2DAsync(p_out + t0 * c->n, sizeof(double) * c->n, p_dev, sizeof(double) * sLoo,
-                               sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpy2DAsync(mdiag_out + t0 * c->n, sizeof(double) * c->n, mdiag_dev, sizeof(double) * sLoo,
-                               sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+      if (int rc = stage.down(hrows + (t0 * nk * nrow + row) * c->n, rowb * nk * nrow, c->bMixH + (int64_t)row * c->np,
+                              sizeof(double) * sW, rowb, B))
+        return rc;
+    if (int rc = stage.down(alpha_out + t0 * c->n, rowb, alpha_dev, sizeof(double) * bs.sVec, rowb, B)) return rc;
+    if (int rc = stage.down(ikdiag_out + t0 * c->n, rowb, diag_dev, sizeof(double) * sLoo, rowb, B)) return rc;
+    if (int rc = stage.down(p_out + t0 * c->n, rowb, p_dev, sizeof(double) * sLoo, rowb, B)) return rc;
+    if (int rc = stage.down(mdiag_out + t0 * c->n, rowb, mdiag_dev, sizeof(double) * sLoo, rowb, B)) return rc;
+    if (int rc = stage.flush()) return rc;
     HIPCHK(c, hipStreamSynchronize(s));
+    stage.finish();
     for (int b = 0; b < B; ++b) {
       const int inf = c->h_bInfo[b];
       INFOCHK(c, inf);

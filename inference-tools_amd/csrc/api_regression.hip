@@ -368,19 +368,22 @@ static int lml_grad_batch_impl(gpmi_ctx* c, int kernel, int64_t T, const double*
   const int nt = (int)(c->np / GPMI_NB);
   const BatchShape shape0{1, c->np * c->ld, (c->np / GPMI_NB) * GPMI_NB * GPMI_NB, 4 * c->np};
   const int W = n_theta + 1;
+  const size_t rowb = sizeof(double) * c->n;
+  RowStage stage(c, s);  // strided rows travel between the caller's arrays and the device through pinned memory (api_internal.h)
+  if (int rc = stage.reserve((size_t)c->bgrad_cap * (7 * (rowb + 256) + sizeof(KParams) + 512))) return rc;
   for (int64_t t0 = 0; t0 < T; t0 += c->bgrad_cap) {
     const int B = (int)((T - t0 < c->bgrad_cap) ? T - t0 : c->bgrad_cap);
     BatchShape bs = shape0;
     bs.count = B;
-    HIPCHK(c, hipMemcpyAsync(c->bParams, ps.data() + t0, sizeof(KParams) * B, hipMemcpyHostToDevice, s));
-    if (mus)
-      HIPCHK(c, hipMemcpyAsync(c->bMu, mus + t0 * c->n, sizeof(double) * B * c->n, hipMemcpyHostToDevice, s));
-    else
-      HIPCHK(c, hipMemcpyAsync(c->bMu, mu_const + t0, sizeof(double) * B, hipMemcpyHostToDevice, s));
+    if (int rc = stage.put_copy(c->bParams, ps.data() + t0, sizeof(KParams) * B)) return rc;  // (inputs leave from pinned memory)
+    if (mus) {
+      if (int rc = stage.put_copy(c->bMu, mus + t0 * c->n, sizeof(double) * B * c->n)) return rc;
+    } else {
+      if (int rc = stage.put_copy(c->bMu, mu_const + t0, sizeof(double) * B)) return rc;
+    }
     HIPCHK(c, hipMemsetAsync(c->bInfo, 0, sizeof(int) * B, s));
     if (noise_batch)
-      HIPCHK(c, hipMemcpy2DAsync(c->bNoise, sizeof(double) * c->np, noise_batch + t0 * c->n, sizeof(double) * c->n,
-                                 sizeof(double) * c->n, B, hipMemcpyHostToDevice, s));
+      if (int rc = stage.up(c->bNoise, sizeof(double) * c->np, noise_batch + t0 * c->n, rowb, rowb, B)) return rc;
     launch_kbuild_square_batched(s, ps[0].kernel, c->bParams, B, c->x, c->n, c->np, noise_batch ? c->bNoise : c->noise,
                                  c->bA, c->ld, bs.sMat, (int)c->d, noise_batch ? c->np : 0);
     potrf_lower_batched(c, s, c->bA, c->np, c->ld, c->bInv, c->bInfo, bs);
@@ -398,17 +401,17 @@ static int lml_grad_batch_impl(gpmi_ctx* c, int kernel, int64_t T, const double*
                             bs.sVec, c->bGws, c->bGout);
     if (qdiag_out) {  // diag(alpha alpha^T - K^-1) per problem, into the noise buffer (consumed by the build above)
       launch_qdiag_batched(s, B, c->bA, c->ld, alpha_dev, c->bNoise, c->n, bs.sMat, bs.sVec, c->np);
-      HIPCHK(c, hipMemcpy2DAsync(qdiag_out + t0 * c->n, sizeof(double) * c->n, c->bNoise, sizeof(double) * c->np,
-                                 sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+      if (int rc = stage.down(qdiag_out + t0 * c->n, rowb, c->bNoise, sizeof(double) * c->np, rowb, B)) return rc;
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_bRed, c->bRed, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(c->h_bGout, c->bGout, sizeof(double) * W * B, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(c->h_bInfo, c->bInfo, sizeof(int) * B, hipMemcpyDeviceToHost, s));
     if (alpha_out)
-      HIPCHK(c, hipMemcpy2DAsync(alpha_out + t0 * c->n, sizeof(double) * c->n, alpha_dev, sizeof(double) * bs.sVec,
-                                 sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+      if (int rc = stage.down(alpha_out + t0 * c->n, rowb, alpha_dev, sizeof(double) * bs.sVec, rowb, B)) return rc;
+    if (int rc = stage.flush()) return rc;
     HIPCHK(c, hipStreamSynchronize(s));
+    stage.finish();
     for (int b = 0; b < B; ++b) {
       const int inf = c->h_bInfo[b];
       INFOCHK(c, inf);
@@ -499,19 +502,22 @@ static int loo_grad_batch_impl(gpmi_ctx* c, int kernel, int64_t T, const double*
   const int nt = (int)(c->np / GPMI_NB);
   const BatchShape shape0{1, c->np * c->ld, (c->np / GPMI_NB) * GPMI_NB * GPMI_NB, 4 * c->np};
   const int W = n_theta + 1;
+  const size_t rowb = sizeof(double) * c->n;
+  RowStage stage(c, s);  // strided rows travel between the caller's arrays and the device through pinned memory (api_internal.h)
+  if (int rc = stage.reserve((size_t)c->bgrad_cap * (7 * (rowb + 256) + sizeof(KParams) + 512))) return rc;
   for (int64_t t0 = 0; t0 < T; t0 += c->bgrad_cap) {
     const int B = (int)((T - t0 < c->bgrad_cap) ? T - t0 : c->bgrad_cap);
     BatchShape bs = shape0;
     bs.count = B;
-    HIPCHK(c, hipMemcpyAsync(c->bParams, ps.data() + t0, sizeof(KParams) * B, hipMemcpyHostToDevice, s));
-    if (mus)
-      HIPCHK(c, hipMemcpyAsync(c->bMu, mus + t0 * c->n, sizeof(double) * B * c->n, hipMemcpyHostToDevice, s));
-    else
-      HIPCHK(c, hipMemcpyAsync(c->bMu, mu_const + t0, sizeof(double) * B, hipMemcpyHostToDevice, s));
+    if (int rc = stage.put_copy(c->bParams, ps.data() + t0, sizeof(KParams) * B)) return rc;  // (inputs leave from pinned memory)
+    if (mus) {
+      if (int rc = stage.put_copy(c->bMu, mus + t0 * c->n, sizeof(double) * B * c->n)) return rc;
+    } else {
+      if (int rc = stage.put_copy(c->bMu, mu_const + t0, sizeof(double) * B)) return rc;
+    }
     HIPCHK(c, hipMemsetAsync(c->bInfo, 0, sizeof(int) * B, s));
     if (noise_batch)
-      HIPCHK(c, hipMemcpy2DAsync(c->bNoise, sizeof(double) * c->np, noise_batch + t0 * c->n, sizeof(double) * c->n,
-                                 sizeof(double) * c->n, B, hipMemcpyHostToDevice, s));
+      if (int rc = stage.up(c->bNoise, sizeof(double) * c->np, noise_batch + t0 * c->n, rowb, rowb, B)) return rc;
     launch_kbuild_square_batched(s, ps[0].kernel, c->bParams, B, c->x, c->n, c->np, noise_batch ? c->bNoise : c->noise,
                                  c->bA, c->ld, bs.sMat, (int)c->d, noise_batch ? c->np : 0);
     potrf_lower_batched(c, s, c->bA, c->np, c->ld, c->bInv, c->bInfo, bs);
@@ -544,16 +550,14 @@ static int loo_grad_batch_impl(gpmi_ctx* c, int kernel, int64_t T, const double*
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_bGout, c->bGout, sizeof(double) * W * B, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(c->h_bInfo, c->bInfo, sizeof(int) * B, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpy2DAsync(alpha_out + t0 * c->n, sizeof(double) * c->n, alpha_dev, sizeof(double) * bs.sVec,
-                               sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpy2DAsync(ikdiag_out + t0 * c->n, sizeof(double) * c->n, diag_dev, sizeof(double) * sLoo,
-                               sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpy2DAsync(p_out + t0 * c->n, sizeof(double) * c->n, p_dev, sizeof(double) * sLoo,
-                               sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+    if (int rc = stage.down(alpha_out + t0 * c->n, rowb, alpha_dev, sizeof(double) * bs.sVec, rowb, B)) return rc;
+    if (int rc = stage.down(ikdiag_out + t0 * c->n, rowb, diag_dev, sizeof(double) * sLoo, rowb, B)) return rc;
+    if (int rc = stage.down(p_out + t0 * c->n, rowb, p_dev, sizeof(double) * sLoo, rowb, B)) return rc;
     if (mdiag_out)
-      HIPCHK(c, hipMemcpy2DAsync(mdiag_out + t0 * c->n, sizeof(double) * c->n, mdiag_dev, sizeof(double) * sLoo,
-                                 sizeof(double) * c->n, B, hipMemcpyDeviceToHost, s));
+      if (int rc = stage.down(mdiag_out + t0 * c->n, rowb, mdiag_dev, sizeof(double) * sLoo, rowb, B)) return rc;
+    if (int rc = stage.flush()) return rc;
     HIPCHK(c, hipStreamSynchronize(s));
+    stage.finish();
     for (int b = 0; b < B; ++b) {
       const int inf = c->h_bInfo[b];
       INFOCHK(c, inf);

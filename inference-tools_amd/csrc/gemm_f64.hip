@@ -335,7 +335,7 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
       // fewer 64 x 64 tiles than three quarters of the CUs, and each of them long (K > 128: the products with the
       // 512 x 512 inverse blocks on the chain of the many-right-hand-side solves, 128 workgroups x up to 13 us of
       // MFMA time on one CU each): 32-row tiles put the same work on twice as many CUs
-      if (tiles == TILES_RECT && !b_kmajor && k > 128 && big * 4 * bt.count <= m32_max) bm = 32;
+      if (tiles == TILES_RECT && !b_kmajor && k > 128 && big * 4 * bt.count <= m32_max && !bt.ring_order_only) bm = 32;
     }
   }
   // the panel TRSM with the caller's word that B (the inverse of a diagonal block) is lower triangular

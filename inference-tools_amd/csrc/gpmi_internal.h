@@ -249,6 +249,10 @@ struct GemmBatch {
   // B of a one-tile-column product with K = 128 is lower triangular (B[j][k] = 0 for k > j: the inverse of a diagonal
   // block): the kernel skips the zero part
   bool b_lower_tri = false;
+  // lockstep launches whose values must not depend on how many problems share the launch: only tile shapes that sum in
+  // the ring kernels' order (no 32-row register-staged tiles at K > 128, whose use depends on the batch size; round 6:
+  // the inverse of a gradient batch of one differed from the same problem's inside a batch of six in the last bits)
+  bool ring_order_only = false;
   FlowHook hook;
 };
 struct BatchShape {
@@ -268,10 +272,11 @@ void launch_add_diag_vec(hipStream_t s, double* A, int64_t ld, const double* noi
                          int batch = 1, int64_t sA = 0, const double* extras = nullptr);
 void launch_vec_mul(hipStream_t s, const double* a, const double* b, double* out, int64_t n, int batch = 1,
                     int64_t sA = 0, int64_t sB = 0, int64_t sOut = 0);
-// h_i = sum_j (1/2 (u_i alpha_j + alpha_i u_j) - iK_ij) Km_ij g_j  (iK, Km full n x n; u = nullptr: u = alpha, the LML form)
+// h_i = sum_j (1/2 (u_i alpha_j + alpha_i u_j) - iK_ij) Km_ij g_j  (iK, Km full n x n; u = nullptr: u = alpha, the LML form);
+// pair != 0: the same pass also takes the weights at g + pair into h + pair
 void launch_mix_rowsum(hipStream_t s, const double* iK, const double* Km, int64_t ld, const double* alpha,
                        const double* g, double* h, int64_t n, int batch = 1, int64_t sMat = 0, int64_t sAlpha = 0,
-                       int64_t sG = 0, const double* u = nullptr, int64_t sU = 0);
+                       int64_t sG = 0, const double* u = nullptr, int64_t sU = 0, int64_t pair = 0);
 
 // gemm_f64.hip  (all dims multiples of 128, k multiple of 16)
 enum GemmTiles { TILES_RECT = 0, TILES_LOWER = 1 };
@@ -350,6 +355,9 @@ void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, 
 void launch_set_identity(hipStream_t s, double* Q, int64_t ld, int64_t np, int batch = 1, int64_t sMat = 0);
 // device-to-device vector copy as a kernel (a runtime D2D memcpy stalled the stream for tens of ms)
 void launch_copy(hipStream_t s, const double* src, double* dst, int64_t n);
+// `height` rows of `width` doubles: src rows `spitch` doubles apart -> dst rows `dpitch` doubles apart
+void launch_copy_rows(hipStream_t s, const double* src, int64_t spitch, double* dst, int64_t dpitch, int64_t width,
+                      int64_t height);
 // r = y - mu (padded with zeros)
 void launch_residual(hipStream_t s, const double* y, const double* mu, double mu_const, double* r,
                      int64_t n, int64_t np);

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void mix_rowsum_kernel(const double* __restric
                                                          const double* __restrict__ u, const double* __restrict__ v,
                                                          const double* __restrict__ g,
                                                          double* __restrict__ h, int64_t n, int64_t sMat,
-                                                         int64_t sU, int64_t sV, int64_t sG) {
+                                                         int64_t sU, int64_t sV, int64_t sG, int64_t pair) {
   iK += (int64_t)blockIdx.z * sMat;
   Km += (int64_t)blockIdx.z * sMat;
   u += (int64_t)blockIdx.z * sU;
@@ -67,16 +67,31 @@ __global__ __launch_bounds__(256) void mix_rowsum_kernel(const double* __restric
   const double ui = u[row], vi = v[row];
   const double* q = iK + row * ld;
   const double* k = Km + row * ld;
-  double s = 0.0;
+  // pair != 0: a second weight vector `pair` doubles behind g, its row sums `pair` doubles behind h - the two window
+  // factors of a ChangePoint sub-kernel from ONE pass over iK and Km (round 6; each sum in the order it has alone)
+  const double* g2 = g + pair;
+  double s = 0.0, s2 = 0.0;
   for (int64_t j = lane * 2; j < n; j += 128) {
     const d2_t qv = *reinterpret_cast<const d2_t*>(q + j);
     const d2_t kv = *reinterpret_cast<const d2_t*>(k + j);
-    s = fma((0.5 * (ui * v[j] + vi * u[j]) - qv[0]) * kv[0], g[j], s);
-    if (j + 1 < n) s = fma((0.5 * (ui * v[j + 1] + vi * u[j + 1]) - qv[1]) * kv[1], g[j + 1], s);
+    const double t0 = (0.5 * (ui * v[j] + vi * u[j]) - qv[0]) * kv[0];
+    s = fma(t0, g[j], s);
+    if (pair) s2 = fma(t0, g2[j], s2);
+    if (j + 1 < n) {
+      const double t1 = (0.5 * (ui * v[j + 1] + vi * u[j + 1]) - qv[1]) * kv[1];
+      s = fma(t1, g[j + 1], s);
+      if (pair) s2 = fma(t1, g2[j + 1], s2);
+    }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if (lane == 0) h[row] = s;
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off, 64);
+    s2 += __shfl_down(s2, off, 64);
+  }
+  if (lane == 0) {
+    h[row] = s;
+    if (pair) h[row + pair] = s2;
+  }
 }
 
 }  // namespace
@@ -103,11 +118,11 @@ void launch_vec_mul(hipStream_t s, const double* a, const double* b, double* out
 
 void launch_mix_rowsum(hipStream_t s, const double* iK, const double* Km, int64_t ld, const double* alpha,
                        const double* g, double* h, int64_t n, int batch, int64_t sMat, int64_t sAlpha, int64_t sG,
-                       const double* u, int64_t sU) {
+                       const double* u, int64_t sU, int64_t pair) {
   if (!u) {  // the LML form: u = v = alpha
     u = alpha;
     sU = sAlpha;
   }
   hipLaunchKernelGGL(mix_rowsum_kernel, dim3((unsigned)((n + 3) / 4), 1, (unsigned)batch), dim3(256), 0, s, iK, Km, ld,
-                     u, alpha, g, h, n, sMat, sU, sAlpha, sG);
+                     u, alpha, g, h, n, sMat, sU, sAlpha, sG, pair);
 }

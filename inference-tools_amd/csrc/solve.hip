@@ -292,6 +292,13 @@ __global__ void set_identity_kernel(double* __restrict__ Q, int64_t ld, int64_t 
     *reinterpret_cast<d2_t*>(Q + i * ld + j) = d2_t{j == i ? 1.0 : 0.0, j + 1 == i ? 1.0 : 0.0};
 }
 
+// `height` rows of `width` doubles between a strided and a packed layout (grid: x over the row, y = row)
+__global__ void copy_rows_kernel(const double* __restrict__ src, int64_t spitch, double* __restrict__ dst, int64_t dpitch,
+                                 int64_t width) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < width) dst[(int64_t)blockIdx.y * dpitch + j] = src[(int64_t)blockIdx.y * spitch + j];
+}
+
 __global__ void copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];
@@ -557,7 +564,8 @@ void trsm_identity_batched(hipStream_t s, const double* L, int64_t np, int64_t l
   launch_set_identity(s, Q, ld, np, bs.count, bs.sMat);
   GemmBatch inplace{bs.count, bs.sMat, bs.sMat, bs.sInv};
   inplace.b_lower_tri = true;  // products with the inverses of the diagonal blocks
-  const GemmBatch upd{bs.count, bs.sMat, bs.sMat, bs.sMat};
+  GemmBatch upd{bs.count, bs.sMat, bs.sMat, bs.sMat};
+  upd.ring_order_only = true;  // the K = 512 updates of a batch of one must sum like those of a batch of many
   for (int J = 0; J < nt; J += OBT) {
     const int Je = (J + OBT < nt) ? J + OBT : nt;
     for (int j = J; j < Je; ++j) {
@@ -576,6 +584,13 @@ void trsm_identity_batched(hipStream_t s, const double* L, int64_t np, int64_t l
       launch_gemm_nt(s, TILES_RECT, OP_SUB, Q + (int64_t)Je * NB, ld, Q + (int64_t)J * NB, ld,
                      L + (int64_t)Je * NB * ld + (int64_t)J * NB, ld, Je, rest, (Je - J) * NB, nullptr, upd);
   }
+}
+
+void launch_copy_rows(hipStream_t s, const double* src, int64_t spitch, double* dst, int64_t dpitch, int64_t width,
+                      int64_t height) {
+  if (width <= 0 || height <= 0) return;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((width + 255) / 256), (unsigned)height), dim3(256), 0, s, src, spitch,
+                     dst, dpitch, width);
 }
 
 void launch_copy(hipStream_t s, const double* src, double* dst, int64_t n) {

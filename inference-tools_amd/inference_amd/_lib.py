@@ -22,6 +22,7 @@ KERNEL_SE = 0
 KERNEL_RQ = 1
 PROF_KBUILD, PROF_SYRK, PROF_PANEL, PROF_SOLVE, PROF_SYRK_REST, PROF_TRSM, PROF_SYRK_SLICE, PROF_FLOW = 0, 1, 2, 3, 4, 5, 6, 7
 OPT_LOCKSTEP_ALWAYS, OPT_RESERVE_POINTS, OPT_NO_FLOW = 1, 2, 3
+_TRACE_MS = float(os.environ["GPMI_TRACE_CALLS"]) if os.environ.get("GPMI_TRACE_CALLS") else None
 ERR_INTERNAL = -5  # GPMI_ERR_INTERNAL
 
 
@@ -210,7 +211,16 @@ class Handle:
                              "gpmi_lml_grad_batch_mix", "gpmi_loo_grad_batch_mix"))
 
     def call(self, name, *args):
-        rc = getattr(self.lib, name)(self.ctx, *args)
+        if _TRACE_MS is not None:  # GPMI_TRACE_CALLS=<ms>: report every entry-point call that takes longer (debugging aid)
+            import time
+
+            t0 = time.perf_counter()
+            rc = getattr(self.lib, name)(self.ctx, *args)
+            dt = (time.perf_counter() - t0) * 1e3
+            if dt > _TRACE_MS:
+                print(f"[gpmi trace] {name}: {dt:.2f} ms", file=sys.stderr, flush=True)
+        else:
+            rc = getattr(self.lib, name)(self.ctx, *args)
         if (rc == ERR_INTERNAL and name in self._REPEATABLE and not getattr(self, "_no_flow", False)
                 and b"[flow-tail]" in self.lib.gpmi_last_error(self.ctx)):
             # a flag-ordered launch did not get its kernels side by side within its time limit (gpmi.h: GPMI_OPT_NO_FLOW):

@@ -588,6 +588,7 @@ class GpRegressor:
         from inference_amd import _lib
 
         self.engine.set_option(_lib.OPT_LOCKSTEP_ALWAYS, 1 if on else 0)
+        self._batch_independent = bool(on)
 
     def marginal_likelihood_batch(self, thetas: ndarray) -> ndarray:
         """(extension) `marginal_likelihood` for T hyper-parameter vectors at once, spread over
@@ -1002,7 +1003,16 @@ class GpRegressor:
                 f, g = batch(X)
                 return -f, -g
 
-            results = lockstep_lbfgsb(neg_batch, array(starting_positions), self.hp_bounds)
+            # a round in which ONE start is still running must evaluate it with the lockstep kernels too (a batch of one
+            # otherwise takes the single-evaluation kernels, whose gradient differs in the last bits - same LML, gradient
+            # within 1e-11): with this a start's iterates do not depend on which other starts share its rounds
+            # (tests: test_lockstep_search_is_independent_of_the_grouping)
+            was = getattr(self, "_batch_independent", False)
+            self.batch_independent_values(True)
+            try:
+                results = lockstep_lbfgsb(neg_batch, array(starting_positions), self.hp_bounds)
+            finally:
+                self.batch_independent_values(was)
         else:
             results = [self.launch_bfgs(x0) for x0 in starting_positions]
         # (start, optimum, objective) of every run, in the order of the starts: what the search did, for inspection

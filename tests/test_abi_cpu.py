@@ -36,6 +36,37 @@ def test_library_exports_every_declared_symbol():
     assert lib.gpmi_version() == 100
 
 
+def test_library_exports_nothing_but_the_header():
+    """The converse: the dynamic symbol table of the plugin boundary is include/gpmi.h and nothing else (csrc/gpmi.map) -
+    no mangled C++ internals, no std:: instantiations, no HIP bookkeeping symbols."""
+    import subprocess
+
+    from inference_amd import _lib
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    defined = sorted({line.split()[-1].split("@")[0] for line in out.splitlines() if line.strip()})
+    assert defined == declared_symbols(), sorted(set(defined) ^ set(declared_symbols()))
+
+
+def test_product_names_no_vendor_solver():
+    """rocSOLVER / rocBLAS / hipBLAS(Lt) / hipSOLVER are a yardstick for tools/vendor_yardstick.py only: nothing of the
+    product (sources, build recipe, the built library's dependencies) names them."""
+    import subprocess
+
+    from inference_amd import _lib
+
+    banned = re.compile(r"rocsolver|rocblas|hipblas|hipsolver|rocsparse|cublas|cusolver", re.I)
+    pkg = os.path.join(ROOT, "inference-tools_amd")
+    for dirpath, dirs, files in os.walk(pkg):
+        dirs[:] = [d for d in dirs if d not in ("build", "__pycache__", ".pytest_cache", "lib")]
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".map")) or f == "Makefile":
+                assert not banned.search(open(os.path.join(dirpath, f)).read()), f"{f} names a vendor BLAS / solver"
+    assert not banned.search(open(HEADER).read())
+    needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert not banned.search(needed), needed
+
+
 def test_ctypes_table_matches_header():
     from inference_amd import _lib
 

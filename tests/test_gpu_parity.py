@@ -1062,6 +1062,57 @@ def test_change_point_batched_gradient(golden, gp_mod, tag, subs, wn):
     check(mu, g[f"{tag}_mu"], what="mu after the batched evaluations")
 
 
+@pytest.mark.parametrize("model", ["se", "change_point"])
+def test_lockstep_search_is_independent_of_the_grouping(gp_mod, model):
+    """(round 6) A start of the lockstep multi-start search (regression.py:585-605) ends where it ends whatever other starts
+    share its rounds: the search evaluates every round - also one with a single survivor - with the lockstep kernels
+    (GPMI_OPT_LOCKSTEP_ALWAYS), whose values do not depend on the batch (gemm: `ring_order_only`), so the iterates of
+    six starts advanced together are, bit for bit, those of every start advanced alone.  The single-evaluation kernels
+    (`launch_bfgs`, one start after another) give the same LML and a gradient within 1e-11 (a different order of summation):
+    those iterates fork in the last digits on a flat optimum, which is why the two paths' optima agree to ~1e-11 only
+    (profiles/r06_search.json)."""
+    from inference_amd.gp._lockstep import lockstep_lbfgsb
+
+    rng = np.random.default_rng(11)
+    n = 700
+    x = np.sort(rng.uniform(0, 1, n)).reshape(-1, 1)
+    y = np.where(x[:, 0] < 0.5, np.sin(4 * x[:, 0]), np.sin(40 * x[:, 0])) + 0.05 * rng.normal(size=n)
+    e = np.full(n, 0.05)
+    if model == "se":
+        th0 = np.array([0.0, 0.0, np.log(0.1)])
+        gp = gp_mod.GpRegressor(x, y, y_err=e, kernel=gp_mod.SquaredExponential, hyperpars=th0)
+    else:
+        th0 = np.array([0.0, 0.0, np.log(0.3), 0.0, np.log(0.05), 0.5, 0.05])
+        gp = gp_mod.GpRegressor(x, y, y_err=e, kernel=gp_mod.ChangePoint(kernels=[gp_mod.SquaredExponential] * 2), hyperpars=th0)
+    assert gp._lockstep_search()
+    lwr, upr = (np.array([b[i] for b in gp.hp_bounds], dtype=float) for i in (0, 1))
+    starts = lwr + (upr - lwr) * rng.uniform(0.2, 0.8, size=(4, len(lwr)))
+
+    def neg(X):
+        f, g = gp.marginal_likelihood_gradient_batch(X)
+        return -f, -g
+
+    gp.batch_independent_values(True)
+    together = lockstep_lbfgsb(neg, starts, gp.hp_bounds, maxiter=25)
+    for k, x0 in enumerate(starts):
+        alone = lockstep_lbfgsb(neg, x0[None, :], gp.hp_bounds, maxiter=25)[0]
+        assert np.array_equal(alone[0], together[k][0]) and alone[1] == together[k][1], (k, alone[1], together[k][1])
+        assert alone[2]["funcalls"] == together[k][2]["funcalls"] and alone[2]["nit"] == together[k][2]["nit"]
+    # a value does not depend on its batch: the same theta alone and as the last row of a batch of five, bit for bit
+    f1, g1 = gp.marginal_likelihood_gradient_batch(starts[:1])
+    f5, g5 = gp.marginal_likelihood_gradient_batch(np.vstack([starts[1:], starts[:1], starts[1:2]]))
+    assert f1[0] == f5[3] and np.array_equal(g1[0], g5[3])
+    gp.batch_independent_values(False)
+    # the single-evaluation kernels: same LML to the last bits' neighbourhood, gradient within 1e-11
+    fs, gs = gp.marginal_likelihood_gradient(starts[0])
+    check(fs, f1[0], 1e-13, "single-evaluation LML vs lockstep batch of one")
+    check_each(gs, g1[0], 1e-11, what="single-evaluation gradient vs lockstep batch of one")
+    # the constructor's search leaves the option as it found it
+    np.random.seed(3)
+    gp2 = gp_mod.GpRegressor(x[:200], y[:200], y_err=e[:200], kernel=gp_mod.SquaredExponential)
+    assert gp2._lockstep_search() and not getattr(gp2, "_batch_independent", False)
+
+
 def test_change_point_search_and_limits(gp_mod):
     """Hyper-parameter search through the mixture path (L-BFGS-B with the analytic gradient); three regions
     work for fit / predict / LML / gradient; sub-kernels without device code take the dense path."""

@@ -11,7 +11,8 @@ import workloads as wl
 from inference_amd.gp import GpRegressor
 
 out = []
-for cfg, n, d in ((1, 512, 2), (5, 2048, 4), (4, 4096, 4)):
+ONLY = os.environ.get("SEARCH_ONLY", "")  # "cp": the ChangePoint cases only; "cp2048": the N = 2048 one only
+for cfg, n, d in ((1, 512, 2), (5, 2048, 4), (4, 4096, 4)) if not ONLY else ():
     x, y, e = wl.synthetic_dataset(cfg, n, d)
     row = {"config": cfg, "N": n, "d": d}
     GpRegressor(x, y, y_err=e, hyperpars=wl.timing_theta(wl.SE, y, d)).marginal_likelihood_gradient_batch(
@@ -42,6 +43,9 @@ from inference_amd.gp import ChangePoint, SquaredExponential
 
 rng = np.random.default_rng(11)
 for n in (512, 2048):
+    if ONLY == "cp2048" and n != 2048:
+        rng.uniform(0, 1, n), rng.normal(size=n)  # (the same data as in the full run)
+        continue
     x = np.sort(rng.uniform(0, 1, n)).reshape(-1, 1)
     y = np.where(x[:, 0] < 0.5, np.sin(4 * x[:, 0]), np.sin(40 * x[:, 0])) + 0.05 * rng.normal(size=n)
     e = np.full(n, 0.05)
@@ -59,3 +63,10 @@ for n in (512, 2048):
     GpRegressor._lockstep_search = keep
     out.append(row)
 print(json.dumps(out, indent=1))
+# the accelerated path must never be the slower one (round 5's profile held a 2.55 s lockstep search beside a 0.94 s serial
+# one for a whole round and nobody looked: profiles/r06_search_regression.txt)
+slow = [(r["config"], r["N"], k) for r in out for k in ("", "cross_val_")
+        if k + "lockstep_seconds" in r and r[k + "lockstep_seconds"] > r[k + "serial_seconds"]]
+if slow:
+    print("search_time.py: the lockstep search is slower than the serial one for", slow, file=sys.stderr)
+    sys.exit(1)
