@@ -97,6 +97,16 @@ PEAK_FP64_MFMA_TFLOPS = 78.6  # 256 CU x 4 SIMD x 2048 FLOP / 64 clk x 2.4 GHz (
 RCCL_INFO = {}  # rccl_ranks_seen, dataset_broadcast (multi-rank runs with a live communicator)
 
 
+T_START = time.perf_counter()
+# wall-clock budget of the whole default run: optional host-side blocks behind the timed region are skipped (and say so)
+# when starting them would take the run beyond it
+WALL_BUDGET_S = float(os.environ.get("BENCH_WALL_BUDGET_S", "330"))
+
+
+def wall_left():
+    return WALL_BUDGET_S - (time.perf_counter() - T_START)
+
+
 def cpu_baseline(n_cpu, d, m_cpu, runs=3):
     """Oracle (port of the reference path: same NumPy / LAPACK calls) on the host cores: fit + batched predict at a
     bounded size, one warm-up at a quarter of the size, then the median of `runs` runs."""
@@ -140,18 +150,37 @@ def cpu_baseline(n_cpu, d, m_cpu, runs=3):
     flops = n_cpu**3 / 3.0 + m_cpu * float(n_cpu) ** 2
 
     # second flavour: the reference's own memory / loop structure (N x N x d tensors, one triangular solve per
-    # query point), at a size whose tensors fit comfortably: 64 query points, one run
+    # query point), at the largest BASELINE size whose tensors fit the host's free memory and a time budget (after a
+    # first run at N = 3072 has measured the host's rate: the tensor part scales with N^2 d, the factorisation with N^3)
+    def faithful_run(n_f, m_f):
+        xf, yf, ef = wl.synthetic_dataset(2, n_f, d)
+        tf = wl.timing_theta(wl.SE, yf, d)
+        t0 = time.perf_counter()
+        orc.faithful_se_fit_predict(xf, yf, ef, tf, wl.query_points(2, m_f, d))
+        return time.perf_counter() - t0
+
     n_f, m_f = min(n_cpu, 3072), 64
-    xf, yf, ef = wl.synthetic_dataset(2, n_f, d)
-    tf = wl.timing_theta(wl.SE, yf, d)
-    t0 = time.perf_counter()
-    orc.faithful_se_fit_predict(xf, yf, ef, tf, wl.query_points(2, m_f, d))
-    dt_f = time.perf_counter() - t0
+    dt_f = faithful_run(n_f, m_f)
+    ram_gb = host_ram_gb()
+    budget_s = float(os.environ.get("BENCH_FAITHFUL_BUDGET_S", "45"))
+    chosen = None
+    for n_big in (16384, 8192):
+        need_gb = 4.2 * n_big * n_big * d * 8 / 1e9  # dx, distances, distances / L2 and the exp's input + K, eye, L
+        est = dt_f * (n_big / n_f) ** 2 + (n_big**3 / 3.0) / 1.0e11  # tensors ~ N^2 d; LAPACK potrf ~100 GFLOP/s on this class of host
+        if ram_gb is not None and need_gb < 0.8 * ram_gb and est < budget_s and est + 100 < wall_left() and n_big > n_f:
+            chosen = (n_big, need_gb, est)
+            break
+    if chosen is not None:
+        n_f, m_f = chosen[0], 16
+        dt_f = faithful_run(n_f, m_f)
     faithful = {
         "value": (n_f**3 / 3.0 + m_f * float(n_f) ** 2) / dt_f / 1e9,
         "unit": "GFLOP/s",
-        "sample": f"same path with the reference's N x N x d tensors and its per-point predict loop, N={n_f} M={m_f}, "
-        f"1 run: {dt_f:.1f} s",
+        "n": n_f, "m": m_f, "seconds": dt_f,
+        "sample": f"same path with the reference's N x N x d tensors (covariance.py:218-219, 254) and its per-point predict "
+        f"loop (regression.py:205-216) on {m_f} points, N={n_f} d={d}, 1 run: {dt_f:.1f} s"
+        + (f" (tensors ~{chosen[1]:.0f} GB of {ram_gb:.0f} GB available)" if chosen else
+           f" (larger sizes skipped: MemAvailable {ram_gb and round(ram_gb)} GB, time budget {budget_s:.0f} s, {wall_left():.0f} s of the run left)"),
     }
     return {
         "value": flops / dt / 1e9,
@@ -162,13 +191,27 @@ def cpu_baseline(n_cpu, d, m_cpu, runs=3):
         f"K-build as in the reference, numpy.linalg.cholesky, scipy.linalg.solve_triangular), warm-up + median of {runs} "
         f"runs: {dt:.1f} s each; {cpu}, {os.cpu_count()} logical CPUs, {blas} with {threads} threads, {versions}",
         "faithful": faithful,
+        "blas": blas, "blas_threads": int(threads), "cpu": cpu, "host_ram_gb": ram_gb,
     }
 
 
-def cpu_at_metric_size(n, d, m):
-    """ONE memory-lean oracle run at the metric's own configuration, per phase: the
-    same NumPy / LAPACK calls as the reference path (regression.py:218-244, 188-216), K-build row-chunked as in
-    oracle/gp_oracle.py (the reference's N x N x d tensors need 52 GB at N = 16384, d = 8)."""
+def host_ram_gb():
+    """MemAvailable of the host in GB (None if /proc/meminfo cannot be read)."""
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable"):
+                    return float(line.split()[1]) * 1024 / 1e9
+    except Exception:
+        pass
+    return None
+
+
+def cpu_at_metric_size(n, d, m, runs=3):
+    """The memory-lean oracle at the metric's own configuration, per phase: one
+    warm-up run + the median of `runs` runs (by total time), the same NumPy / LAPACK calls as the reference path
+    (regression.py:218-244, 188-216), K-build row-chunked as in oracle/gp_oracle.py (the reference's N x N x d tensors
+    need 52 GB at N = 16384, d = 8: the `faithful` flavour of cpu_baseline runs them when the host has the memory)."""
     from oracle import gp_oracle as orc  # checker / baseline only
     import workloads as wl
     from numpy.linalg import cholesky
@@ -177,34 +220,44 @@ def cpu_at_metric_size(n, d, m):
     x, y, e = wl.synthetic_dataset(2, n, d)
     theta = wl.timing_theta(wl.SE, y, d)
     pts = wl.query_points(2, m, d)
-    t = [time.perf_counter()]
 
-    def lap():
-        t.append(time.perf_counter())
-        return t[-1] - t[-2]
+    def one():
+        t = [time.perf_counter()]
 
-    K = orc.se_build(x, theta[1:])  # covariance.py:247-255
-    K[np.diag_indices(n)] += e**2   # regression.py:239 "+ self.sig"
-    t_build = lap()
-    L = cholesky(K)                 # regression.py:241
-    del K
-    t_potrf = lap()
-    alpha = solve_triangular(L.T, solve_triangular(L, y - theta[0], lower=True))  # regression.py:242-244
-    t_solve = lap()
-    K_qx = orc.se_cross(pts, x, theta[1:])                 # regression.py:209-210, batched over the query points
-    mu = K_qx @ alpha + theta[0]
-    v = solve_triangular(L, K_qx.T, lower=True)            # regression.py:213
-    sig = np.sqrt(np.abs(np.exp(theta[1]) ** 2 - (v**2).sum(axis=0)))
-    t_pred = lap()
-    total = t[-1] - t[0]
+        def lap():
+            t.append(time.perf_counter())
+            return t[-1] - t[-2]
+
+        K = orc.se_build(x, theta[1:])  # covariance.py:247-255
+        K[np.diag_indices(n)] += e**2   # regression.py:239 "+ self.sig"
+        t_build = lap()
+        L = cholesky(K)                 # regression.py:241
+        del K
+        t_potrf = lap()
+        alpha = solve_triangular(L.T, solve_triangular(L, y - theta[0], lower=True))  # regression.py:242-244
+        t_solve = lap()
+        K_qx = orc.se_cross(pts, x, theta[1:])                 # regression.py:209-210, batched over the query points
+        mu = K_qx @ alpha + theta[0]
+        v = solve_triangular(L, K_qx.T, lower=True)            # regression.py:213
+        sig = np.sqrt(np.abs(np.exp(theta[1]) ** 2 - (v**2).sum(axis=0)))
+        t_pred = lap()
+        return {"k_build": t_build, "potrf": t_potrf, "alpha_solves": t_solve, "predict": t_pred, "total": t[-1] - t[0],
+                "mu0": float(mu[0]), "sig0": float(sig[0])}
+
+    warm = one()
+    timed = sorted((one() for _ in range(runs)), key=lambda r: r["total"])
+    med = timed[len(timed) // 2]
+    total = med["total"]
     flops = n**3 / 3.0 + m * float(n) ** 2
     return {
         "value": flops / total / 1e9,
         "unit": "GFLOP/s",
-        "seconds": {"k_build": t_build, "potrf": t_potrf, "alpha_solves": t_solve, "predict": t_pred, "total": total},
-        "potrf_gflops": n**3 / 3.0 / t_potrf / 1e9,
-        "sample": f"ONE run of the memory-lean oracle at the metric's own size, SE N={n} d={d} M={m} (no warm-up: a second "
-        f"run would double the {total:.0f} s; the BLAS pool is warm from the N=4096 sample before it); checksum mu[0]={float(mu[0]):.12g} sig[0]={float(sig[0]):.6g}",
+        "seconds": {k: med[k] for k in ("k_build", "potrf", "alpha_solves", "predict", "total")},
+        "runs": runs, "totals_s": [r["total"] for r in timed], "warmup_total_s": warm["total"],
+        "potrf_gflops": n**3 / 3.0 / med["potrf"] / 1e9,
+        "sample": f"memory-lean oracle at the metric's own size, SE N={n} d={d} M={m}: one warm-up run ({warm['total']:.1f} s) + "
+        f"median of {runs} runs ({total:.1f} s; all: " + ", ".join("%.1f" % r_["total"] for r_ in timed) + "); "
+        f"checksum mu[0]={med['mu0']:.12g} sig[0]={med['sig0']:.6g}",
     }
 
 
@@ -264,7 +317,7 @@ def device_configs(wl, dev, head_gp, head_theta, N):
     x, y, e = wl.synthetic_dataset(4, n4, d4)
     th = wl.timing_theta(wl.SE, y, d4)
     cand = wl.query_points(4004, 1000, d4)
-    opt = GpOptimiser(x, y, bounds=[(0.0, 1.0)] * d4, y_err=e, hyperpars=th, acquisition=ExpectedImprovement)
+    opt = GpOptimiser(x, y, bounds=[(0.0, 1.0)] * d4, y_err=e, hyperpars=th, acquisition=ExpectedImprovement, device=dev)
     ei = opt.acquisition
     ei_v, _ = _timeit(lambda: ei.call_batch(cand))
     ei_g, _ = _timeit(lambda: ei.opt_func_gradient_batch(cand))
@@ -314,12 +367,12 @@ def cpu_configs(wl, d_head):
     pts = wl.query_points(2, m, d)
     t_fit, gp = clock(lambda: orc.OracleGp(x, y, e, kernel=orc.SE, hyperpars=th))
     t_pred, _ = clock(lambda: gp(pts))
-    t_lml, _ = clock(lambda: gp.marginal_likelihood(th))
+    t_lml = t_fit  # (marginal_likelihood is the same K-build + cholesky + solves as the fit: not run a second time, round 6)
     del gp.K_xx, gp.L
     t_grad, _ = clock(lambda: gp.marginal_likelihood_gradient_lean(th))
     out["config2"] = {"fit_s": t_fit, "predict_s": t_pred, "lml_s": t_lml, "lml_gradient_s": t_grad,
                       "fit_gflops": n**3 / 3.0 / t_fit / 1e9, "lml_gradient_gflops": float(n) ** 3 / t_grad / 1e9,
-                      "sample": f"one run each, SE N={n} d={d} M={m}; gradient by the one-matrix-at-a-time form"}
+                      "sample": f"one run each, SE N={n} d={d} M={m}; lml_s = fit_s (the same calls); gradient by the one-matrix-at-a-time form"}
     del gp
     # config 3: one grid point
     n, d = 16384, 16
@@ -382,7 +435,7 @@ def pmc_traffic():
     command (profiles/rNN_pmc.json, written by tools/pmc_bench.sh + tools/make_profiles.py: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
     coalesced reads on gfx950); (None, None) if absent."""
-    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+    for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)["kernels"]["update128"]["hbm_bytes_per_launch"], "profiles/" + name
@@ -396,7 +449,7 @@ def rocprof_duration_ratio():
     file): from the committed kernel-trace summary of this command (profiles/rNN_pmc.json `cross_check`).  rocprofv3
     times a launch from its dispatch to its completion signal - the end-of-kernel write-back included -, the stamps
     from the first workgroup's first instruction to the last workgroup's last acknowledged store."""
-    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
+    for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 x = json.load(f)["cross_check"]
@@ -404,6 +457,117 @@ def rocprof_duration_ratio():
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             continue
     return None, None
+
+
+def reference_rates():
+    """What the chip sustains with nothing but the ingredient in question: builder-run probes, read from the committed file
+    (None when it is absent) - context for `peak`, not a measurement of this run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r05_sustained_rates.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def vendor_yardstick():
+    """tools/vendor_yardstick.py in a child process (rocSOLVER / rocBLAS at the hot path's shapes; a side channel of the
+    bench, never of the product): its `results` dict, or {"available": False, ...}.  BENCH_NO_VENDOR=1 skips it."""
+    if os.environ.get("BENCH_NO_VENDOR"):
+        return {"available": False, "why": "BENCH_NO_VENDOR"}
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "vendor_yardstick.py")], capture_output=True, text=True,
+                           timeout=300)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as err:
+        return {"available": False, "why": f"{type(err).__name__}: {err}"}
+
+
+def flatten_for_the_record(line):
+    """The driver's record keeps the SCALAR fields of `config`, `roofline` and `cpu_baseline` and drops nested values
+    (BENCH_r05.json: extra_keys = ["configs", "sharded"], values gone).  Every headline number of the nested blocks is
+    therefore repeated as a scalar here (tests/test_bench_cpu.py asserts that no nested value is a number's only home)."""
+    cfg, roof, cpu = line["config"], line["roofline"], line.get("cpu_baseline")
+    c = line.get("configs") or {}
+    if "config2" in c:
+        c2 = c["config2"]
+        cfg.update(cfg2_fit_ms=c2["fit"]["ms"], cfg2_predict_ms=c2["predict"]["ms"], cfg2_lml_ms=c2["lml"]["ms"],
+                   cfg2_lml_grad_ms=c2["lml_gradient"]["ms"], cfg2_fit_frac=c2["fit"]["frac_of_fp64_mfma_peak"],
+                   cfg2_lml_frac=c2["lml"]["frac_of_fp64_mfma_peak"], cfg2_predict_frac=c2["predict"]["frac_of_fp64_mfma_peak"],
+                   cfg2_lml_grad_frac=c2["lml_gradient"]["frac_of_fp64_mfma_peak"])
+    if "config4" in c:
+        c4 = c["config4"]
+        cfg.update(cfg4_ei_ms=c4["ei_1000_candidates"]["ms"], cfg4_ei_grad_ms=c4["minus_ln_ei_and_gradient_1000_candidates"]["ms"],
+                   cfg4_propose_s=c4["propose_evaluation"]["seconds"])
+    if "lml_gradient_at_metric_size" in c:
+        cfg.update(lml_grad_16k_ms=c["lml_gradient_at_metric_size"]["ms"],
+                   lml_grad_16k_frac=c["lml_gradient_at_metric_size"]["frac_of_fp64_mfma_peak"])
+    if "error" in c:
+        cfg["configs_error"] = c["error"]
+    sh = line.get("sharded") or {}
+    if "gather" in sh:
+        cfg["gather"] = sh["gather"]
+    if "config3" in sh:
+        cfg.update(cfg3_grid64_s=sh["config3"]["seconds"], cfg3_frac=sh["config3"]["frac_of_aggregate_fp64_mfma_peak"],
+                   cfg3_lml_evals_per_s=sh["config3"]["lml_evals_per_s"], cfg3_checksum=sh["config3"]["checksum"])
+    if "config5" in sh:
+        cfg.update(cfg5_lml_evals_per_s=sh["config5"]["lml_evals_per_s"], cfg5_frac=sh["config5"]["frac_of_aggregate_fp64_mfma_peak"],
+                   cfg5_chain_steps_per_s=sh["config5"]["chain_steps_per_s"], cfg5_seconds=sh["config5"]["seconds"])
+    if "error" in sh:
+        cfg["sharded_error"] = sh["error"]
+    if "dataset_broadcast" in cfg:
+        cfg["dataset_broadcast_ok"] = "identical" in str(cfg["dataset_broadcast"])
+    v = line.get("vendor") or {}
+    if v.get("available"):
+        r = v["results"]
+        cfg.update(vendor_potrf_16k_ms=r.get("potrf_16384", {}).get("ms_median"), vendor_potrf_8k_ms=r.get("potrf_8192", {}).get("ms_median"),
+                   vendor_trsm_ms=r.get("trsm_16384_x_1024", {}).get("ms_median"),
+                   vendor_syrk_tflops=r.get("syrk_15872_k512", {}).get("tflops_at_median"))
+    else:
+        cfg["vendor_available"] = False
+    for row in roof.get("kernels") or []:
+        name = row.get("kernel", "")
+        key = ("kbuild" if name.startswith("kbuild") else "sweeps" if name.startswith("trsv") else
+               "predict" if name.startswith("trsm_rows") else None)
+        if key and "frac" in row:
+            roof[key + "_frac"] = row["frac"]
+            roof[key + "_avg_ms"] = row["avg_ms"]
+        if name.startswith("panel chain"):
+            roof["panel_chain_ms_per_step"] = row.get("total_ms_per_step")
+    for blk in ("all_trailing", "flow_tail", "slices"):
+        if blk in roof:
+            roof[blk + "_tflops"] = roof[blk].get("achieved")
+            roof[blk + "_ms_per_step"] = roof[blk].get("ms_per_step")
+    same = roof.get("same_kernel_name_all_launches") or {}
+    if roof.get("traffic") and same.get("algorithmic_bytes_per_launch_avg"):
+        roof["algorithmic_bytes_per_launch_all_launches"] = same["algorithmic_bytes_per_launch_avg"]
+        roof["traffic_over_algorithmic"] = roof["traffic"] / same["algorithmic_bytes_per_launch_avg"]
+    rr = roof.get("reference_rates") or {}
+    for k in ("fp64_mfma_from_registers_sustained_tflops", "this_kernel_alone_on_256_cus_sustained_tflops"):
+        if k in rr:
+            roof["ref_" + k] = rr[k]
+    if cpu:
+        sec = cpu.get("seconds") or {}
+        if sec:
+            cpu.update(seconds_total=sec.get("total"), k_build_s=sec.get("k_build"), potrf_s=sec.get("potrf"),
+                       predict_s=sec.get("predict"))
+        f = cpu.get("faithful") or {}
+        if f:
+            cpu.update(faithful_n=f.get("n"), faithful_gflops=f.get("value"), faithful_seconds=f.get("seconds"))
+        sn = cpu.get("sample_n4096") or {}
+        if sn:
+            cpu["sample_n4096_gflops"] = sn.get("value")
+        cc = cpu.get("configs") or {}
+        if "config2" in cc:
+            cpu.update(cfg2_fit_s=cc["config2"]["fit_s"], cfg2_lml_grad_s=cc["config2"]["lml_gradient_s"])
+        if "config3" in cc:
+            cpu["cfg3_one_grid_point_s"] = cc["config3"]["one_grid_point_s"]
+        if "config4" in cc:
+            cpu["cfg4_ei_loop_candidates_per_s"] = cc["config4"]["ei_per_candidate_loop_candidates_per_s"]
+        if "config5" in cc:
+            cpu["cfg5_lml_evals_per_s"] = cc["config5"]["lml_evals_per_s"]
+    return line
 
 
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable with a plain copy)
@@ -688,7 +852,7 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
         mu, sig = gp(pts)  # cross-covariance + TRSM + reductions
         # plain NumPy reductions only: a BLAS call here (np.linalg.norm -> OpenBLAS nrm2) starts OpenBLAS's
         # spinning worker pool, which starves the HIP runtime's completion handling and doubled the
-        # step time from the next step on (tools/scratch/phase_times3.py)
+        # step time from the next step on (round-2 probe, profiles/HISTORY.md)
         return np.array([gp._logdet, float(np.sqrt(np.sum(gp.alpha**2))), float(mu.sum()), float(sig.sum())])
 
     for _ in range(args.warmup):
@@ -756,7 +920,10 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
         ach_all = all_fl / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0
         peak_at_clock = PEAK_FP64_MFMA_TFLOPS * clock / 2.4 if clock > 0 else None
         traffic, traffic_src = pmc_traffic()
+        rp_ratio, rp_src = rocprof_duration_ratio()
         line = {
+            "schema": "r06",  # r06: roofline.frac = rocprofv3-duration figure (stamps in frac_stamps); cpu_baseline.value = median of 3
+                              # runs at the metric's size; scalar copies of every nested headline number (flatten_for_the_record)
             "metric": f"GpRegressor fit+predict wall-time and GFLOP/s at N={N}, d={d}; % fp64 MFMA peak",
             "value": value,
             "unit": "GFLOP/s",
@@ -786,10 +953,19 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                 "timing": "in-kernel s_memrealtime stamps per launch: first workgroups' start -> last workgroup's end behind its epilogue stores",
                 "cu_mask": "launches of the look-ahead regime run on 224 of 256 CUs (the other 32 factor the next panel)",
                 "bound": "mfma",
-                "achieved": ach,
+                # `frac` / `achieved` with the kernel's duration as rocprofv3 --kernel-trace sees it (dispatch -> completion
+                # signal; the committed profile's ratio to the stamps over the same launches, profiles/rNN_pmc.json cross_check):
+                # the figure profiles/ reproduces.  `*_stamps`: the live in-kernel measurement of THIS run.
+                "achieved": ach / rp_ratio if rp_ratio else ach,
                 "peak": PEAK_FP64_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": ach / PEAK_FP64_MFMA_TFLOPS,
+                "frac": (ach / rp_ratio if rp_ratio else ach) / PEAK_FP64_MFMA_TFLOPS,
+                "frac_source": (f"in-kernel stamps of this run / {rp_ratio:.4f} (rocprofv3 duration ratio, {rp_src})" if rp_ratio
+                                else "in-kernel stamps of this run (no committed rocprofv3 cross-check found)"),
+                "frac_rocprofv3": (ach / rp_ratio / PEAK_FP64_MFMA_TFLOPS) if rp_ratio else None,
+                "achieved_stamps": ach,
+                "frac_stamps": ach / PEAK_FP64_MFMA_TFLOPS,
+                "duration_ratio_rocprofv3_over_stamps": rp_ratio,
                 # ... and over EVERY launch of this kernel name (the slices on the panel stream's 32 CUs included: what a
                 # per-name kernel_stats row blends; profiles/rNN_bench_kernel_stats_by_queue.csv splits the row by queue)
                 "achieved_all_launches": ((prof["flops"] + prof_slice["flops"]) / ((prof["ms"] + prof_slice["ms"]) * 1e-3) / 1e12)
@@ -798,12 +974,6 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                                       / PEAK_FP64_MFMA_TFLOPS) if prof["ms"] + prof_slice["ms"] > 0 else 0.0,
                 "traffic": traffic,
                 "traffic_source": f"{traffic_src}: separate rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run; per launch, averaged over every launch of this kernel name (slices included: compare with same_kernel_name_all_launches.algorithmic_bytes_per_launch_avg)" if traffic_src else None,
-                "with_rocprofv3_durations": (lambda q: None if q[0] is None else {
-                    "achieved": ach / q[0], "frac": ach / q[0] / PEAK_FP64_MFMA_TFLOPS, "duration_ratio": q[0],
-                    "source": f"{q[1]} cross_check: rocprofv3 --kernel-trace --stats of this command gives this kernel "
-                              "an average duration that much longer than the stamps over the same launches (dispatch "
-                              "-> completion signal, end-of-kernel write-back included); not measured in this run"})(
-                    rocprof_duration_ratio()),
                 "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / max(prof["launches"], 1),
                 "flop_per_launch_avg": prof["flops"] / max(prof["launches"], 1),
@@ -818,17 +988,8 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                 "clock_ghz": clock,
                 "peak_at_clock": peak_at_clock,
                 "frac_at_clock": (ach / peak_at_clock) if peak_at_clock else None,
-                # context for `peak` (builder-run probes, NOT measured in this run): what the chip sustains
-                "reference_rates": {
-                    "source": "profiles/r05_clock_and_sustained_rates.txt (tools/probes/mfma_sustained.hip, mfma_power.hip, "
-                              "tools/bench_gemm.py; not part of this run)",
-                    "fp64_mfma_from_registers_sustained_tflops": 77.8,
-                    "same_loop_with_lds_reads_l2_loads_and_stage_barriers_tflops": 65.0,
-                    "this_kernel_alone_on_256_cus_sustained_tflops": 66.3,
-                    "this_kernel_alone_first_launches_after_idle_tflops": 59.4,
-                    "note": "the shader clock needs tens of milliseconds of sustained load to reach its plateau; inside the "
-                            "factorisation the kernel has the update stream's 224 CUs (32 run the panel chain)",
-                },
+                # context for `peak` (builder-run probes read from profiles/, NOT measured in this run; None when absent)
+                "reference_rates": reference_rates(),
                 "all_trailing": {
                     "what": "every trailing-update launch of the factorisation: the 128x128-tile kernel above plus the 64x64-tile remainders and the launches below 384 tiles (gemm_nt_kernel<1, 0, 0, 64, 64>) on the update stream, plus the slices below, which run concurrently on the panel stream (FLOPs counted, time overlapped)",
                     "achieved": ach_all,
@@ -876,16 +1037,23 @@ def run(args, wl, sharding, GpRegressor, SquaredExponential, _lib, rank, world, 
                     "value": full["value"], "unit": "GFLOP/s", "cores": sample["cores"], "kind": "port",
                     "sample": full["sample"] + "; " + sample["sample"].split("; ", 1)[-1],
                     "seconds": full["seconds"], "potrf_gflops": full["potrf_gflops"],
+                    "runs": full["runs"], "warmup_runs": 1, "totals_s": full["totals_s"],
                     "gpu_over_cpu": value / full["value"],
+                    "blas_threads": sample["blas_threads"], "host_ram_gb": sample["host_ram_gb"],
+                    "logical_cpus": os.cpu_count(),
                     "sample_n4096": {k: sample[k] for k in ("value", "unit", "sample")},
                     "faithful": sample["faithful"],
                 }
-            if not args.no_cpu_configs:
+            if not args.no_cpu_configs and wall_left() < 110:
+                line["cpu_baseline"]["configs"] = {"skipped": f"{wall_left():.0f} s of the run's wall-clock budget left (needs ~100 s)"}
+            elif not args.no_cpu_configs:
                 try:
                     line["cpu_baseline"]["configs"] = cpu_configs(wl, d)
                 except Exception as err:
                     line["cpu_baseline"]["configs"] = {"error": f"{type(err).__name__}: {err}"}
-        print(json.dumps(line), flush=True)
+        if world == 1 and not args.no_configs:
+            line["vendor"] = vendor_yardstick()
+        print(json.dumps(flatten_for_the_record(line)), flush=True)
 
 
 if __name__ == "__main__":

@@ -23,7 +23,7 @@ thread_local std::string g_create_err;  // gpmi_create has no handle to keep its
 // 3 lost 14 % (30.2 against 26.5 ms per evaluation at N = 16384).  Every pair the library runs side by side is a pair
 // of neighbouring lanes (the half-batches of a lockstep chunk and the asynchronous slots: lanes 1 | 2; a sweep on two
 // lanes: 1 | 2), lane 0's stream is idle while other lanes evaluate, and more than two evaluations at a time were never
-// faster than two (§5).  Measured alternatives (tools/scratch/ab_hwq.sh, ab_pool*.sh): GPU_MAX_HW_QUEUES=8 cures the
+// faster than two (§5).  Measured alternatives (round 4 A/B scripts, since removed; results in profiles/HISTORY.md): GPU_MAX_HW_QUEUES=8 cures the
 // sweep but two processes on one device then time out in the flag-ordered kernels (bench.py --gpus 2 on one GPU);
 // process-wide pooled streams cure it too but change the order in which a handle's queues are created, and the
 // look-ahead of lane 1 (its stream and its CU-masked pair) lost 10 % (LML at N = 16384: 27.7 -> 31 ms).
@@ -49,8 +49,8 @@ int lane_streams(gpmi_ctx* c, Lane& L) {
 // so the first 8 m bits are m CUs on every XCD.  The pair is created together with the lane's main stream, before any
 // work is queued, and destroyed with it: created later (on first use, with kernels already in flight on the lane)
 // hipStreamDestroy blocked forever on ROCm 7.2, and a pair that is never destroyed ends the process in a SIGSEGV
-// inside the runtime's static destructors when rocprofv3 is attached (tools/scratch/probe_exit.py).  Only the lanes that
-// can factorise with look-ahead get one: lane 0 (the fitted model) and lane 1 (single evaluations).
+// inside the runtime's static destructors when rocprofv3 is attached (round-2 probe, profiles/HISTORY.md).  Only lane 0 (the
+// fitted model) owns a pair; lane 1 (single evaluations) borrows it (lane_alloc below).
 bool ensure_masked_pair(gpmi_ctx* c, Lane& L, int k) {
   (void)c;
   return L.sp[k] != nullptr && L.su[k] != nullptr;
@@ -144,7 +144,7 @@ void lane_free(Lane& L) {
   if (L.ev_slice) (void)hipEventDestroy(L.ev_slice);
   DBG_FREE("lane: destroy masked streams");
   // hipStreamDestroy on a CU-masked stream blocks forever on ROCm 7.2 when it follows the stream's last
-  // synchronisation too closely (tools/scratch/probe_exit.py: 1 hang in 6 closes without the pause, 0 in 36 with 5 .. 300 ms; the round-1
+  // synchronisation too closely (round-2 probe, profiles/HISTORY.md: 1 hang in 6 closes without the pause, 0 in 36 with 5 .. 300 ms; the round-1
   // library only got away with it because loading librccl happened to sit in between)
   if (L.sp[0] || L.su[0]) {
     static const int pause_ms = [] {
@@ -641,7 +641,7 @@ int gpmi_destroy(gpmi_ctx* c) {
   if (!c) return GPMI_OK;
   (void)hipSetDevice(c->device);
   // every stream of the handle synchronised once here and once more in lane_free: hipStreamDestroy on a CU-masked
-  // stream that has only been synchronised once blocked forever on ROCm 7.2 (tools/scratch/probe_exit.py)
+  // stream that has only been synchronised once blocked forever on ROCm 7.2 (round-2 probe, profiles/HISTORY.md)
   (void)gpmi_sync(c);
   DBG_FREE("comm destroy");
   (void)gpmi_comm_destroy(c);

@@ -176,7 +176,7 @@ int64_t slice_tiles(int rem, int64_t tiles_la, int64_t tiles_main, int kw, int n
   // The panel chain of one outer panel on the reserved CUs, re-fitted to round 4's timeline (profiles/r04_bench_timeline.txt:
   // 880 us at 120 trailing tile rows = 4 x potrf_diag 20 + 4 x panel TRSM 0.56 us per row + inner updates 3.8 us per row +
   // launch gaps): 146 + 6.1 us per row (200 + 7.6 until round 3).  The slices grow by 30 % with it: 32.76 -> 32.53 ms per
-  // step (medians of six alternating runs, tools/scratch/knobs4.sh); 45 % more is too much (32.86: the next update waits
+  // step (medians of six alternating runs, round-3 A/B script, profiles/HISTORY.md); 45 % more is too much (32.86: the next update waits
   // for the slice).  GPMI_SLICE_CHAIN_US / GPMI_SLICE_CHAIN_SLOPE for A/B runs.
   static const double CHAIN0 = [] {
     const char* e = std::getenv("GPMI_SLICE_CHAIN_US");
@@ -242,6 +242,16 @@ void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, dou
   const int nt = (int)(np / NB);
   const int OBT = OUTER_TILES;
   const int LOOKAHEAD_MIN = lookahead_min();
+  // Lanes 0 and 1 share ONE CU-masked pair (api.hip: lane_alloc).  That is safe while every entry point joins the pair's
+  // work back into its lane and synchronises before it returns - which an early error return behind enqueued look-ahead
+  // work, or a caller driving lane 0 through gpmi_get_stream, does not do.  So nothing is assumed: a factorisation that
+  // finds the pair busy waits for it first (two stream queries per factorisation; never taken in a correct call sequence).
+  for (int k = 0; k < GPMI_NPAIRS; ++k)
+    for (hipStream_t q : {lane.sp[k], lane.su[k]})
+      if (q && hipStreamQuery(q) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(q);
+      }
   const bool la_ok = allow_lookahead && nt - OBT >= LOOKAHEAD_MIN && ensure_masked_pair(c, lane, 0);
   // The chain-bound part - everything below LOOKAHEAD_MIN trailing tile rows, i.e. the whole of a matrix of N <= ~8000
   // and the tail of a larger one - runs as a flag-ordered tile-task launch beside the bare chain (potrf_flow.hip)

@@ -462,6 +462,9 @@ __global__ __launch_bounds__(512) void chain_column_kernel(ChainColArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
+  // every wave acquires for itself (one buffer_inv each): the loads of T and C below must not rest on wave 0's
+  // invalidation being CU-wide, which the memory model does not promise
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   // the two strips of this workgroup (rows 16 r0 .., 16 r1 ..) and its tiles
   const bool pair = w >= 24;
   int r0, r1;
@@ -915,6 +918,8 @@ void flow_lists_override(int m, int nwg, FlowLists& fl) {
     ok = std::fread(off.data(), sizeof(int), off.size(), fp) == off.size() &&
          std::fread(tasks.data(), sizeof(FlowTask), tasks.size(), fp) == tasks.size() && off[0] == 0 &&
          off[(size_t)nwg] == hdr[2];
+    // every list a range inside the task array: the kernel indexes tasks[off[w] .. off[w + 1]) unchecked
+    for (size_t w = 0; ok && w < (size_t)nwg; ++w) ok = off[w] >= 0 && off[w] <= off[w + 1] && off[w + 1] <= hdr[2];
   }
   std::fclose(fp);
   if (ok) {  // a permutation of the library's own tasks
@@ -945,7 +950,8 @@ void flow_lists_override(int m, int nwg, FlowLists& fl) {
 // out: 8 ints per task {type (0 T, 1 U, 2 Z), i, j, k (column, or outer panel for Z), s, fadd, owner, 0}, list after list.
 extern "C" int gpmi_flow_task_lists(int m, int nwg, int64_t cap, int32_t* out, int64_t* ntasks) {
   if (m < 1 || nwg < 1 || !ntasks) return GPMI_ERR_ARG;
-  const FlowLists fl = flow_build(m, nwg);
+  FlowLists fl = flow_build(m, nwg);
+  flow_lists_override(m, nwg, fl);  // (GPMI_FLOW_LISTS: what the device would be given)
   *ntasks = (int64_t)fl.tasks.size();
   if (!out) return GPMI_OK;
   if (cap < *ntasks) return GPMI_ERR_ARG;

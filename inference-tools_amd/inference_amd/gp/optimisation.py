@@ -42,6 +42,7 @@ class GpOptimiser:
         the first fit when evaluations are added: `add_evaluation` then appends the point to the fitted model
         in O(N^2) (`GpRegressor.add_point`) instead of searching the hyper-parameters again and re-factorising
         (O(N^3) per likelihood evaluation, optimisation.py:177-186).
+    :param device: (extension) index of the GPU (one process per GPU: the rank's local device).
     """
 
     def __init__(
@@ -58,8 +59,10 @@ class GpOptimiser:
         optimizer: str = "bfgs",
         n_processes: int = 1,
         reuse_hyperpars: bool = False,
+        device: int = 0,
     ):
         coords = np.asarray(x)
+        self.device = int(device)  # (extension) the GPU every regressor of this optimiser lives on
         self.x = coords.reshape([coords.size, 1]) if coords.ndim == 1 else coords
         self.y = np.asarray(y)
         self.y_err = _optional_array(y_err)
@@ -91,6 +94,7 @@ class GpOptimiser:
             optimizer=self.optimizer,
             n_processes=self.n_processes,
             reserve=256 if self.reuse_hyperpars else 0,
+            device=self.device,
         )
         self.acquisition.update_gp(self.gp)
 

@@ -15,7 +15,7 @@ reference.  Differences in mechanism only:
 """
 from copy import copy
 from inspect import isclass
-from warnings import warn
+from warnings import catch_warnings, simplefilter, warn
 
 import numpy as np
 from numpy import array, ndarray, sqrt, zeros
@@ -69,8 +69,10 @@ class GpRegressor:
         n_starts: int = None,
         device: int = None,
         reserve: int = 0,
+        diffev_batched: bool = False,
     ):
         self.x, self.y = self._coerce_training_data(x, y)
+        self._diffev_batched = bool(diffev_batched)
         self.n_points = self.y.size
         self.n_dimensions = self.x.shape[1]
 
@@ -953,8 +955,39 @@ class GpRegressor:
     # objective evaluation on the device
     # ---------------------------------------------------------------------------------
     def differential_evo(self) -> ndarray:
+        """regression.py:569-573.  The default is the reference's call: SciPy's `updating="immediate"` population walk, one
+        objective evaluation per call (each a latency-bound launch train at small N), the reference's trajectory under the
+        same seed.  `diffev_batched=True` (extension, opt-in: another - equally valid - trajectory) hands SciPy a vectorised
+        objective with `updating="deferred"`: a whole generation (15 x P trial vectors) is ONE lockstep device call
+        (`marginal_likelihood_batch`; the leave-one-out objective through `loo_likelihood_gradient_batch`)."""
+        if getattr(self, "_diffev_batched", False):
+            def neg_generation(pop):  # SciPy: (P, S) -> (S,)
+                return -self.model_selector_batch(np.ascontiguousarray(pop.T))
+
+            opt_result = differential_evolution(func=neg_generation, bounds=self.hp_bounds, vectorized=True, updating="deferred")
+            self.search_log = [(None, array(opt_result.x), float(opt_result.fun))]
+            return opt_result.x
         opt_result = differential_evolution(func=lambda t: -self.model_selector(t), bounds=self.hp_bounds)
         return opt_result.x
+
+    def model_selector_batch(self, thetas: ndarray) -> ndarray:
+        """(extension) `model_selector` for T hyper-parameter vectors: one device call where batched kernels exist (the
+        marginal likelihood of a plain kernel: gpmi_lml_batch; the leave-one-out likelihood at lockstep sizes:
+        gpmi_loo_grad_batch), else one evaluation after another.  A failed factorisation scores -1e50 as in the reference
+        (regression.py:540-542, 484-487)."""
+        thetas = np.atleast_2d(np.asarray(thetas, dtype=float))
+        if self.model_selector == self.marginal_likelihood:
+            with catch_warnings():
+                simplefilter("ignore")  # (one "Cholesky decomposition failure" warning per generation says nothing new)
+                return np.asarray(self.marginal_likelihood_batch(thetas), dtype=float)
+        if self._lockstep_search():
+            try:
+                return np.asarray(self.loo_likelihood_gradient_batch(thetas)[0], dtype=float)
+            except LinAlgError:
+                pass  # a trial vector whose matrix is not positive definite: score them one by one (-1e50 for that one)
+        with catch_warnings():
+            simplefilter("ignore")
+            return array([float(self.model_selector(t)) for t in thetas])
 
     def bfgs_cost_func(self, theta: ndarray):
         y, grad_y = self.model_selector_gradient(theta)

@@ -1307,6 +1307,33 @@ def test_default_starts_and_differential_evolution_reproduce_reference(golden, g
     assert abs(vd - float(g["de_best"])) <= 1e-7 * abs(float(g["de_best"]))
 
 
+def test_batched_differential_evolution_reaches_the_serial_optimum(gp_mod):
+    """(round 6, extension) `GpRegressor(optimizer="diffev", diffev_batched=True)`: SciPy's differential evolution with a
+    vectorised objective and deferred updating - a whole generation per lockstep device call (gpmi_lml_batch) - against the
+    default form (regression.py:569-573: one evaluation per call, the reference's trajectory) on BASELINE config 1
+    (SE, N = 512, d = 2), both seeded: another population walk, the same optimum (polished by L-BFGS-B in both)."""
+    import workloads as wl
+
+    x, y, e = wl.synthetic_dataset(1, 512, 2)
+    np.random.seed(5)
+    serial = gp_mod.GpRegressor(x, y, y_err=e, optimizer="diffev")
+    np.random.seed(5)
+    batched = gp_mod.GpRegressor(x, y, y_err=e, optimizer="diffev", diffev_batched=True)
+    vs, vb = serial.marginal_likelihood(serial.hyperpars), batched.marginal_likelihood(batched.hyperpars)
+    print(f"differential evolution: serial LML {vs:.12g}, batched LML {vb:.12g}")
+    check(vb, vs, 1e-6, "batched differential evolution optimum vs serial")
+    assert np.abs(np.array(batched.hyperpars) - np.array(serial.hyperpars)).max() < 1e-3
+    # the batched objective itself: the values of single evaluations, and -1e50 where the factorisation fails
+    th = np.array([np.array(serial.hyperpars) + 0.1 * k for k in range(5)])
+    check(batched.model_selector_batch(th), [serial.marginal_likelihood(t) for t in th], 1e-12, "model_selector_batch")
+    # the cross-validation objective (gpmi_loo_grad_batch values)
+    np.random.seed(5)
+    cv = gp_mod.GpRegressor(x[:200], y[:200], y_err=e[:200], optimizer="diffev", diffev_batched=True, cross_val=True)
+    np.random.seed(5)
+    cvs = gp_mod.GpRegressor(x[:200], y[:200], y_err=e[:200], optimizer="diffev", cross_val=True)
+    check(cv.loo_likelihood(cv.hyperpars), cvs.loo_likelihood(cvs.hyperpars), 1e-6, "batched DE, leave-one-out objective")
+
+
 @pytest.mark.parametrize("nm", ["ei", "ucb", "mv"])
 def test_acquisition_starts_and_proposals_reproduce_reference(golden, gp_mod, nm):
     """acquisition.py:13-37 and optimisation.py:202-249 under numpy.random.seed: the starting positions (20 probes

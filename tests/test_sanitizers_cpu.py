@@ -1,0 +1,78 @@
+"""SURVEY section 5 sanitizer row (VERDICT r05 missing #4): the host side of libgpmi built with AddressSanitizer +
+UndefinedBehaviorSanitizer (`make -C inference-tools_amd/csrc asan`: host code only, device code untouched - GPU ASan is not
+available on the pool and is never attempted) and driven, in a child interpreter with the sanitizer runtime preloaded,
+through everything that works without a device: argument validation of every entry point, handle creation failing cleanly,
+the task-list builder of the flag-ordered factorisation at m = 1 .. 64, and the GPMI_FLOW_LISTS override parser on
+well-formed and malformed files.  A sanitizer report aborts the child."""
+import glob
+import os
+import shutil
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+CSRC = os.path.join(ROOT, "inference-tools_amd", "csrc")
+ASAN_LIB = os.path.join(CSRC, "build_asan", "libgpmi_asan.so")
+
+
+def _runtime():
+    hits = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    return hits[0] if hits else None
+
+
+def _write_override(prefix, m, nwg, mode):
+    """<prefix>_m<m>.bin from the library's own lists (read through the plain build): int32 {m, nwg, ntasks}, int32
+    off[nwg + 1], 16-byte tasks {u8 type, u8 pad, u8 fadd, u8 pad, u16 i, u16 j, u16 k, u16 s ...} - the test does not
+    need to know the task layout: it permutes whole 16-byte records."""
+    import ctypes as C
+
+    from inference_amd import _lib
+
+    lib = _lib.load()
+    cnt = C.c_int64(0)
+    assert lib.gpmi_flow_task_lists(m, nwg, 0, None, C.byref(cnt)) == 0
+    ntasks = cnt.value
+    # the records themselves are not exported: a file whose records are all zero is not a permutation and must be ignored,
+    # which is the malformed-input path this test is after; offsets are what the hardening checks
+    off = np.linspace(0, ntasks, nwg + 1).astype(np.int32)
+    if mode == "not_monotone":
+        off[3], off[4] = off[4] + 5, off[3]
+    if mode == "beyond":
+        off[5] = ntasks + 1000
+    if mode == "negative":
+        off[2] = -7
+    hdr = [m, nwg, ntasks]
+    if mode == "wrong_header":
+        hdr = [m + 1, nwg, ntasks]
+    body = struct.pack("<3i", *hdr) + off.tobytes() + bytes(16 * ntasks)
+    if mode == "truncated":
+        body = body[: len(body) // 2]
+    with open(f"{prefix}_m{m}.bin", "wb") as f:
+        f.write(body)
+
+
+@pytest.mark.timeout(900)
+def test_host_code_under_asan_and_ubsan(tmp_path):
+    rt = _runtime()
+    if rt is None or shutil.which("make") is None:
+        pytest.skip("no clang AddressSanitizer runtime in this image")
+    res = subprocess.run(["make", "-C", CSRC, "asan", "-j", str(min(8, os.cpu_count() or 1))], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    prefix = os.path.join(str(tmp_path), "lists")
+    for m, mode in ((9, "not_monotone"), (10, "beyond"), (11, "truncated"), (12, "wrong_header"), (13, "negative")):
+        _write_override(prefix, m, 64, mode)
+    env = dict(os.environ, LD_PRELOAD=rt, GPMI_LIB=ASAN_LIB, GPMI_FLOW_LISTS=prefix,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sanitize_driver.py")], env=env, capture_output=True,
+                         text=True, timeout=800)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-6000:]
+    assert "sanitize ok" in res.stdout
+    assert "ERROR: AddressSanitizer" not in res.stderr and "runtime error" not in res.stderr, res.stderr[-4000:]
+    # every malformed override was refused out loud
+    for m in (9, 10, 11, 12, 13):
+        assert f"lists_m{m}.bin does not hold the task lists" in res.stderr, res.stderr[-3000:]

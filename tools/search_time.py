@@ -62,11 +62,26 @@ for n in (512, 2048):
             row["starts"] = int(2 * np.sqrt(len(gp.hp_bounds))) + 1
     GpRegressor._lockstep_search = keep
     out.append(row)
+# differential evolution (regression.py:569-573): SciPy's default walk, one evaluation per call, against the opt-in batched
+# form (round 6: diffev_batched=True, one lockstep call per generation), BASELINE config 1 and the N = 2048 shape
+if not ONLY:
+    for cfg, n, d in ((1, 512, 2), (5, 2048, 4)):
+        x, y, e = wl.synthetic_dataset(cfg, n, d)
+        row = {"config": cfg, "N": n, "d": d, "optimizer": "diffev"}
+        for mode, kw in (("serial", {}), ("batched", {"diffev_batched": True})):
+            np.random.seed(5)
+            t0 = time.perf_counter()
+            gp = GpRegressor(x, y, y_err=e, optimizer="diffev", **kw)
+            row[f"diffev_{mode}_seconds"] = time.perf_counter() - t0
+            row[f"diffev_{mode}_lml"] = float(gp.marginal_likelihood(gp.hyperpars))
+        out.append(row)
 print(json.dumps(out, indent=1))
 # the accelerated path must never be the slower one (round 5's profile held a 2.55 s lockstep search beside a 0.94 s serial
 # one for a whole round and nobody looked: profiles/r06_search_regression.txt)
 slow = [(r["config"], r["N"], k) for r in out for k in ("", "cross_val_")
         if k + "lockstep_seconds" in r and r[k + "lockstep_seconds"] > r[k + "serial_seconds"]]
+slow += [(r["config"], r["N"], "diffev") for r in out if "diffev_batched_seconds" in r
+         and r["diffev_batched_seconds"] > r["diffev_serial_seconds"]]
 if slow:
     print("search_time.py: the lockstep search is slower than the serial one for", slow, file=sys.stderr)
     sys.exit(1)
