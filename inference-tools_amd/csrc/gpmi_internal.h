@@ -62,7 +62,7 @@ struct Lane {
   void* flow_tasks = nullptr;
   int* flow_off = nullptr;
   int* flow_flags = nullptr;
-  int flow_m = 0, flow_nwg = 0;
+  int flow_m = 0, flow_nwg = 0, flow_nlists = 0;
   int64_t flow_ntasks = 0;
   double flow_flops_update = 0.0, flow_flops_trsm = 0.0;
 };

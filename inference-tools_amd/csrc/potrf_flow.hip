@@ -66,7 +66,19 @@ int env_int(const char* name, int dflt) {
 }
 const int FLOW_NEAR_D = env_int("GPMI_FLOW_NEAR_D", 3);
 const int FLOW_NEAR_WGS = (env_int("GPMI_FLOW_NEAR_WGS", 32) + 7) / 8 * 8;
-constexpr int FT_T = 0, FT_U = 1, FT_Z = 2;
+constexpr int FT_T = 0, FT_U = 1, FT_Z = 2, FT_ZS = 3;
+// (round 6) GPMI_FLOW_SPLIT=1: the K = 512 chunks of a workgroup in a SECOND list (list nwg + b of workgroup b), looked at
+// only when the head of its first list (panel TRSMs, one-column updates) is not ready; GPMI_FLOW_QUARTER=<q0>: the chunks
+// of the outer panels q >= q0 as four 64 x 64 sub-tile tasks FT_ZS (35 us instead of 125: what a short task can sit behind)
+const int FLOW_SPLIT = env_int("GPMI_FLOW_SPLIT", 1);
+const int FLOW_QUARTER = env_int("GPMI_FLOW_QUARTER", 0);
+// GPMI_FLOW_URGENT=<d> (with GPMI_FLOW_SPLIT): the last d chunks of a tile - the ones its own outer panel waits for - in a list
+// of their own per workgroup (list nwg + b), ordered by the panel that needs them (as late as possible: right in front
+// of the tile's first single-column task) and looked at before the remaining chunks (list 2 nwg + b, as soon as possible:
+// by outer panel q).  With every chunk in ONE list in q order, chunk q + 1 on the tiles the chain is about to reach sat
+// behind all of chunk q on tiles it will not reach for another millisecond (tools/flow_curve.py: the bodies of chunk
+// q + 1 began when the last body of chunk q ended, 200 - 250 us after their inputs were complete).
+const int FLOW_URGENT = env_int("GPMI_FLOW_URGENT", 3);
 
 struct FlowTask {
   uint8_t type, s, fadd, pad;
@@ -81,7 +93,8 @@ constexpr int FL_DDONE = 0, FL_ABORT = 32, FL_T0 = 48, FL_STATS = 64, FL_ROWCNT 
 __host__ __device__ inline int flow_f_off(int m) { return FL_LCNT + ((m + 31) / 32) * 32; }
 __host__ __device__ inline int flow_owner_off(int m) { return flow_f_off(m) + ((m * m + 31) / 32) * 32; }  // one word per list
 inline int flow_flag_ints(int m, int nwg) { return flow_owner_off(m) + nwg; }
-constexpr int FLOW_MAX_LISTS = 512;                  // lists a workgroup can hold (its own + adopted ones)
+constexpr int FLOW_MAX_LISTS = 1536;                 // lists a workgroup can hold (its own + adopted ones)
+constexpr int FLOW_MAX_WGS = 512;                    // workgroups of the task launch (up to three lists each with GPMI_FLOW_SPLIT)
 constexpr unsigned long long FLOW_GRACE_TICKS = 5000;  // 50 us: a list nobody has claimed by then is an orphan
 
 struct FlowArgs {
@@ -90,7 +103,8 @@ struct FlowArgs {
   int64_t ld;
   int m;
   const FlowTask* tasks;  // the lists, workgroup after workgroup
-  const int* off;         // list of workgroup b: tasks[off[b] .. off[b + 1])
+  const int* off;         // list l: tasks[off[l] .. off[l + 1]); workgroup b owns list b (and list gridDim.x + b if nlists = 2 gridDim.x)
+  int nlists;
   int* flags;
   int* info;
   unsigned long long* stamp;
@@ -106,6 +120,9 @@ __device__ __forceinline__ bool flow_ready(const FlowTask& t, const int* __restr
   if (t.type == FT_U)
     return flow_ld(Lcnt + t.i) >= 4 * (t.k + 1) && flow_ld(Lcnt + t.j) >= 4 * (t.k + 1) &&
            flow_ld(F + t.i * m + t.j) >= 4 * t.k;
+  if (t.type == FT_ZS)  // a quarter of chunk k: its siblings may already have counted
+    return flow_ld(Lcnt + t.i) >= 4 * OBT * (t.k + 1) && flow_ld(Lcnt + t.j) >= 4 * OBT * (t.k + 1) &&
+           flow_ld(F + t.i * m + t.j) >= 4 * OBT * t.k;
   return flow_ld(Lcnt + t.i) >= 4 * OBT * (t.k + 1) && flow_ld(Lcnt + t.j) >= 4 * OBT * (t.k + 1) &&
          flow_ld(F + t.i * m + t.j) == 4 * OBT * t.k;
 }
@@ -127,9 +144,12 @@ __device__ __attribute__((noinline)) void flow_do_T(glb_double_t* C, const glb_d
 }
 template <int PROTO>
 __device__ __attribute__((noinline)) void flow_do_U(const glb_double_t* Ai, const glb_double_t* Bj, glb_double_t* C,
-                                                    int64_t ld, lds_double_t* smem) {
+                                                    int64_t ld, lds_double_t* smem, int nk) {
+  // (nk and the LDS block arrive in vector registers - the function is not inlined and has two callers -; the ring's
+  // stage addresses must be scalar: they go through m0)
+  lds_double_t* su = (lds_double_t*)(uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)smem);
   dma64_tile<OP_SUB, PROTO == 3 ? CST_NT : CST_SC1, PROTO == 2 ? LD_SC1 : LD_PLAIN>(
-      (const double*)Ai, (const double*)Bj, (double*)C, ld, ld, ld, NB / DMA_BK, (double*)smem);
+      (const double*)Ai, (const double*)Bj, (double*)C, ld, ld, ld, __builtin_amdgcn_readfirstlane(nk), (double*)su);
 }
 // ---- the chain's two products per column, on tiles of 16 rows (round 4) ----------------------------------------------
 // Tc(k): tile (k+1, k) <- tile * invD(k)^T and Uc(k): tile (k+1, k+1) -= X X^T are 128 x 128 x 128 products on the
@@ -626,17 +646,19 @@ __global__ __launch_bounds__(256, 2) void flow_task_kernel(FlowArgs a) {
   // finish, not all of them, and a workgroup that arrives after its list was adopted just leaves.
   __shared__ int s_own[FLOW_MAX_LISTS], s_cur[FLOW_MAX_LISTS];
   int* owner = fl + flow_owner_off(a.m);
-  const int nlists = (int)gridDim.x;
+  const int nlists = a.nlists;
   int nown = 0, last_slot = -1, n = 0;
   if (wave == 0) {
     if (lane == 0) {
       unsigned long long* t0p = reinterpret_cast<unsigned long long*>(fl + FL_T0);
       atomicCAS(t0p, 0ull, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-      if (atomicCAS(owner + blockIdx.x, 0, (int)blockIdx.x + 1) == 0) {
-        s_own[0] = (int)blockIdx.x;
-        s_cur[0] = a.off[blockIdx.x];
-        nown = 1;
-      }
+      // own lists, in priority order: a ready head of an earlier slot is taken first
+      for (int l = (int)blockIdx.x; l < nlists; l += (int)gridDim.x)
+        if (atomicCAS(owner + l, 0, (int)blockIdx.x + 1) == 0) {
+          s_own[nown] = l;
+          s_cur[nown] = a.off[l];
+          ++nown;
+        }
     }
     nown = __shfl(nown, 0, 64);
   }
@@ -774,12 +796,16 @@ __global__ __launch_bounds__(256, 2) void flow_task_kernel(FlowArgs a) {
       double* C = a.A + ((int64_t)t.i * NB + 32 * t.s) * ld + (int64_t)t.k * NB;
       flow_do_T<PROTO>((glb_double_t*)C, (const glb_double_t*)(a.invD + (int64_t)t.k * NB * NB), ld, (lds_double_t*)smem);
       flag = Lcnt + t.i;
-    } else if (t.type == FT_U) {
+    } else if (t.type == FT_U || t.type == FT_ZS) {
+      // one column k (K = 128), or - FT_ZS - the four columns of outer panel k (K = 512), on a 64 x 64 sub-tile: the
+      // ring body sums k in the order of the 128 x 128 body, so a chunk in quarters leaves the same bits
       const int r0 = 64 * (t.s >> 1), c0 = 64 * (t.s & 1);
+      const int64_t kcol = t.type == FT_U ? (int64_t)t.k * NB : (int64_t)t.k * OBT * NB;
       double* C = a.A + ((int64_t)t.i * NB + r0) * ld + (int64_t)t.j * NB + c0;
-      const double* Ai = a.A + ((int64_t)t.i * NB + r0) * ld + (int64_t)t.k * NB;
-      const double* Bj = a.A + ((int64_t)t.j * NB + c0) * ld + (int64_t)t.k * NB;
-      flow_do_U<PROTO>((const glb_double_t*)Ai, (const glb_double_t*)Bj, (glb_double_t*)C, ld, (lds_double_t*)smem);
+      const double* Ai = a.A + ((int64_t)t.i * NB + r0) * ld + kcol;
+      const double* Bj = a.A + ((int64_t)t.j * NB + c0) * ld + kcol;
+      flow_do_U<PROTO>((const glb_double_t*)Ai, (const glb_double_t*)Bj, (glb_double_t*)C, ld, (lds_double_t*)smem,
+                       t.type == FT_U ? NB / DMA_BK : OBT * NB / DMA_BK);
       flag = F + t.i * a.m + t.j;
     } else {
       double* C = a.A + (int64_t)t.i * NB * ld + (int64_t)t.j * NB;
@@ -876,16 +902,46 @@ FlowLists flow_build(int m, int nwg) {
   // of one XCD, as the launch-per-product kernels order their tiles - the tiles were no faster, 117 us with two on a CU
   // either way, and the chain waited 0.8 ms longer for the rows near the diagonal: 7.0 against 6.1 ms at N = 8192.)
   {
-    std::vector<std::pair<Key, FlowTask>> zt;
+    std::vector<std::pair<Key, FlowTask>> zt, zu;  // the chunks; the urgent ones (GPMI_FLOW_URGENT)
+    const bool split = FLOW_SPLIT && nn > 0;
     for (int i = 0; i < m; ++i)
-      for (int j = 0; j <= i; ++j)
-        for (int q = 0; q < flow_lazy_panels(i, j); ++q) {
-          FlowTask t{(uint8_t)FT_Z, 0, (uint8_t)(4 * OBT), 0, (uint16_t)i, (uint16_t)j, (uint16_t)q, 0};
-          zt.push_back({Key(4 * (OBT * q + OBT - 1) + 1, i, j, 0), t});
-          out.flops_update += 2.0 * NB * NB * NB * OBT;
+      for (int j = 0; j <= i; ++j) {
+        const int lazy = flow_lazy_panels(i, j);
+        for (int q = 0; q < lazy; ++q) {
+          const bool urgent = split && FLOW_URGENT > 0 && lazy - q <= FLOW_URGENT;
+          auto& dst = urgent ? zu : zt;
+          // as soon as possible: right behind T(., 4 q + 3); as late as possible: right in front of the tile's first
+          // single-column task T / U(., ., 4 lazy) - both positions respect every dependency of the chunk
+          const int key = urgent ? 4 * (OBT * lazy) - 1 : 4 * (OBT * q + OBT - 1) + 1;
+          const int major = urgent ? q * 4096 + i : i;
+          if (q >= FLOW_QUARTER) {
+            for (int s = 0; s < 4; ++s) {
+              if (i == j && s == 1) continue;  // (as the one-column tasks: the lower triangle of a diagonal tile)
+              FlowTask t{(uint8_t)FT_ZS, (uint8_t)s, (uint8_t)((i == j && s == 0) ? 2 * OBT : OBT), 0, (uint16_t)i,
+                         (uint16_t)j, (uint16_t)q, 0};
+              dst.push_back({Key(key, major, j, s), t});
+            }
+            out.flops_update += (i == j ? 0.75 : 1.0) * 2.0 * NB * NB * NB * OBT;
+          } else {
+            FlowTask t{(uint8_t)FT_Z, 0, (uint8_t)(4 * OBT), 0, (uint16_t)i, (uint16_t)j, (uint16_t)q, 0};
+            dst.push_back({Key(key, major, j, 0), t});
+            out.flops_update += 2.0 * NB * NB * NB * OBT;
+          }
         }
+      }
     std::sort(zt.begin(), zt.end(), by_key);
-    for (size_t n = 0; n < zt.size(); ++n) lists[(size_t)nn + (n + rest.size()) % (size_t)(nwg - nn)].push_back(zt[n]);
+    std::sort(zu.begin(), zu.end(), by_key);
+    if (split) {
+      // further lists: list c nwg + b belongs to workgroup b (c = 1: urgent chunks, if any; then the rest); the near
+      // workgroups take no chunks, as before
+      const size_t classes = zu.empty() ? 2 : 3;
+      lists.resize(classes * (size_t)nwg);
+      const size_t c0 = (size_t)nn, cw = (size_t)(nwg - nn);  // the workgroups that take chunks
+      for (size_t n = 0; n < zu.size(); ++n) lists[(size_t)nwg + c0 + n % cw].push_back(zu[n]);
+      for (size_t n = 0; n < zt.size(); ++n) lists[(classes - 1) * (size_t)nwg + c0 + n % cw].push_back(zt[n]);
+    } else {
+      for (size_t n = 0; n < zt.size(); ++n) lists[(size_t)nn + (n + rest.size()) % (size_t)(nwg - nn)].push_back(zt[n]);
+    }
   }
   for (auto& l : lists) std::stable_sort(l.begin(), l.end(), by_key);
   out.off.push_back(0);
@@ -911,7 +967,7 @@ void flow_lists_override(int m, int nwg, FlowLists& fl) {
   std::vector<int> off;
   std::vector<FlowTask> tasks;
   bool ok = std::fread(hdr, sizeof(hdr), 1, fp) == 1 && hdr[0] == m && hdr[1] == nwg &&
-            hdr[2] == (int32_t)fl.tasks.size();
+            hdr[2] == (int32_t)fl.tasks.size() && fl.off.size() == (size_t)nwg + 1;  // (not with GPMI_FLOW_SPLIT)
   if (ok) {
     off.resize((size_t)nwg + 1);
     tasks.resize((size_t)hdr[2]);
@@ -955,7 +1011,7 @@ extern "C" int gpmi_flow_task_lists(int m, int nwg, int64_t cap, int32_t* out, i
   *ntasks = (int64_t)fl.tasks.size();
   if (!out) return GPMI_OK;
   if (cap < *ntasks) return GPMI_ERR_ARG;
-  for (int w = 0; w < nwg; ++w)
+  for (int w = 0; w + 1 < (int)fl.off.size(); ++w)  // (w: the list; with GPMI_FLOW_SPLIT list nwg + b is workgroup b's second)
     for (int n = fl.off[(size_t)w]; n < fl.off[(size_t)w + 1]; ++n) {
       const FlowTask& t = fl.tasks[(size_t)n];
       int32_t* o = out + 8 * (int64_t)n;
@@ -1065,7 +1121,7 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
     return (v == 1 || v == 2) ? v : 2;
   }();
   // (a lone resident workgroup must be able to adopt every list: never more lists than FLOW_MAX_LISTS)
-  const int nwg = wgs_per_cu * ncu_u < FLOW_MAX_LISTS ? wgs_per_cu * ncu_u : FLOW_MAX_LISTS;
+  const int nwg = wgs_per_cu * ncu_u < FLOW_MAX_WGS ? wgs_per_cu * ncu_u : FLOW_MAX_WGS;
   if (!flow_gate_try(c->device)) return false;
   if (lane.flow_m != m || lane.flow_nwg != nwg) {
     potrf_flow_free(lane);
@@ -1074,7 +1130,7 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
     const size_t total = fl.tasks.size();
     if (hipMalloc(&lane.flow_tasks, sizeof(FlowTask) * (total ? total : 1)) != hipSuccess ||
         hipMalloc(&lane.flow_off, sizeof(int) * fl.off.size()) != hipSuccess ||
-        hipMalloc(&lane.flow_flags, sizeof(int) * flow_flag_ints(m, nwg)) != hipSuccess ||
+        hipMalloc(&lane.flow_flags, sizeof(int) * flow_flag_ints(m, (int)fl.off.size() - 1)) != hipSuccess ||
         (total && hipMemcpy(lane.flow_tasks, fl.tasks.data(), sizeof(FlowTask) * total, hipMemcpyHostToDevice) !=
                       hipSuccess) ||
         hipMemcpy(lane.flow_off, fl.off.data(), sizeof(int) * fl.off.size(), hipMemcpyHostToDevice) != hipSuccess) {
@@ -1088,9 +1144,11 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
     lane.flow_ntasks = (int64_t)total;
     lane.flow_m = m;
     lane.flow_nwg = nwg;
+    lane.flow_nlists = (int)fl.off.size() - 1;
   }
+  const int nlists = lane.flow_nlists;
   int* fl = lane.flow_flags;
-  (void)hipMemsetAsync(fl, 0, sizeof(int) * flow_flag_ints(m, nwg), sf);
+  (void)hipMemsetAsync(fl, 0, sizeof(int) * flow_flag_ints(m, nlists), sf);
   (void)hipEventRecord(lane.ev_join, sf);
   (void)hipStreamWaitEvent(sp, lane.ev_join, 0);
   (void)hipStreamWaitEvent(su, lane.ev_join, 0);
@@ -1104,6 +1162,7 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
   fa.m = m;
   fa.tasks = static_cast<const FlowTask*>(lane.flow_tasks);
   fa.off = lane.flow_off;
+  fa.nlists = nlists;
   fa.flags = fl;
   fa.info = info;
   // one stamped "launch" of its own class for the bench: FLOPs of every U and Z task over the launch's whole duration
@@ -1225,13 +1284,13 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
     (void)hipStreamSynchronize(sf);
     std::vector<unsigned long long> h((size_t)trace_words);
     std::vector<FlowTask> ht((size_t)ntasks);
-    std::vector<int> ho((size_t)nwg + 1);
+    std::vector<int> ho((size_t)nlists + 1);
     (void)hipMemcpy(h.data(), trace, sizeof(unsigned long long) * trace_words, hipMemcpyDeviceToHost);
     (void)hipMemcpy(ht.data(), lane.flow_tasks, sizeof(FlowTask) * ntasks, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(ho.data(), lane.flow_off, sizeof(int) * (nwg + 1), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(ho.data(), lane.flow_off, sizeof(int) * (nlists + 1), hipMemcpyDeviceToHost);
     (void)hipFree(trace);
     if (FILE* fp = std::fopen(trace_path, "wb")) {
-      const int64_t hdr[4] = {m, nwg, ntasks, GPMI_STAMP_WORDS + 4};
+      const int64_t hdr[4] = {m, nlists, ntasks, GPMI_STAMP_WORDS + 4};
       std::fwrite(hdr, sizeof(hdr), 1, fp);
       std::fwrite(ho.data(), sizeof(int), ho.size(), fp);
       std::fwrite(ht.data(), sizeof(FlowTask), ht.size(), fp);

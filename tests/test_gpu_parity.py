@@ -1652,6 +1652,9 @@ def test_schedule_variants_agree(tmp_path):
         {"GPMI_CHAIN_TILES": "1"},  # ... two 16 x 16-tile launches behind potrf_diag
         {"GPMI_CHAIN_TILES": "0"},  # ... and the generic tile kernels
         {"GPMI_LOOKAHEAD_MIN": "84", "GPMI_FLOW_NEAR_WGS": "64", "GPMI_FLOW_NEAR": "0", "GPMI_FLOW_NEAR_D": "5"},
+        # (round 6) the task lists of rounds 3-5: one list per workgroup, whole 128 x 128 chunks in q order
+        {"GPMI_FLOW_SPLIT": "0", "GPMI_FLOW_QUARTER": "99999"},
+        {"GPMI_FLOW_URGENT": "0", "GPMI_FLOW_QUARTER": "2"},  # chunks of the outer panels 0, 1 whole, the later ones in quarters
     ]
     base = None
     for k, extra in enumerate(variants):
@@ -1685,7 +1688,11 @@ def test_flow_tail_is_bit_identical_to_stream_order(tmp_path, n):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tool = os.path.join(root, "tools", "fit_digest.py")
     res = []
-    for k, extra in enumerate(({"GPMI_FLOW": "0"}, {}, {"GPMI_FLOW_NEAR_WGS": "16", "GPMI_FLOW_PROTO": "2", "GPMI_FLOW_WGS": "1"})):
+    # (round 6: the default lists hold every chunk as four quarter tasks, the urgent ones in lists of their own; the fourth
+    # variant is the one-list schedule of rounds 3-5 with whole 128 x 128 chunks - the ring bodies sum alike)
+    for k, extra in enumerate(({"GPMI_FLOW": "0"}, {}, {"GPMI_FLOW_NEAR_WGS": "16", "GPMI_FLOW_PROTO": "2", "GPMI_FLOW_WGS": "1"},
+                               {"GPMI_FLOW_SPLIT": "0", "GPMI_FLOW_QUARTER": "99999"},
+                               {"GPMI_FLOW_URGENT": "99", "GPMI_FLOW_QUARTER": "1"})):
         out = str(tmp_path / f"f{k}.npz")
         run = subprocess.run([sys.executable, tool, out, str(n)], env=dict(os.environ, **extra), capture_output=True,
                              text=True, timeout=300)

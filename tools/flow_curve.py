@@ -7,7 +7,8 @@ import sys
 import numpy as np
 
 raw = open(sys.argv[1], "rb").read()
-m, nwg, ntasks, cw = struct.unpack("4q", raw[:32])
+m, nwg, ntasks, cw = struct.unpack("4q", raw[:32])  # (nwg: the number of LISTS)
+nwg_phys = nwg // 2 if nwg > 512 else nwg  # round 6: GPMI_FLOW_SPLIT gives every workgroup two lists
 p = 32
 off = np.frombuffer(raw, np.int32, nwg + 1, p); p += 4 * (nwg + 1)
 tasks = np.frombuffer(raw, np.dtype([("type", "u1"), ("s", "u1"), ("fadd", "u1"), ("pad", "u1"), ("i", "u2"), ("j", "u2"), ("k", "u2"), ("pad2", "u2")]), ntasks, p); p += 12 * ntasks
@@ -25,9 +26,9 @@ edges = np.arange(0, end + 250, 250)
 row = []
 for a, b in zip(edges[:-1], edges[1:]):
     ov = np.clip(np.minimum(body[:, 1], b) - np.maximum(body[:, 0], a), 0, None).sum()
-    row.append(ov / ((b - a) * nwg))
+    row.append(ov / ((b - a) * nwg_phys))
 print("task workgroups busy, per 250 us:", " ".join(f"{x:.2f}" for x in row))
-z = tasks["type"] == 2
+z = (tasks["type"] == 2) | (tasks["type"] == 3)  # K = 512 chunks, whole or as quarters (FT_ZS)
 for q in np.unique(tasks["k"][z]):
     sel = z & (tasks["k"] == q)
     print(f"  Z k={q}: {sel.sum()} tiles, bodies from {us(tt[sel, 1].min()):.0f} to {us(tt[sel, 2].max()):.0f} us, median body {np.median((tt[sel, 2] - tt[sel, 1]) * 0.01):.0f} us")
