@@ -8,7 +8,8 @@ import numpy as np
 
 raw = open(sys.argv[1], "rb").read()
 m, nwg, ntasks, cw = struct.unpack("4q", raw[:32])  # (nwg: the number of LISTS)
-nwg_phys = nwg // 2 if nwg > 512 else nwg  # round 6: GPMI_FLOW_SPLIT gives every workgroup two lists
+# round 6: GPMI_FLOW_SPLIT gives every workgroup two lists, three with GPMI_FLOW_URGENT (the launch has at most 512 workgroups)
+nwg_phys = nwg if nwg <= 512 else (nwg // 3 if nwg % 3 == 0 and nwg // 3 <= 512 and nwg // 2 > 512 else nwg // 2)
 p = 32
 off = np.frombuffer(raw, np.int32, nwg + 1, p); p += 4 * (nwg + 1)
 tasks = np.frombuffer(raw, np.dtype([("type", "u1"), ("s", "u1"), ("fadd", "u1"), ("pad", "u1"), ("i", "u2"), ("j", "u2"), ("k", "u2"), ("pad2", "u2")]), ntasks, p); p += 12 * ntasks

@@ -21,8 +21,8 @@ for b in range(nwg):
     owner[off[b]:off[b + 1]] = b
 t0 = ct[0, 0]
 us = lambda x: (x - t0) * 0.01
-names = "TUZR"
-print(f"m={m} workgroups={nwg} tasks={ntasks}; whole chain {us(ct[m-1, 8]):.0f} us")
+names = "TUZQ"  # (Q: a quarter of a K = 512 chunk, FT_ZS, round 6)
+print(f"m={m} lists={nwg} tasks={ntasks}; whole chain {us(ct[m-1, 8]):.0f} us")
 dur = (tt[:, 2] - tt[:, 1]) * 0.01
 for ty in range(4):
     sel = tasks["type"] == ty

@@ -17,7 +17,8 @@ for sub in ("bench", "cfg2", "cfg3", "cfg4", "cfg5", "lmlgrad", "pt"):
     st = stats_of(sub)
     if st:
         shutil.copy(st, os.path.join(pr, f"{tag}_{sub}_kernel_stats.csv"))
-for name in ("cfg2.txt", "cfg3.txt", "cfg4.txt", "cfg5.txt", "lmlgrad.txt", "pt.json", "pt16.json", "pt_traced.json", "propose.json", "search.json", "bench_timeline.txt"):
+for name in ("cfg2.txt", "cfg3.txt", "cfg4.txt", "cfg5.txt", "lmlgrad.txt", "pt.json", "pt16.json", "pt_traced.json", "propose.json", "search.json", "bench_timeline.txt",
+             "vendor.json", "flow_curve_n8192.txt"):
     src = os.path.join(go, name)
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(pr, f"{tag}_{name}"))
@@ -75,8 +76,10 @@ out = {
     "cross_check": {"rocprof_kernel_stats_avg_us_of_the_dominant_kernel": upd_us, "launches": int(upd["Calls"]),
                     "bench_stamp_avg_us": bench["roofline"]["avg_launch_ms"] * 1e3,
                     "bench_stamp_avg_us_all_launches_of_this_kernel_name": bench["roofline"].get("same_kernel_name_all_launches", {}).get("avg_launch_ms", float("nan")) * 1e3,
-                    "bench_achieved_tflops": bench["roofline"]["achieved"],
-                    "achieved_tflops_with_rocprof_durations": bench["roofline"]["achieved"]
+                    # (since round 6 the line's `achieved` is already the rocprofv3-duration figure of the PREVIOUS committed
+                    # profile; the live stamp figure is `achieved_stamps`)
+                    "bench_achieved_tflops": bench["roofline"].get("achieved_stamps", bench["roofline"]["achieved"]),
+                    "achieved_tflops_with_rocprof_durations": bench["roofline"].get("achieved_stamps", bench["roofline"]["achieved"])
                     * bench["roofline"].get("same_kernel_name_all_launches", {}).get("avg_launch_ms", float("nan")) * 1e3 / upd_us},
 }
 for cmd, pmc in pmc_sets.items():

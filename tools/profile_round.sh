@@ -11,7 +11,7 @@ cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench -- python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-sharded --no-configs > $out/bench_traced.json 2> $out/bench_traced.err
 python3 tools/timeline_full.py $out/bench $out/bench_timeline.txt > /dev/null 2>&1
 python3 tools/by_queue.py $out/bench $out/bench_kernel_stats_by_queue.csv > /dev/null 2>&1
-timeout 300 python3 bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err
+timeout 900 python3 bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 # 2. the other BASELINE configurations and the LML-gradient path: per-kernel stats of the same public calls
 for cfg in cfg2 cfg3 cfg4 cfg5; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$cfg -- python3 tools/config_bench.py $cfg > $out/$cfg.txt 2> $out/$cfg.err
@@ -37,7 +37,10 @@ cp $out/pmc_bench/FETCH_SIZE.log $out/pmc_bench_line.txt 2>/dev/null
 bash tools/pmc_stalls.sh $out/pmc_stalls > $out/pmc_stalls.log 2>&1
 # 5. the flag-ordered tail: chain step and task timings from in-kernel stamps (tools/flow_tr.sh)
 N=8192 bash tools/flow_tr.sh $out/flowt > $out/flow_trace_n8192.txt 2>&1
+python3 tools/flow_curve.py $out/flowt/trace.bin > $out/flow_curve_n8192.txt 2>&1
 rm -rf $out/flowt
+# 6. the vendor's routines at the same shapes (tools only: never on the product path)
+timeout 300 python3 tools/vendor_yardstick.py > $out/vendor.json 2> $out/vendor.err
 find $out -name "*counter_collection.csv" -delete
 find $out -name "*agent_info.csv" -delete
 ls -R $out | head -80
