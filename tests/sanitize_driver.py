@@ -1,6 +1,6 @@
 """Run INSIDE a child interpreter by tests/test_sanitizers_cpu.py with the AddressSanitizer runtime preloaded and
 GPMI_LIB pointing at csrc/build_asan/libgpmi_asan.so (host code of every translation unit compiled with
--fsanitize=address,undefined).  Exercises what the library does without a device; any sanitizer report aborts the
+AddressSanitizer + UndefinedBehaviorSanitizer).  Exercises what the library does without a device; any sanitizer report aborts the
 process (non-zero exit), which is what the test looks at.  Prints "sanitize ok <n calls>" at the end."""
 import ctypes as C
 import os
@@ -56,7 +56,9 @@ for m in list(range(8, 65, 4)) + [1, 2, 3, 63]:
         assert lib.gpmi_flow_task_lists(m, nwg, 0, None, C.byref(cnt)) == 0
         out = np.full((cnt.value, 8), -1, dtype=np.int32)
         assert lib.gpmi_flow_task_lists(m, nwg, cnt.value, out.ctypes.data_as(ip32), C.byref(cnt)) == 0
-        assert (out[:, 0] >= 0).all() and (out[:, 0] <= 2).all() and (out[:, 6] >= 0).all() and (out[:, 6] < nwg).all()
+        # (the shipped default: up to three lists per workgroup, chunks as quarter tasks - type 3; GPMI_FLOW_SPLIT=0: one list)
+        nl = nwg if os.environ.get("GPMI_FLOW_SPLIT") == "0" else 3 * nwg
+        assert (out[:, 0] >= 0).all() and (out[:, 0] <= 3).all() and (out[:, 6] >= 0).all() and (out[:, 6] < nl).all()
         assert (np.diff(out[:, 6]) >= 0).all()  # list after list
         if cnt.value > 1:
             assert lib.gpmi_flow_task_lists(m, nwg, cnt.value - 1, out.ctypes.data_as(ip32), C.byref(cnt)) == ERR_ARG
