@@ -301,6 +301,7 @@ int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const dou
                                const MixEval* mix, bool prebuild_inv2) {
   hipStream_t s = L.stream;
   L.inv2_valid = false;
+  potrf_pair_quiesce(L);  // (before this call's own work reaches the pair: the build below uses the update stream)
   HIPCHK(c, hipMemsetAsync(L.info + slot, 0, sizeof(int), s));
   if (mix) {
     build_mix_square(c, s, *mix, L.A, false);

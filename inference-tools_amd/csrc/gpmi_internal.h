@@ -43,6 +43,7 @@ struct Lane {
   hipStream_t sp[GPMI_NPAIRS] = {nullptr};
   hipStream_t su[GPMI_NPAIRS] = {nullptr};
   bool owns_pair = true;           // false (lane 1): the pair is lane 0's (api.hip: lane_alloc)
+  bool pair_checked = false;       // potrf_pair_quiesce has run for the factorisation being enqueued (potrf.hip)
   hipEvent_t ev_la = nullptr, ev_panel = nullptr, ev_join = nullptr, ev_main = nullptr, ev_slice = nullptr;
   double* A = nullptr;      // np x ld scratch (K then L)
   double* invD = nullptr;   // (np/128) x 128 x 128 inverses of the diagonal blocks
@@ -307,6 +308,8 @@ void launch_gemm(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, int k
 
 // potrf.hip
 hipStream_t potrf_first_update_stream(gpmi_ctx* c, Lane& lane, int64_t np, bool allow_lookahead);
+// waits for whatever an earlier (failed / foreign) call left on the lane's CU-masked pair; before the caller's own enqueues
+void potrf_pair_quiesce(Lane& lane);
 void launch_potrf_diag(hipStream_t s, double* Ablk, int64_t ld, double* invD, int* info, int col0,
                        unsigned long long* dbg = nullptr, const BatchShape& bs = BatchShape(), int* pub = nullptr,
                        int pub_val = 0);

@@ -214,6 +214,23 @@ int lookahead_min() {
 }
 }  // namespace
 
+// Lanes 0 and 1 share ONE CU-masked pair (api.hip: lane_alloc).  That is safe while every entry point joins the pair's
+// work back into its lane and synchronises before it returns - which an early error return behind enqueued look-ahead
+// work, or a caller driving lane 0 through gpmi_get_stream, does not do.  So nothing is assumed: a factorisation that
+// finds the pair busy waits for it first (two stream queries per factorisation; never taken in a correct call sequence).
+// Called BEFORE the caller enqueues anything of its own on the pair (the fit builds covariance tiles on the update
+// stream beside the first panel: checked behind that build, the query would find it and wait for it - 0.13 ms per fit at
+// N = 16384, measured); potrf_lower runs the check itself for callers that did not.
+void potrf_pair_quiesce(Lane& lane) {
+  for (int k = 0; k < GPMI_NPAIRS; ++k)
+    for (hipStream_t q : {lane.sp[k], lane.su[k]})
+      if (q && hipStreamQuery(q) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(q);
+      }
+  lane.pair_checked = true;
+}
+
 // The stream the first trailing update of potrf_lower will run on when it is not the lane's own (the look-ahead
 // regime applies from the first panel on), else nullptr.  Work enqueued there beforehand precedes that update: the
 // fit builds the covariance tiles to the right of the first panel on it while the first panel is being factored.
@@ -242,16 +259,8 @@ void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, dou
   const int nt = (int)(np / NB);
   const int OBT = OUTER_TILES;
   const int LOOKAHEAD_MIN = lookahead_min();
-  // Lanes 0 and 1 share ONE CU-masked pair (api.hip: lane_alloc).  That is safe while every entry point joins the pair's
-  // work back into its lane and synchronises before it returns - which an early error return behind enqueued look-ahead
-  // work, or a caller driving lane 0 through gpmi_get_stream, does not do.  So nothing is assumed: a factorisation that
-  // finds the pair busy waits for it first (two stream queries per factorisation; never taken in a correct call sequence).
-  for (int k = 0; k < GPMI_NPAIRS; ++k)
-    for (hipStream_t q : {lane.sp[k], lane.su[k]})
-      if (q && hipStreamQuery(q) != hipSuccess) {
-        (void)hipGetLastError();
-        (void)hipStreamSynchronize(q);
-      }
+  if (!lane.pair_checked) potrf_pair_quiesce(lane);
+  lane.pair_checked = false;
   const bool la_ok = allow_lookahead && nt - OBT >= LOOKAHEAD_MIN && ensure_masked_pair(c, lane, 0);
   // The chain-bound part - everything below LOOKAHEAD_MIN trailing tile rows, i.e. the whole of a matrix of N <= ~8000
   // and the tail of a larger one - runs as a flag-ordered tile-task launch beside the bare chain (potrf_flow.hip)

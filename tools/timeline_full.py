@@ -8,6 +8,9 @@ ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'
              r.get('Stream_Id', r.get('Queue_Id', '?'))) for r in rows)
 idx = [i for i, k in enumerate(ks) if 'kbuild_kernel<true' in k[2]]
 s = idx[-1]
+# (the build is split over two streams when the factorisation starts in its look-ahead regime: both launches belong to the step)
+if len(idx) > 1 and ks[idx[-1]][0] - ks[idx[-2]][0] < 200000:
+    s = idx[-2]
 full = ks[s:]
 t0 = full[0][0]
 def short(n):
