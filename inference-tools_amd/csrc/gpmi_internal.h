@@ -292,6 +292,7 @@ void launch_gemm_nt(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_
 // `stamp` times the first launch only.  nend >= 0: the product stops at logical tile `nend` - the tiles from there on
 // are somebody else's (launch_gemm_nt_range on another stream)
 int64_t gemm_split_point(int64_t T, int ncu, int k);
+bool gemm_mixed_launches();  // GPMI_GEMM_MIXED: launch_gemm_nt_split puts the remainder's quarters into the launch of the full rounds
 void launch_gemm_nt_split(hipStream_t s, GemmTiles tiles, GemmOp op, double* C, int64_t ldc, const double* A,
                           int64_t lda, const double* B, int64_t ldb, int ntr, int ntc, int k, int64_t nfull,
                           unsigned long long* stamp = nullptr, unsigned long long* stamp_rest = nullptr,

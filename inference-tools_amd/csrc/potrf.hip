@@ -128,7 +128,8 @@ void update_columns(gpmi_ctx* c, hipStream_t s, double* A, int64_t ld, int nt, i
     return (int64_t)(e ? std::atoi(e) : 384);
   }();
   const bool big = tiles >= BIG_MIN && kw > 128;
-  const int64_t nmain = big ? nfull : 0;
+  int64_t nmain = big ? nfull : 0;
+  if (big && nfull > 0 && nfull < tiles && gemm_mixed_launches()) nmain = tiles;  // ONE launch: full tiles + the rest in quarters
   unsigned long long* stamp = nullptr;
   unsigned long long* stamp_rest = nullptr;
   if (nmain > 0)
