@@ -47,6 +47,17 @@ def golden():
     return load
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """Destroy every live device context while the interpreter and the HIP runtime are fully alive (the library also does
+    this from atexit: a context torn down later, during interpreter shutdown, can end in the runtime's static destructors)."""
+    try:
+        mod = sys.modules.get("inference_amd._lib")
+        if mod is not None:
+            mod._close_all_handles()
+    except Exception:
+        pass
+
+
 def pytest_terminal_summary(terminalreporter):
     """Achieved errors of the GPU parity comparisons (tests/test_gpu_parity.py logs every `check`): the worst
     ratio error / tolerance per test and label."""
