@@ -64,6 +64,31 @@ __device__ inline double flow_poll(const double* p, int* err, bool& dead) {
   return (bits == FLOW_SENTINEL) ? 0.0 : __longlong_as_double((long long)bits);
 }
 
+// Two neighbouring elements in ONE memory round trip: both loads are issued before either is looked at (the forward sweep's
+// lanes need v[2 l] and v[2 l + 1]; polled one after the other - round 3 to 5 - the second load started only when the
+// first had returned a value: a second agent-scope round trip, ~1 us, on every step of the sweep's critical path).
+__device__ inline void flow_poll2(const double* p, int* err, bool& dead, double& a, double& b) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  unsigned long long x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int spins = 0;
+  while ((x == FLOW_SENTINEL || y == FLOW_SENTINEL) && !dead) {
+    __builtin_amdgcn_s_sleep(1);
+    const unsigned long long x2 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long y2 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    x = x2;
+    y = y2;
+    ++spins;
+    if ((spins & 4095) == 0 && err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) dead = true;
+    if (spins > FLOW_SPIN_LIMIT) {
+      if (err) atomicCAS(err, 0, GPMI_ERR_INTERNAL);
+      dead = true;
+    }
+  }
+  a = (x == FLOW_SENTINEL) ? 0.0 : __longlong_as_double((long long)x);
+  b = (y == FLOW_SENTINEL) ? 0.0 : __longlong_as_double((long long)y);
+}
+
 // Which (step, problem) a workgroup of a BATCHED sweep is.  One problem's workgroups form a dependency chain, and a
 // resident workgroup must never wait for one that has not been dispatched: the dispatcher hands linear workgroup id n to
 // XCD n % 8 and every XCD starts its share in order, so problem z lives entirely on XCD z % 8, its steps in increasing
@@ -79,6 +104,34 @@ __device__ inline bool flow_batched_id(int nt, int batch, int& step, int& z) {
   z = (m / nt) * 8 + xcd;
   return z < batch;
 }
+
+// -DGPMI_SWEEP_STAMPS (tools/probes/sweep_hops.hip only): 10 ns wall-clock stamps of wave 0 at the phases of a step
+#ifdef GPMI_SWEEP_STAMPS
+__device__ unsigned long long g_sweep_stamp[8][1024];
+#define SWEEP_STAMP_DECL unsigned long long sweep_t[5] = {0, 0, 0, 0, 0}
+#define SWEEP_STAMP(slot, k) sweep_t[slot] = __builtin_amdgcn_s_memrealtime()  // kept in registers: no store on the path
+#define SWEEP_STAMP_FLUSH(k)                                                  \
+  do {                                                                        \
+    if (threadIdx.x == 0)                                                     \
+      for (int q_ = 0; q_ < 5; ++q_) g_sweep_stamp[q_][k] = sweep_t[q_];      \
+  } while (0)
+#else
+#define SWEEP_STAMP_DECL
+#define SWEEP_STAMP(slot, k)
+#define SWEEP_STAMP_FLUSH(k)
+#endif
+
+// x of lane (l ^ 1) / (l ^ 2) of the same quad, by DPP (a couple of cycles; __shfl_xor goes through ds_bpermute, an LDS
+// round trip, twice per fold, on every step of a sweep's critical path)
+template <int CTRL>
+__device__ inline double quad_swap(double x) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_mov_dpp((int)b, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+constexpr int QUAD_XOR1 = 0xB1;  // quad_perm [1, 0, 3, 2]
+constexpr int QUAD_XOR2 = 0x4E;  // quad_perm [2, 3, 0, 1]
 
 __device__ inline void flow_publish(double* p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
@@ -102,15 +155,23 @@ __global__ __launch_bounds__(FLOW_THREADS) void trsv_fwd_flow_kernel(
     int64_t sInv, int64_t sVec, int nt, int batch) {
   int k = blockIdx.x, z = 0;
   if (batch > 1 && !flow_batched_id(nt, batch, k, z)) return;
+  SWEEP_STAMP_DECL;
   L += (int64_t)z * sMat;
   invD += (int64_t)z * sInv + (int64_t)k * NB * NB;
   r += (int64_t)z * sVec;
   v += (int64_t)z * sVec;
   if (err) err += z;
-  __shared__ double part[NB][65];
-  __shared__ double u[NB];
+  // LDS layouts chosen against the bank rules of gfx950 (ds_write_b64: 16 contiguous lanes on 32 banks; ds_read_b128: groups of
+  // 16 lanes = 4 rows x 4 quarter-rows on 64 banks).  A row of `part` is 32 slots of 16 B plus one of padding; the partial sum
+  // of source lane 16 q + c lives in slot 8 q + ((c / 2 + 4 (q / 2)) % 8), half c % 2: the writers of a group hit 16 different
+  // bank pairs, and the four quarter-rows x four rows a reader group fetches fall into 16 different slots.  `u` carries one
+  // slot of padding per 32 values for the same reason.  (Rounds 3-5: part[NB][65] read as 16 doubles per lane and u[NB] - both
+  // 4-way conflicts, ~0.6 us each on every step of the sweep; the summation order is the same, the results bit-identical.)
+  __shared__ __attribute__((aligned(16))) double part[NB][66];
+  __shared__ __attribute__((aligned(16))) double u[NB + 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row4 = tid >> 2, q4 = tid & 3;  // four threads per row, 32 columns each
+  const int wpos = 2 * (8 * (lane >> 4) + ((((lane & 15) >> 1) + 4 * (lane >> 5)) & 7)) + (lane & 1);
   // invD_k, requested first (static data: no dependence on the sweep), four threads per row
   double xi[32];
   {
@@ -139,8 +200,9 @@ __global__ __launch_bounds__(FLOW_THREADS) void trsv_fwd_flow_kernel(
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         hb[i] = *reinterpret_cast<const d2_t*>(base + (int64_t)(8 + i) * ld + (int64_t)j * NB);
-      const double v0 = flow_poll(v + (int64_t)j * NB + 2 * lane, err, dead);
-      const double v1 = flow_poll(v + (int64_t)j * NB + 2 * lane + 1, err, dead);
+      double v0, v1;
+      flow_poll2(v + (int64_t)j * NB + 2 * lane, err, dead, v0, v1);
+      if (j == nmain - 1) SWEEP_STAMP(0, k);
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] = fma(ha[i][0], v0, fma(ha[i][1], v1, acc[i]));
       if (j + 1 < nmain) {
@@ -153,25 +215,47 @@ __global__ __launch_bounds__(FLOW_THREADS) void trsv_fwd_flow_kernel(
     }
   }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) part[wave * 16 + i][lane] = acc[i];
-  __syncthreads();
+  for (int i = 0; i < 16; ++i) part[wave * 16 + i][wpos] = acc[i];
+  SWEEP_STAMP(1, k);
+  // Rows 16 w .. 16 w + 15 are written AND folded by wave w (row4 = tid >> 2): the LDS operations of one wave execute in
+  // order, so no workgroup barrier stands between the partial sums and their fold (rounds 3-5 had one: ~0.2 us per step).
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  SWEEP_STAMP(2, k);
   {
-    // fold the 64 lane partials of every row: 4 threads per row, 16 each, fixed order
+    // fold the 64 lane partials of every row: 4 threads per row, 16 each (eight 16-byte reads), fixed order; all reads
+    // are issued before the first add
+    double pv[16];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const d2_t x = *reinterpret_cast<const d2_t*>(&part[row4][2 * (8 * q4 + ((t + 4 * (q4 >> 1)) & 7))]);
+      pv[2 * t] = x[0];
+      pv[2 * t + 1] = x[1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     double s = 0.0;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) s += part[row4][q4 * 16 + c];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (q4 == 0) u[row4] = rk - s;
+    for (int c = 0; c < 16; ++c) s += pv[c];
+    s += quad_swap<QUAD_XOR1>(s);
+    s += quad_swap<QUAD_XOR2>(s);
+    if (q4 == 0) u[row4 + 2 * (row4 >> 5)] = rk - s;
   }
   __syncthreads();
+  SWEEP_STAMP(3, k);
   {
+    double uv[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) uv[c] = u[q4 * 34 + c];
+    __builtin_amdgcn_sched_barrier(0);
     double s = 0.0;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) s = fma(xi[c], u[q4 * 32 + c], s);
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
+    for (int c = 0; c < 32; ++c) s = fma(xi[c], uv[c], s);
+    s += quad_swap<QUAD_XOR1>(s);
+    s += quad_swap<QUAD_XOR2>(s);
     if (q4 == 0) flow_publish(v + (int64_t)k * NB + row4, s);
+    SWEEP_STAMP(4, k);
+    SWEEP_STAMP_FLUSH(k);
   }
 }
 
@@ -185,6 +269,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void trsv_bwd_flow_kernel(
     int64_t sInv, int64_t sVec, int batch) {
   int step = blockIdx.x, z = 0;
   if (batch > 1 && !flow_batched_id(nt, batch, step, z)) return;
+  SWEEP_STAMP_DECL;
   const int k = nt - 1 - step;
   L += (int64_t)z * sMat;  // batch (lockstep evaluations)
   invD += (int64_t)z * sInv;
@@ -226,7 +311,9 @@ __global__ __launch_bounds__(FLOW_THREADS) void trsv_bwd_flow_kernel(
       // a_j into LDS (double-buffered: a slow wave may still read the previous block's values)
       double* aj = ain[t & 1];
       if (tid < NB) aj[tid] = flow_poll(a + (int64_t)j * NB + tid, err, dead);
+      if (t == nmain - 1) SWEEP_STAMP(0, step);
       __syncthreads();
+      if (t == nmain - 1) SWEEP_STAMP(1, step);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const double x = aj[wave + 8 * i];
@@ -249,6 +336,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void trsv_bwd_flow_kernel(
   part[wave][2 * lane] = acc[0];
   part[wave][2 * lane + 1] = acc[1];
   __syncthreads();
+  SWEEP_STAMP(2, step);
   if (tid < NB) {
     double s = 0.0;
 #pragma unroll
@@ -256,6 +344,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void trsv_bwd_flow_kernel(
     u[tid] = wk - s;
   }
   __syncthreads();
+  SWEEP_STAMP(3, step);
   {
     double s = 0.0;
 #pragma unroll
@@ -264,6 +353,8 @@ __global__ __launch_bounds__(FLOW_THREADS) void trsv_bwd_flow_kernel(
     __syncthreads();
     if (tid < NB)
       flow_publish(a + (int64_t)k * NB + tid, (part[4][tid] + part[5][tid]) + (part[6][tid] + part[7][tid]));
+    SWEEP_STAMP(4, step);
+    SWEEP_STAMP_FLUSH(step);
   }
 }
 
