@@ -298,7 +298,7 @@ void build_mix_square(gpmi_ctx* c, hipStream_t s, const MixEval& mx, double* dst
 // info[slot].  `mu_dev` may be null (then mu_const is used).  `mix` != nullptr: mixture covariance.
 int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const double* mu_dev,
                                double mu_const, int slot, bool allow_lookahead,
-                               const MixEval* mix, bool prebuild_inv2) {
+                               const MixEval* mix, bool prebuild_inv2, double* backward_out) {
   hipStream_t s = L.stream;
   L.inv2_valid = false;
   potrf_pair_quiesce(L);  // (before this call's own work reaches the pair: the build below uses the update stream)
@@ -325,7 +325,24 @@ int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const dou
     }
   }
   if (c->ycov) launch_add_full(s, L.A, c->ld, c->ycov, c->n);
+  // the residual and the sweeps' sentinel fills do not depend on the factor: the factorisation enqueues them where the
+  // lane's stream idles (GPMI_EARLY_FILL=0: behind it, as until round 6); `backward_out`: the caller's backward sweep
+  // writes there next and passes prefilled = true
+  static const bool early_fill = !std::getenv("GPMI_EARLY_FILL") || std::atoi(std::getenv("GPMI_EARLY_FILL")) != 0;
+  L.early = Lane::EarlyWork();
+  L.early.pending = true;
+  L.early.y = c->y;
+  L.early.mu = mu_dev;
+  L.early.mu_const = mu_const;
+  L.early.r = L.vec + 2 * c->np;
+  L.early.n = c->n;
+  L.early.np = c->np;
+  L.early.fill[0] = L.vec;
+  L.early.fill[1] = backward_out;
+  if (!early_fill) L.early.pending = false;
   potrf_lower(c, L, L.A, c->np, c->ld, L.invD, L.info + slot, allow_lookahead);
+  if (!early_fill) L.early.pending = true;
+  lane_run_early(L, s);  // (a no-op when the factorisation found a place for it)
   if (prebuild_inv2 && L.su[0] && c->np >= 4 * GPMI_OB) {
     // the fit's caller predicts next: the inverses of the 512 x 512 diagonal blocks (six small batched launches, 0.2 ms
     // on a stream of their own) are built on the lane's update stream beside the two triangular sweeps, which are
@@ -335,8 +352,7 @@ int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const dou
     if (int rc = ensure_inv2(c, L, L.su[0])) return rc;
     HIPCHK(c, hipEventRecord(L.ev_main, L.su[0]));
   }
-  launch_residual(s, c->y, mu_dev, mu_const, L.vec + 2 * c->np, c->n, c->np);
-  trsv_forward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, L.vec, L.info + slot);
+  trsv_forward(c, s, L.A, c->np, c->ld, L.invD, L.vec + 2 * c->np, L.vec, L.info + slot, BatchShape(), true);
   if (prebuild_inv2 && L.inv2_valid && L.su[0]) {
     // (same caller: v . v and sum ln L_ii - one workgroup, 42 us - beside the backward sweep instead of in front of it)
     HIPCHK(c, hipEventRecord(L.ev_la, s));

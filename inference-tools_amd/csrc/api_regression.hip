@@ -19,10 +19,10 @@ int gpmi_fit(gpmi_ctx* c, int kernel, const double* theta, int n_theta, double e
   const bool dbg = std::getenv("GPMI_DEBUG_TIMING") != nullptr;
   const auto h0 = std::chrono::steady_clock::now();
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
-  if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0, true, nullptr, true)) return rc;
+  if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0, true, nullptr, true, c->alpha)) return rc;
   const auto h1 = std::chrono::steady_clock::now();
-  // alpha = L^-T v
-  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, c->alpha, L.info);
+  // alpha = L^-T v  (c->alpha already holds the sweep's sentinel: enqueue_factor_and_forward, backward_out)
+  trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, c->alpha, L.info, BatchShape(), true);
   if (L.inv2_valid) HIPCHK(c, hipStreamWaitEvent(s, L.ev_main, 0));  // (the inverse blocks built beside the sweeps)
   HIPCHK(c, hipMemcpyAsync(L.h_red, L.red, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(L.h_info, L.info, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -43,6 +43,20 @@ struct Lane {
   hipStream_t sp[GPMI_NPAIRS] = {nullptr};
   hipStream_t su[GPMI_NPAIRS] = {nullptr};
   bool owns_pair = true;           // false (lane 1): the pair is lane 0's (api.hip: lane_alloc)
+  // Work of the alpha phase that does not depend on the factor (the residual y - mu, the sentinel fills of the two sweeps'
+  // outputs), enqueued on the lane's stream by the factorisation at the point where that stream has handed the work to the
+  // masked pair and would otherwise idle until the join (potrf_lower / potrf_flow_tail call lane_run_early; whoever set it
+  // calls it again behind the factorisation, where it is a no-op unless no such point came up): ~15 us per fit off the
+  // critical path (round 6)
+  struct EarlyWork {
+    bool pending = false;
+    const double* y = nullptr;
+    const double* mu = nullptr;
+    double mu_const = 0.0;
+    double* r = nullptr;
+    int64_t n = 0, np = 0;
+    double* fill[2] = {nullptr, nullptr};
+  } early;
   bool pair_checked = false;       // potrf_pair_quiesce has run for the factorisation being enqueued (potrf.hip)
   hipEvent_t ev_la = nullptr, ev_panel = nullptr, ev_join = nullptr, ev_main = nullptr, ev_slice = nullptr;
   double* A = nullptr;      // np x ld scratch (K then L)
@@ -335,13 +349,16 @@ void potrf_flow_free(Lane& lane);
 // solve.hip
 // forward substitution  L v = r : the solution goes to `out` (no aliasing; `r` is only read).
 // `err` (device int, may be null) receives GPMI_ERR_INTERNAL if the sweep's polling ever times out.
+// `prefilled`: `out` already holds the sentinel (lane_run_early), the sweep does not fill it again.
 void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
                   const double* invD, const double* r, double* out, int* err = nullptr,
-                  const BatchShape& bs = BatchShape());
+                  const BatchShape& bs = BatchShape(), bool prefilled = false);
 // backward substitution  L^T a = v : the solution goes to `out` (no aliasing; `r` is only read)
 void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
                    const double* invD, const double* r, double* out, int* err = nullptr,
-                   const BatchShape& bs = BatchShape());
+                   const BatchShape& bs = BatchShape(), bool prefilled = false);
+// the lane's pending EarlyWork, if any, on stream s (the lane's own stream)
+void lane_run_early(Lane& lane, hipStream_t s);
 // lockstep batch: Q_z <- L_z^-T (np <= 4096), every launch carries the batch
 void trsm_identity_batched(hipStream_t s, const double* L, int64_t np, int64_t ld, const double* invD, double* Q,
                            const BatchShape& bs);

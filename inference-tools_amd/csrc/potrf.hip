@@ -282,6 +282,9 @@ void potrf_lower(gpmi_ctx* c, Lane& lane, double* A, int64_t np, int64_t ld, dou
   bool sliced = false;            // a slice of the latest update is in flight on the panel stream (ev_slice)
   (void)hipEventRecord(lane.ev_panel, sf);
   (void)hipEventRecord(lane.ev_main, sf);
+  // from here to the join the lane's own stream idles when the masked pair takes over: the alpha phase's factor-independent
+  // launches go there (gpmi_internal.h: Lane::EarlyWork)
+  if (la_ok && NP > 1 && nt - tile0(1) >= LOOKAHEAD_MIN) lane_run_early(lane, sf);
   for (int p = 0; p + 1 < NP; ++p) {
     const int k0 = tile0(p), k1 = tile0(p + 1);  // tile columns of the panel being applied
     const int rem = nt - k1;                      // trailing tile rows

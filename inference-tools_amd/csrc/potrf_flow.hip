@@ -1188,6 +1188,7 @@ bool potrf_flow_tail(gpmi_ctx* c, Lane& lane, double* A, int64_t ld, double* inv
     (void)hipStreamWaitEvent(sp, lane.ev_join, 0);
     (void)hipStreamWaitEvent(su, lane.ev_join, 0);
   }
+  lane_run_early(lane, sf);  // (sf idles until the join: the alpha phase's factor-independent launches, Lane::EarlyWork)
   static const int proto = [] {
     const char* e = std::getenv("GPMI_FLOW_PROTO");
     return e ? std::atoi(e) : 0;

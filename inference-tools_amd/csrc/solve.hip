@@ -524,13 +524,23 @@ static void flow_gate_leave(gpmi_ctx* c, hipStream_t s, int64_t workgroups) {
   g_sweep_used[d] = true;
 }
 
+void lane_run_early(Lane& lane, hipStream_t s) {
+  Lane::EarlyWork& e = lane.early;
+  if (!e.pending) return;
+  e.pending = false;
+  launch_residual(s, e.y, e.mu, e.mu_const, e.r, e.n, e.np);
+  for (double* f : e.fill)
+    if (f) hipLaunchKernelGGL(flow_fill_kernel, dim3((unsigned)((e.np + 255) / 256), 1, 1), dim3(256), 0, s, f, e.np, (int64_t)0);
+}
+
 void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                  const double* invD, const double* r, double* out, int* err, const BatchShape& bs) {
+                  const double* invD, const double* r, double* out, int* err, const BatchShape& bs, bool prefilled) {
   const int nt = (int)(np / NB);
   flow_gate_enter(c, s, (int64_t)nt);
   ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)np * np, 4.0 * np * np);
-  hipLaunchKernelGGL(flow_fill_kernel, dim3((unsigned)((np + 255) / 256), 1, (unsigned)bs.count), dim3(256), 0, s,
-                     out, np, bs.sVec);
+  if (!prefilled)
+    hipLaunchKernelGGL(flow_fill_kernel, dim3((unsigned)((np + 255) / 256), 1, (unsigned)bs.count), dim3(256), 0, s,
+                       out, np, bs.sVec);
   const unsigned grid = bs.count > 1 ? 8u * (unsigned)nt * (unsigned)((bs.count + 7) / 8) : (unsigned)nt;
   hipLaunchKernelGGL(trsv_fwd_flow_kernel, dim3(grid), dim3(FLOW_THREADS), 0, s, L, ld, invD, r, out, err, bs.sMat,
                      bs.sInv, bs.sVec, nt, bs.count);
@@ -538,12 +548,13 @@ void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64
 }
 
 void trsv_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                   const double* invD, const double* r, double* out, int* err, const BatchShape& bs) {
+                   const double* invD, const double* r, double* out, int* err, const BatchShape& bs, bool prefilled) {
   const int nt = (int)(np / NB);
   flow_gate_enter(c, s, (int64_t)nt);
   ProfScope ps(c, s, GPMI_PROF_SOLVE, (double)np * np, 4.0 * np * np);
-  hipLaunchKernelGGL(flow_fill_kernel, dim3((unsigned)((np + 255) / 256), 1, (unsigned)bs.count), dim3(256), 0, s, out,
-                     np, bs.sVec);
+  if (!prefilled)
+    hipLaunchKernelGGL(flow_fill_kernel, dim3((unsigned)((np + 255) / 256), 1, (unsigned)bs.count), dim3(256), 0, s, out,
+                       np, bs.sVec);
   const unsigned grid = bs.count > 1 ? 8u * (unsigned)nt * (unsigned)((bs.count + 7) / 8) : (unsigned)nt;
   hipLaunchKernelGGL(trsv_bwd_flow_kernel, dim3(grid), dim3(FLOW_THREADS), 0, s, L, ld, invD, r, out, err, nt, bs.sMat,
                      bs.sInv, bs.sVec, bs.count);
