@@ -371,6 +371,161 @@ __global__ __launch_bounds__(FLOW_THREADS) void bwd_lab(const double* __restrict
   }
 }
 
+// ---- two block rows per workgroup: 256 rows per cross-workgroup hand-off.  The workgroup is the virtual workgroups 2p and
+// 2p + 1 of the 128-row kernel (same lane partials in the same order, same fold, same solve: bit-identical); the second one's
+// last input, v_{2p}, is handed over through LDS instead of through memory.
+__global__ __launch_bounds__(FLOW_THREADS) void fwd2_lab(const double* __restrict__ L, int64_t ld, const double* __restrict__ invD,
+                                                         const double* __restrict__ r, double* __restrict__ v, int* __restrict__ err, int nt) {
+  const int p = blockIdx.x, kA = 2 * p, kB = 2 * p + 1;
+  const bool hasB = kB < nt;
+  __shared__ __attribute__((aligned(16))) double part[NB][66];
+  __shared__ __attribute__((aligned(16))) double u[NB + 8];
+  __shared__ __attribute__((aligned(16))) double vl[NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row4 = tid >> 2, q4 = tid & 3;
+  const int wpos = 2 * (8 * (lane >> 4) + ((((lane & 15) >> 1) + 4 * (lane >> 5)) & 7)) + (lane & 1);
+  double xiA[32], xiB[32];
+  {
+    const double* pa = invD + (int64_t)kA * NB * NB + row4 * NB + q4 * 32;
+    const double* pb = invD + (int64_t)(hasB ? kB : kA) * NB * NB + row4 * NB + q4 * 32;
+#pragma unroll
+    for (int c = 0; c < 32; c += 2) {
+      const d2_t a = *reinterpret_cast<const d2_t*>(pa + c);
+      xiA[c] = a[0];
+      xiA[c + 1] = a[1];
+      const d2_t b = *reinterpret_cast<const d2_t*>(pb + c);
+      xiB[c] = b[0];
+      xiB[c + 1] = b[1];
+    }
+  }
+  const double rkA = r[(int64_t)kA * NB + row4];
+  const double rkB = hasB ? r[(int64_t)kB * NB + row4] : 0.0;
+  double accA[16], accB[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accA[i] = accB[i] = 0.0;
+  const int nA = kA;
+  const double* baseA = L + (int64_t)(kA * NB + wave * 16) * ld + 2 * lane;
+  const double* baseB = baseA + (hasB ? (int64_t)NB * ld : 0);
+  d2_t a0[8], a1[8], b0[8], b1[8];
+  bool dead = false;
+  // first tiles: block 0 of both halves (for p = 0, B's only block is the diagonal-adjacent one, block kA = 0)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    b0[i] = *reinterpret_cast<const d2_t*>(baseB + (int64_t)i * ld);
+    b1[i] = *reinterpret_cast<const d2_t*>(baseB + (int64_t)(8 + i) * ld);
+  }
+  if (nA > 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      a0[i] = *reinterpret_cast<const d2_t*>(baseA + (int64_t)i * ld);
+      a1[i] = *reinterpret_cast<const d2_t*>(baseA + (int64_t)(8 + i) * ld);
+    }
+    for (int j = 0; j < nA; ++j) {
+      double v0, v1;
+      flow_poll2(v + (int64_t)j * NB + 2 * lane, err, dead, v0, v1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) accA[i] = fma(a0[i][0], v0, fma(a0[i][1], v1, accA[i]));
+      if (j + 1 < nA) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a0[i] = *reinterpret_cast<const d2_t*>(baseA + (int64_t)i * ld + (int64_t)(j + 1) * NB);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) accA[8 + i] = fma(a1[i][0], v0, fma(a1[i][1], v1, accA[8 + i]));
+      if (j + 1 < nA) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a1[i] = *reinterpret_cast<const d2_t*>(baseA + (int64_t)(8 + i) * ld + (int64_t)(j + 1) * NB);
+      }
+      if (hasB) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) accB[i] = fma(b0[i][0], v0, fma(b0[i][1], v1, accB[i]));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b0[i] = *reinterpret_cast<const d2_t*>(baseB + (int64_t)i * ld + (int64_t)(j + 1) * NB);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) accB[8 + i] = fma(b1[i][0], v0, fma(b1[i][1], v1, accB[8 + i]));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b1[i] = *reinterpret_cast<const d2_t*>(baseB + (int64_t)(8 + i) * ld + (int64_t)(j + 1) * NB);
+      }
+    }
+  }
+  // ---- stage A
+  double sA;
+  {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[wave * 16 + i][wpos] = accA[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double pv[16];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const d2_t x = *reinterpret_cast<const d2_t*>(&part[row4][2 * (8 * q4 + ((t + 4 * (q4 >> 1)) & 7))]);
+      pv[2 * t] = x[0];
+      pv[2 * t + 1] = x[1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s += pv[c];
+    s += quad_swap<QUAD_XOR1>(s);
+    s += quad_swap<QUAD_XOR2>(s);
+    if (q4 == 0) u[row4 + 2 * (row4 >> 5)] = rkA - s;
+    __syncthreads();
+    double uv[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) uv[c] = u[q4 * 34 + c];
+    __builtin_amdgcn_sched_barrier(0);
+    s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) s = fma(xiA[c], uv[c], s);
+    s += quad_swap<QUAD_XOR1>(s);
+    s += quad_swap<QUAD_XOR2>(s);
+    sA = s;
+    if (q4 == 0) {
+      flow_publish(v + (int64_t)kA * NB + row4, sA);
+      vl[row4] = sA;
+    }
+  }
+  if (!hasB) return;
+  __syncthreads();  // v_A in LDS; every read of u by stage A is done
+  {
+    const d2_t va = *reinterpret_cast<const d2_t*>(&vl[2 * lane]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) accB[i] = fma(b0[i][0], va[0], fma(b0[i][1], va[1], accB[i]));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) accB[8 + i] = fma(b1[i][0], va[0], fma(b1[i][1], va[1], accB[8 + i]));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[wave * 16 + i][wpos] = accB[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double pv[16];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const d2_t x = *reinterpret_cast<const d2_t*>(&part[row4][2 * (8 * q4 + ((t + 4 * (q4 >> 1)) & 7))]);
+      pv[2 * t] = x[0];
+      pv[2 * t + 1] = x[1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s += pv[c];
+    s += quad_swap<QUAD_XOR1>(s);
+    s += quad_swap<QUAD_XOR2>(s);
+    if (q4 == 0) u[row4 + 2 * (row4 >> 5)] = rkB - s;
+    __syncthreads();
+    double uv[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) uv[c] = u[q4 * 34 + c];
+    __builtin_amdgcn_sched_barrier(0);
+    s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) s = fma(xiB[c], uv[c], s);
+    s += quad_swap<QUAD_XOR1>(s);
+    s += quad_swap<QUAD_XOR2>(s);
+    if (q4 == 0) flow_publish(v + (int64_t)kB * NB + row4, s);
+  }
+}
+
 struct Bufs {
   double *L, *invD, *r, *v;
   int* err;
@@ -437,6 +592,9 @@ int main(int argc, char** argv) {
     run("forward  product (solve.hip)", b, [&] {
       hipLaunchKernelGGL(trsv_fwd_flow_kernel, dim3(b.nt), dim3(FLOW_THREADS), 0, b.s, b.L, b.ld, b.invD, b.r, b.v, b.err, (int64_t)0,
                          (int64_t)0, (int64_t)0, b.nt, 1);
+    });
+    run("forward  TWO block rows per workgroup", b, [&] {
+      hipLaunchKernelGGL(fwd2_lab, dim3((b.nt + 1) / 2), dim3(FLOW_THREADS), 0, b.s, b.L, b.ld, b.invD, b.r, b.v, b.err, b.nt);
     });
     FWD("round-5 form", 0);
     FWD("no first barrier", F_NOBAR1);
