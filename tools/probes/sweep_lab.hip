@@ -2,6 +2,12 @@
 // with HIP events (min of 10 launches, the fill outside the timed region) and check-summed - the product kernels of
 // solve.hip ("product") run beside them.  Variants that survive are ported into solve.hip by hand; nothing here ships.
 //   bash tools/probes/sweep_lab.sh [n ...]
+// Flags: NOBAR1 (fold without the first barrier), DPP (lane exchanges), UPFRONT (LDS reads issued before their use), PAD (the
+// conflict-free layouts - the form solve.hip ships), BACKOFF (far pollers sleep longer), WARM (a dummy pass through the
+// tail code), SKIP_FOLD / SKIP_SOLVE (ablations: wrong results by design), RING4 / RING8 (several polls in flight: the
+// check sums DIFFER - the compiler may copy a ring register between the load and its wait, and loads still in flight at
+// the exit are only drained, not owned; kept as the record of the timing experiment, not as code to port), and
+// fwd2_lab (two block rows per workgroup: 179 spilled registers).  profiles/HISTORY.md R6.8.
 #include "../../inference-tools_amd/csrc/solve.hip"
 
 #include <cstdio>
