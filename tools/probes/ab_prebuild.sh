@@ -1,3 +1,5 @@
+# NOTE: the GPMI_PREBUILD_INV2 mode switch this script drives was a temporary patch of enqueue_factor_and_forward (api.hip) and is
+# not in the library; the script is kept as the record of the experiment in profiles/HISTORY.md R6.12.
 # where the prediction's 512 x 512 inverse blocks are built (GPMI_PREBUILD_INV2: 1 beside the forward sweep on the update
 # stream, 2 on the panel stream's 32 CUs, 3 beside the backward sweep, 4 not at all (first predict builds them), 0 not at
 # all and the v.v / log det reduction in front of the backward sweep): fit alone, fit + predict, sweep kernel durations
