@@ -31,13 +31,14 @@ __device__ inline double wave_sum(double v) {
 // left on the critical path.  The summation order is fixed, so results are bit-reproducible.
 //
 // Progress.  Workgroup k only ever waits for workgroups with a lower index of the SAME launch.  HIP promises
-// no dispatch order, so the argument is residency, not order: a sweep never has more workgroups in flight
-// than the chip holds resident at once (FLOW_THREADS = 512 threads, ~67 KiB of LDS: two per CU, 512 on the
-// chip), hence every workgroup of the launch - the producers a poller waits for included - is resident or
-// already finished, whatever order the dispatcher (one per XCD) picked.  The host side enforces it:
-// sweeps_in_flight() below serialises sweeps of different lanes once their workgroups would not all fit
-// (a batched sweep carries its whole batch in one launch, in-order per XCD queue, lowest unfinished index
-// always dispatchable).  Should a poll still time out (a bug, not a wait) the workgroup gives up for good:
+// no dispatch order, so the first argument is residency, not order: a sweep of up to `ncu` workgroups (N <= 32768 on 256
+// CUs; a workgroup's 8 waves x ~200 registers and ~68 KiB of LDS leave room for exactly one per CU) has every workgroup of
+// the launch - the producers a poller waits for included - resident or already finished, whatever order the dispatcher
+// (one per XCD) picked.  The host side keeps it that way across streams: sweeps_in_flight() below serialises sweeps of
+// different lanes once their workgroups would not all fit.  Larger sweeps, and batched ones (a whole batch in one
+// launch), rest on what the hardware does: linear workgroup ids are handed out in ascending order, each XCD starting its
+// share in order, so the lowest unfinished index is always resident or next to be dispatched (flow_batched_id below
+// spells this out for batches).  Should a poll still time out (a bug, not a wait) the workgroup gives up for good:
 // every later poll of that lane returns at once, it publishes what it has, and its consumers - which then
 // read a non-sentinel value - do the same, so the launch drains in O(1) polls per workgroup and the host
 // reports GPMI_ERR_INTERNAL instead of a hung GPU.
@@ -490,10 +491,10 @@ __global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restric
 }  // namespace
 
 // Serialise sweeps of different streams so that their workgroups are always all resident together (see the
-// progress argument above): the chip holds 2 x ncu flow workgroups; a sweep of nt >= FLOW_GATE_MIN workgroups
+// progress argument above): the chip holds one flow workgroup per CU; a sweep of nt >= FLOW_GATE_MIN workgroups
 // (N > 4096: the sizes that run one lane per evaluation, gpmi_lml_batch) queues behind the previous such sweep of
-// the context through one event, whichever lane or context issues it, so at most one of them (<= 2 x ncu workgroups for
-// N <= 65536) is in flight beside any number of small ones.  They are HBM-bound and sub-millisecond: nothing is
+// the context through one event, whichever lane or context issues it, so at most one of them (<= ncu workgroups for
+// N <= 32768) is in flight beside any number of small ones.  They are HBM-bound and sub-millisecond: nothing is
 // lost by not overlapping them.
 // The gate is per DEVICE, process-wide (one event per device id under a mutex), not per context: a regressor, the
 // engine its covariance object keeps for cross-covariances, a second regressor or another thread each have a context
