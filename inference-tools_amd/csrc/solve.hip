@@ -65,31 +65,6 @@ __device__ inline double flow_poll(const double* p, int* err, bool& dead) {
   return (bits == FLOW_SENTINEL) ? 0.0 : __longlong_as_double((long long)bits);
 }
 
-// Two neighbouring elements in ONE memory round trip: both loads are issued before either is looked at (the forward sweep's
-// lanes need v[2 l] and v[2 l + 1]; polled one after the other - round 3 to 5 - the second load started only when the
-// first had returned a value: a second agent-scope round trip, ~1 us, on every step of the sweep's critical path).
-__device__ inline void flow_poll2(const double* p, int* err, bool& dead, double& a, double& b) {
-  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-  unsigned long long x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  unsigned long long y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  int spins = 0;
-  while ((x == FLOW_SENTINEL || y == FLOW_SENTINEL) && !dead) {
-    __builtin_amdgcn_s_sleep(1);
-    const unsigned long long x2 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long y2 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    x = x2;
-    y = y2;
-    ++spins;
-    if ((spins & 4095) == 0 && err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) dead = true;
-    if (spins > FLOW_SPIN_LIMIT) {
-      if (err) atomicCAS(err, 0, GPMI_ERR_INTERNAL);
-      dead = true;
-    }
-  }
-  a = (x == FLOW_SENTINEL) ? 0.0 : __longlong_as_double((long long)x);
-  b = (y == FLOW_SENTINEL) ? 0.0 : __longlong_as_double((long long)y);
-}
-
 // Which (step, problem) a workgroup of a BATCHED sweep is.  One problem's workgroups form a dependency chain, and a
 // resident workgroup must never wait for one that has not been dispatched: the dispatcher hands linear workgroup id n to
 // XCD n % 8 and every XCD starts its share in order, so problem z lives entirely on XCD z % 8, its steps in increasing
@@ -170,6 +145,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void trsv_fwd_flow_kernel(
   // 4-way conflicts, ~0.6 us each on every step of the sweep; the summation order is the same, the results bit-identical.)
   __shared__ __attribute__((aligned(16))) double part[NB][66];
   __shared__ __attribute__((aligned(16))) double u[NB + 8];
+  __shared__ __attribute__((aligned(16))) double vin[2][NB];  // v_j on its way from the two polling waves to all eight
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row4 = tid >> 2, q4 = tid & 3;  // four threads per row, 32 columns each
   const int wpos = 2 * (8 * (lane >> 4) + ((((lane & 15) >> 1) + 4 * (lane >> 5)) & 7)) + (lane & 1);
@@ -201,9 +177,17 @@ __global__ __launch_bounds__(FLOW_THREADS) void trsv_fwd_flow_kernel(
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         hb[i] = *reinterpret_cast<const d2_t*>(base + (int64_t)(8 + i) * ld + (int64_t)j * NB);
-      double v0, v1;
-      flow_poll2(v + (int64_t)j * NB + 2 * lane, err, dead, v0, v1);
+      // Two waves poll (one element per lane) and hand v_j on through LDS, as the backward sweep does: the step's fold
+      // waits for the LAST wave that has seen the values, and the last of eight independent poll loops (each one memory
+      // round trip per turn) is later than the one loop of a wave pair by a third of a round trip - 0.25 us per step at
+      // N = 16384, where all eight waves polling for themselves also put eight times the requests on v_j's lines
+      // (tools/probes/sweep_lab.hip: POLL2W; rounds 3-6a polled per wave).  Double-buffered: a slow wave may still read v_{j-1}.
+      double* vj = vin[j & 1];
+      if (tid < NB) vj[tid] = flow_poll(v + (int64_t)j * NB + tid, err, dead);
       if (j == nmain - 1) SWEEP_STAMP(0, k);
+      __syncthreads();
+      const d2_t vv = *reinterpret_cast<const d2_t*>(&vj[2 * lane]);
+      const double v0 = vv[0], v1 = vv[1];
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] = fma(ha[i][0], v0, fma(ha[i][1], v1, acc[i]));
       if (j + 1 < nmain) {

@@ -15,7 +15,31 @@
 #include <vector>
 
 namespace {
-enum { F_NOBAR1 = 1, F_DPP = 2, F_UPFRONT = 4, F_SKIP_FOLD = 8, F_SKIP_SOLVE = 16, F_BACKOFF = 32, F_UPLOOP = 64, F_RING4 = 128, F_RING8 = 256, F_WARM = 512, F_PAD = 1024 };
+// Two neighbouring elements in ONE memory round trip: both loads are issued before either is looked at (measured flat
+// against two polls one after the other; the product kernel now polls with two waves, one element per lane).
+__device__ inline void flow_poll2(const double* p, int* err, bool& dead, double& a, double& b) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  unsigned long long x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int spins = 0;
+  while ((x == FLOW_SENTINEL || y == FLOW_SENTINEL) && !dead) {
+    __builtin_amdgcn_s_sleep(1);
+    const unsigned long long x2 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long y2 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    x = x2;
+    y = y2;
+    ++spins;
+    if ((spins & 4095) == 0 && err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) dead = true;
+    if (spins > FLOW_SPIN_LIMIT) {
+      if (err) atomicCAS(err, 0, GPMI_ERR_INTERNAL);
+      dead = true;
+    }
+  }
+  a = (x == FLOW_SENTINEL) ? 0.0 : __longlong_as_double((long long)x);
+  b = (y == FLOW_SENTINEL) ? 0.0 : __longlong_as_double((long long)y);
+}
+
+enum { F_NOBAR1 = 1, F_DPP = 2, F_UPFRONT = 4, F_SKIP_FOLD = 8, F_SKIP_SOLVE = 16, F_BACKOFF = 32, F_UPLOOP = 64, F_RING4 = 128, F_RING8 = 256, F_WARM = 512, F_PAD = 1024, F_POLL1 = 2048, F_POLL2W = 4096 };
 
 template <int F>
 __device__ inline double poll_far(const double* p, int* err, bool& dead, int far) {
@@ -112,6 +136,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void fwd_lab(const double* __restrict
   invD += (int64_t)k * NB * NB;
   __shared__ __attribute__((aligned(16))) double part[NB][66];
   __shared__ __attribute__((aligned(16))) double u[NB + 8];
+  __shared__ __attribute__((aligned(16))) double vin[2][NB];  // F_POLL1 / F_POLL2W: v_j through LDS, one / two waves poll
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row4 = tid >> 2, q4 = tid & 3;
   // F_PAD layout: a row is 32 slots of 16 B (+1 pad); the partial of source lane 16 q + c sits in slot 8 q + ((c/2 + 4 (q/2)) % 8)
@@ -144,7 +169,22 @@ __global__ __launch_bounds__(FLOW_THREADS) void fwd_lab(const double* __restrict
 #pragma unroll
       for (int i = 0; i < 8; ++i) hb[i] = *reinterpret_cast<const d2_t*>(base + (int64_t)(8 + i) * ld + (int64_t)j * NB);
       double v0, v1;
-      if ((F & (F_RING4 | F_RING8)) && j == nmain - 1 && !dead) {
+      if (F & (F_POLL1 | F_POLL2W)) {
+        double* vj = vin[j & 1];
+        if (F & F_POLL1) {
+          if (wave == 0) {
+            double a, b;
+            poll2_far<F>(v + (int64_t)j * NB + 2 * lane, err, dead, a, b, 0);
+            *reinterpret_cast<d2_t*>(&vj[2 * lane]) = d2_t{a, b};
+          }
+        } else if (tid < NB) {
+          vj[tid] = poll_far<F>(v + (int64_t)j * NB + tid, err, dead, 0);
+        }
+        __syncthreads();
+        const d2_t x = *reinterpret_cast<const d2_t*>(&vj[2 * lane]);
+        v0 = x[0];
+        v1 = x[1];
+      } else if ((F & (F_RING4 | F_RING8)) && j == nmain - 1 && !dead) {
         const u64x2 g = ring_poll<u64x2, (F & F_RING8) ? 8 : 4>(v + (int64_t)j * NB + 2 * lane, err, dead);
         v0 = ring_value(g.x);
         v1 = ring_value(g.y);
@@ -615,6 +655,8 @@ int main(int argc, char** argv) {
     FWD("pad+nobar+dpp+upfront", F_PAD | F_NOBAR1 | F_DPP | F_UPFRONT);
     FWD("pad+nobar+dpp", F_PAD | F_NOBAR1 | F_DPP);
     FWD("pad+nobar+dpp+upfront+backoff", F_PAD | F_NOBAR1 | F_DPP | F_UPFRONT | F_BACKOFF);
+    FWD("pad+nobar+dpp+upfront+POLL1 (one wave polls)", F_PAD | F_NOBAR1 | F_DPP | F_UPFRONT | F_POLL1);
+    FWD("pad+nobar+dpp+upfront+POLL2W (two waves poll)", F_PAD | F_NOBAR1 | F_DPP | F_UPFRONT | F_POLL2W);
     FWD("warm (round-5 form)", F_WARM);
     FWD("nobar+dpp+upfront+warm", F_NOBAR1 | F_DPP | F_UPFRONT | F_WARM);
     FWD("nobar+dpp+warm", F_NOBAR1 | F_DPP | F_WARM);
