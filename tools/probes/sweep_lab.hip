@@ -7,7 +7,9 @@
 // tail code), SKIP_FOLD / SKIP_SOLVE (ablations: wrong results by design), RING4 / RING8 (several polls in flight: the
 // check sums DIFFER - the compiler may copy a ring register between the load and its wait, and loads still in flight at
 // the exit are only drained, not owned; kept as the record of the timing experiment, not as code to port), and
-// fwd2_lab (two block rows per workgroup: 179 spilled registers).  profiles/HISTORY.md R6.8.
+// fwd2_lab (two block rows per workgroup: 179 spilled registers); POLL1 / POLL2W (one / two waves poll and hand v_j on
+// through LDS - POLL2W is what solve.hip ships since R6.13), PUB2 / PUB1 (the step's 128 values published by two waves / one wave
+// instead of by sixteen lanes of each of the eight: slower by the extra barrier).  profiles/HISTORY.md R6.8, R6.13.
 #include "../../inference-tools_amd/csrc/solve.hip"
 
 #include <cstdio>
@@ -39,7 +41,7 @@ __device__ inline void flow_poll2(const double* p, int* err, bool& dead, double&
   b = (y == FLOW_SENTINEL) ? 0.0 : __longlong_as_double((long long)y);
 }
 
-enum { F_NOBAR1 = 1, F_DPP = 2, F_UPFRONT = 4, F_SKIP_FOLD = 8, F_SKIP_SOLVE = 16, F_BACKOFF = 32, F_UPLOOP = 64, F_RING4 = 128, F_RING8 = 256, F_WARM = 512, F_PAD = 1024, F_POLL1 = 2048, F_POLL2W = 4096 };
+enum { F_NOBAR1 = 1, F_DPP = 2, F_UPFRONT = 4, F_SKIP_FOLD = 8, F_SKIP_SOLVE = 16, F_BACKOFF = 32, F_UPLOOP = 64, F_RING4 = 128, F_RING8 = 256, F_WARM = 512, F_PAD = 1024, F_POLL1 = 2048, F_POLL2W = 4096, F_PUB2 = 8192, F_PUB1 = 16384 };
 
 template <int F>
 __device__ inline double poll_far(const double* p, int* err, bool& dead, int far) {
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void fwd_lab(const double* __restrict
   __shared__ __attribute__((aligned(16))) double part[NB][66];
   __shared__ __attribute__((aligned(16))) double u[NB + 8];
   __shared__ __attribute__((aligned(16))) double vin[2][NB];  // F_POLL1 / F_POLL2W: v_j through LDS, one / two waves poll
+  __shared__ __attribute__((aligned(16))) double vout[NB];    // F_PUB1 / F_PUB2: v_k on its way to the publishing wave(s)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row4 = tid >> 2, q4 = tid & 3;
   // F_PAD layout: a row is 32 slots of 16 B (+1 pad); the partial of source lane 16 q + c sits in slot 8 q + ((c/2 + 4 (q/2)) % 8)
@@ -273,7 +276,19 @@ __global__ __launch_bounds__(FLOW_THREADS) void fwd_lab(const double* __restrict
       s += __shfl_xor(s, 1, 64);
       s += __shfl_xor(s, 2, 64);
     }
-    if (q4 == 0 && pass == 1) flow_publish(v + (int64_t)k * NB + row4, s);
+    if (F & (F_PUB2 | F_PUB1)) {
+      // publish from two waves / one wave instead of from sixteen lanes of each of the eight
+      double* vo = vout;
+      if (q4 == 0) vo[row4] = s;
+      __syncthreads();
+      if (pass == 1) {
+        if ((F & F_PUB2) && tid < NB) flow_publish(v + (int64_t)k * NB + tid, vo[tid]);
+        if ((F & F_PUB1) && tid < 64) {
+          flow_publish(v + (int64_t)k * NB + 2 * tid, vo[2 * tid]);
+          flow_publish(v + (int64_t)k * NB + 2 * tid + 1, vo[2 * tid + 1]);
+        }
+      }
+    } else if (q4 == 0 && pass == 1) flow_publish(v + (int64_t)k * NB + row4, s);
   }
   }
 }
@@ -657,6 +672,8 @@ int main(int argc, char** argv) {
     FWD("pad+nobar+dpp+upfront+backoff", F_PAD | F_NOBAR1 | F_DPP | F_UPFRONT | F_BACKOFF);
     FWD("pad+nobar+dpp+upfront+POLL1 (one wave polls)", F_PAD | F_NOBAR1 | F_DPP | F_UPFRONT | F_POLL1);
     FWD("pad+nobar+dpp+upfront+POLL2W (two waves poll)", F_PAD | F_NOBAR1 | F_DPP | F_UPFRONT | F_POLL2W);
+    FWD("POLL2W + publish from two waves", F_PAD | F_NOBAR1 | F_DPP | F_UPFRONT | F_POLL2W | F_PUB2);
+    FWD("POLL2W + publish from one wave", F_PAD | F_NOBAR1 | F_DPP | F_UPFRONT | F_POLL2W | F_PUB1);
     FWD("warm (round-5 form)", F_WARM);
     FWD("nobar+dpp+upfront+warm", F_NOBAR1 | F_DPP | F_UPFRONT | F_WARM);
     FWD("nobar+dpp+warm", F_NOBAR1 | F_DPP | F_WARM);
