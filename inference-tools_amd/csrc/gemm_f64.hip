@@ -142,6 +142,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     tj = 2 * bj + (wid & 1);
   } else {
     tile_of<TILES>(g.tile_base + wid, g.ntr, g.ntc, ti, tj);
+    // Products with a lower-triangular B (kskip 2: the contraction of tile column tj ends at (tj + 1) BN) have tile columns of
+    // very different length.  The second half of the tile rows takes them in mirrored order, so that the two workgroups a
+    // CU holds - one from each half of a launch of 2 x #CUs tiles - carry a long and a short contraction.
+    if (TILES == TILES_RECT && g.kskip == 2 && 2 * ti >= g.ntr) tj = g.ntc - 1 - tj;
   }
 
   const int tid = threadIdx.x;
@@ -373,6 +377,14 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
       // 512 x 512 inverse blocks on the chain of the many-right-hand-side solves, 128 workgroups x up to 13 us of
       // MFMA time on one CU each): 32-row tiles put the same work on twice as many CUs
       if (tiles == TILES_RECT && !b_kmajor && k > 128 && big * 4 * bt.count <= m32_max && !bt.ring_order_only) bm = 32;
+      // ... and with a triangular B (the contraction of a tile column ends at its diagonal) 32 x 32 tiles: twice the
+      // workgroups again, the long columns' MFMA time halved, long and short columns paired on a CU (gemm_nt_kernel).
+      // GPMI_CHAIN_BN32=0: 32 x 64 tiles (rounds 5-6a)
+      static const bool bn32 = [] {
+        const char* e = std::getenv("GPMI_CHAIN_BN32");
+        return !e || std::atoi(e) != 0;
+      }();
+      if (bn32 && bm == 32 && kskip == 2 && op == OP_ASSIGN && big * 8 * bt.count <= 2 * 256) bn = 32;
     }
   }
   // the panel TRSM with the caller's word that B (the inverse of a diagonal block) is lower triangular
@@ -466,6 +478,8 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
     GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0, 32, 128);
   } else if (bn == 128) {
     if (b_kmajor) GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 1, 64, 128); else GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0, 64, 128);
+  } else if (bm == 32 && bn == 32) {
+    GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0, 32, 32);
   } else if (bm == 32) {
     if (op == OP_SUB) GPMI_LAUNCH(TILES_RECT, OP_SUB, 0, 32, 64); else GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0, 32, 64);
   } else {

@@ -1657,6 +1657,7 @@ def test_schedule_variants_agree(tmp_path):
         {"GPMI_FLOW_URGENT": "0", "GPMI_FLOW_QUARTER": "2"},  # chunks of the outer panels 0, 1 whole, the later ones in quarters
         {"GPMI_GEMM_MIXED": "0"},  # (round 6) the 64 x 64 remainder of a trailing update in a launch of its own
         {"GPMI_EARLY_FILL": "0"},  # (round 6) residual and the sweeps' sentinel fills behind the factorisation, not beside it
+        {"GPMI_CHAIN_BN32": "0"},  # (round 6) the predict's chain products on 32 x 64 instead of 32 x 32 tiles
     ]
     base = None
     for k, extra in enumerate(variants):
