@@ -691,7 +691,7 @@ int gpmi_spatial_derivatives(gpmi_ctx* c, const double* pts, int64_t m, double* 
     if (int rc = ensure_inv2(c, L, s)) return rc;
     if (int rc = ensure_trsm_panel(c, mp)) return rc;
     trsm_rows_forward(c, s, L.A, c->np, c->ld, L.inv2, c->Q2, mp, false, nullptr, c->trsm_panel);
-    trsm_rows_backward(c, s, L.A, c->np, c->ld, L.invD, c->Q2, mp);
+    trsm_rows_backward(c, s, L.A, c->np, c->ld, L.invD, c->Q2, mp, L.inv2, c->trsm_panel);
     double* dmu_dev = c->pvec;
     double* dvar_dev = c->pvec + mp * d;
     launch_sd_reduce(s, p, c->x, c->n, c->pts, mc, c->Q, c->ld, c->alpha, 0, 1.0, dmu_dev);

@@ -36,6 +36,8 @@ struct GemmArgs {
   // 2: contraction ends at k = (tj + 1) * BN (B is lower triangular: B[j][k] = 0 for k > j)
   // 3: one tile column of 128 = the whole contraction with a lower-triangular B (the panel TRSM as a product with the
   //    inverse diagonal block): the zero part is skipped inside the tile (gemm_tiles::staged_tile, BTRI)
+  // 4 (register-staged kernels, k-major B): contraction starts at k = tj * BN (B[k][j] = 0 for k < j: a lower-triangular
+  //    B applied from the right, untransposed - the backward row solve's products with the 512 x 512 inverse blocks)
   int kskip;
   // optional wall-clock stamps of this launch (s_memrealtime, 100 MHz; 16 words, see the kernel): per-launch
   // durations for the roofline without HIP events in the stream (event records between the look-ahead
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     // Products with a lower-triangular B (kskip 2: the contraction of tile column tj ends at (tj + 1) BN) have tile columns of
     // very different length.  The second half of the tile rows takes them in mirrored order, so that the two workgroups a
     // CU holds - one from each half of a launch of 2 x #CUs tiles - carry a long and a short contraction.
-    if (TILES == TILES_RECT && g.kskip == 2 && 2 * ti >= g.ntr) tj = g.ntc - 1 - tj;
+    if (TILES == TILES_RECT && (g.kskip == 2 || g.kskip == 4) && 2 * ti >= g.ntr) tj = g.ntc - 1 - tj;
   }
 
   const int tid = threadIdx.x;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     r_start = __builtin_amdgcn_s_memrealtime();
     c_start = __builtin_amdgcn_s_memtime();
   }
-  const int kbeg = (g.kskip == 1) ? ti * BM : 0;
+  const int kbeg = (g.kskip == 1) ? ti * BM : (g.kskip == 4) ? tj * BN : 0;
   const int kend = (g.kskip == 2 && (tj + 1) * BN < g.k) ? (tj + 1) * BN : g.k;
   const int64_t bz = me.bz;
   const double* __restrict__ Ag = g.A + bz * g.sA + (int64_t)ti * BM * g.lda + kbeg;
@@ -387,6 +389,17 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
       if (bn32 && bm == 32 && kskip == 2 && op == OP_ASSIGN && big * 8 * bt.count <= 2 * 256) bn = 32;
     }
   }
+  // the backward row solve's product with an inverse block (k-major triangular B, kskip 4): 32 x 32 tiles while that puts
+  // at most two workgroups on a CU (long and short contractions paired, see gemm_nt_kernel), 64 x 128 beyond
+  if (part == 0 && kskip == 4 && b_kmajor && op == OP_ASSIGN && tiles == TILES_RECT) {
+    if (big * 16 * bt.count <= 2 * 256) {
+      bm = 32;
+      bn = 32;
+    } else {
+      bm = 64;
+      bn = 128;
+    }
+  }
   // the panel TRSM with the caller's word that B (the inverse of a diagonal block) is lower triangular
   if (bt.b_lower_tri && kskip == 0 && bn == 128 && bm <= 64 && ntc == 1 && k == 128 && !b_kmajor && op == OP_ASSIGN) kskip = 3;
   GemmArgs g{C, A, B, ldc, lda, ldb, ntr * (128 / bm), ntc * (128 / bn), k, kskip, stamp,
@@ -479,7 +492,7 @@ void launch_gemm_part(hipStream_t s, GemmTiles tiles, GemmOp op, bool b_kmajor, 
   } else if (bn == 128) {
     if (b_kmajor) GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 1, 64, 128); else GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0, 64, 128);
   } else if (bm == 32 && bn == 32) {
-    GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0, 32, 32);
+    if (b_kmajor) GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 1, 32, 32); else GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0, 32, 32);
   } else if (bm == 32) {
     if (op == OP_SUB) GPMI_LAUNCH(TILES_RECT, OP_SUB, 0, 32, 64); else GPMI_LAUNCH(TILES_RECT, OP_ASSIGN, 0, 32, 64);
   } else {

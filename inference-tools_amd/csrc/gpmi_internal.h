@@ -396,8 +396,10 @@ void launch_rows_sumsq(hipStream_t s, const double* Q, int64_t ld, int64_t mp, i
                        double base, double* out, int batch = 1, int64_t sQ = 0, int64_t sVec = 0, double sign = 1.0);
 
 // Q (mp x np) <- Q L^-1   (backward solve of mp right-hand sides stored as rows)
+// (inv2 / panel: the 512 x 512 inverse blocks and an mp x (512 + 32) scratch panel, as for trsm_rows_forward; without them
+// the sweep runs over the 128-wide blocks with invD)
 void trsm_rows_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                        const double* invD, double* Q, int64_t mp);
+                        const double* invD, double* Q, int64_t mp, const double* inv2 = nullptr, double* panel = nullptr);
 
 // predgrad.hip
 void launch_sd_reduce(hipStream_t s, const KParams& p, const double* x, int64_t n, const double* pts,

@@ -623,9 +623,35 @@ void trsm_rows_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, 
 }
 
 void trsm_rows_backward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
-                        const double* invD, double* Q, int64_t mp) {
+                        const double* invD, double* Q, int64_t mp, const double* inv2, double* panel) {
   const int nt = (int)(np / NB), mt = (int)(mp / NB);
   ProfScope ps(c, s, GPMI_PROF_TRSM, (double)mp * np * np, 4.0 * np * np);
+  // GPMI_BACKWARD_OB=0: the 128-wide steps of rounds 1-6a (two launches per tile column)
+  static const bool wide = [] {
+    const char* e = std::getenv("GPMI_BACKWARD_OB");
+    return !e || std::atoi(e) != 0;
+  }();
+  if (wide && inv2 && panel) {
+    // Right-looking over the 512-wide outer blocks from the last to the first, the mirror image of trsm_rows_forward: the
+    // block's solution is ONE product with the inverted diagonal block (untransposed: B is k-major, the contraction of
+    // tile column j starts at its diagonal), then ONE update with K = 512 carries it to all columns to its left.  At
+    // N = 4096 that is 8 dependent pairs of launches instead of 32 (round 6; the spatial derivatives of config 4's
+    // acquisition gradient spent 45 % of their time in those 64 launches).
+    const int OBT = GPMI_OB / NB;
+    const int64_t ldp = GPMI_OB + 32;
+    const int nob = (nt + OBT - 1) / OBT;
+    for (int b = nob - 1; b >= 0; --b) {
+      const int J = b * OBT, Je = (J + OBT < nt) ? J + OBT : nt, w = Je - J;
+      double* QJ = Q + (int64_t)J * NB;
+      launch_gemm(s, TILES_RECT, OP_ASSIGN, true, 4, panel, ldp, QJ, ld, inv2 + (int64_t)b * GPMI_OB * GPMI_OB, GPMI_OB, mt, w,
+                  w * NB);
+      if (J > 0)  // Q[:, 0:J] -= X * L[J:Je, 0:J]     (B = block rows J .. Je of L, k-major)
+        launch_gemm(s, TILES_RECT, OP_SUB, true, 0, Q, ld, panel, ldp, L + (int64_t)J * NB * ld, ld, mt, J, w * NB);
+      hipLaunchKernelGGL(copy_panel_kernel, dim3((unsigned)(w * NB / 2 / 64), (unsigned)((int64_t)mt * NB)), dim3(64), 0, s, panel,
+                         ldp, QJ, ld);
+    }
+    return;
+  }
   for (int k = nt - 1; k >= 0; --k) {
     double* Qk = Q + (int64_t)k * NB;
     // Q[:, k] <- Q[:, k] * invD_k          (B = invD_k is k-major here)

@@ -1677,6 +1677,51 @@ def test_schedule_variants_agree(tmp_path):
                 assert np.array_equal(r[q + "0"], base[q + "0"]), (extra, q)
 
 
+def test_backward_row_solve_over_wide_blocks_matches_the_narrow_steps(tmp_path, gp_mod):
+    """Spatial derivatives (regression.py:388-418) need K^-1 k per query point: a forward and a BACKWARD solve with the
+    factor over many right-hand sides.  Since round 6 the backward one runs over the 512-wide outer blocks (one product
+    with the untransposed inverse block - k-major triangular B, contraction from the tile column's diagonal on - and one
+    K = 512 update per block) instead of over 128-wide steps (GPMI_BACKWARD_OB=0, a child process: the switch is read
+    once).  Ragged N with a partial last outer block, a whole number of blocks, one block only; also against the oracle."""
+    import os
+    import subprocess
+    import sys
+
+    from oracle import gp_oracle as orc
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys\n"
+        f"sys.path[:0] = [{root!r}, {os.path.join(root, 'inference-tools_amd')!r}]\n"
+        "import numpy as np, workloads as wl\n"
+        "from inference_amd.gp import GpRegressor\n"
+        "out = {}\n"
+        "for n, d, m in ((2500, 3, 77), (4096, 4, 300), (400, 2, 9)):\n"
+        "    x, y, e = wl.synthetic_dataset(4, n, d)\n"
+        "    gp = GpRegressor(x, y, y_err=e, hyperpars=wl.timing_theta(wl.SE, y, d))\n"
+        "    dm, dv = gp.spatial_derivatives(wl.query_points(4, m, d))\n"
+        "    out[f'dm{n}'] = dm; out[f'dv{n}'] = dv\n"
+        "np.savez(sys.argv[1], **out)\n")
+    res = {}
+    for tag, extra in (("wide", {}), ("narrow", {"GPMI_BACKWARD_OB": "0"})):
+        out = str(tmp_path / f"{tag}.npz")
+        run = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **extra), capture_output=True, text=True,
+                             timeout=300)
+        assert run.returncode == 0, (extra, run.stderr[-2000:])
+        res[tag] = dict(np.load(out))
+    for k in res["wide"]:
+        # (two orders of summation of the same products; the variance derivative is a difference of terms: measured 1.1e-13)
+        check(res["wide"][k], res["narrow"][k], 1e-12, f"{k}: 512-wide blocks vs 128-wide steps")
+    # and the wide form against the oracle at the ragged size
+    n, d, m = 2500, 3, 77
+    x, y, e = wl.synthetic_dataset(4, n, d)
+    th = wl.timing_theta(wl.SE, y, d)
+    ref = orc.OracleGp(x, y, e, kernel=wl.SE, hyperpars=th)
+    dm, dv = ref.spatial_derivatives(wl.query_points(4, m, d))
+    check(res["wide"]["dm2500"], dm, what="d mu / dx vs oracle")
+    check(res["wide"]["dv2500"], dv, what="d var / dx vs oracle")
+
+
 @pytest.mark.parametrize("n", [5200, 6500, 8192])
 def test_flow_tail_is_bit_identical_to_stream_order(tmp_path, n):
     """The flag-ordered tile-task factorisation of the chain-bound part (csrc/potrf_flow.hip: persistent task kernel
