@@ -24,9 +24,9 @@ from scipy.optimize import fmin_l_bfgs_b
 class _Run:
     """Reverse-communication state of one L-BFGS-B run (scipy/optimize/_lbfgsb_py.py, _minimize_lbfgsb)."""
 
-    def __init__(self, x0, low, upp, nbd, m, maxls):
+    def __init__(self, x0, clip_low, clip_upp, m):
         n = x0.size
-        self.x = np.array(np.clip(x0, low_or(-np.inf, low, nbd, 1), low_or(np.inf, upp, nbd, 3)), dtype=np.float64)
+        self.x = np.array(np.clip(x0, clip_low, clip_upp), dtype=np.float64)
         self.f = np.array(0.0, dtype=np.float64)
         self.g = np.zeros(n, dtype=np.float64)
         self.wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, np.float64)
@@ -134,7 +134,8 @@ def lockstep_lbfgsb(fun_batch, starts, bounds, pgtol=1e-5, factr=1e7, m=10, maxf
 
 def _drive(setulb, fun_batch, starts, bounds, n, pgtol, factr, m, maxfun, maxiter, maxls):
     low, upp, nbd = _encode_bounds(bounds, n)
-    runs = [_Run(x0, low, upp, nbd, m, maxls) for x0 in starts]
+    clip_low, clip_upp = low_or(-np.inf, low, nbd, 1), low_or(np.inf, upp, nbd, 3)  # (once, not per run: 4096 runs at config 4)
+    runs = [_Run(x0, clip_low, clip_upp, m) for x0 in starts]
     active = list(range(len(runs)))
     while active:
         waiting = []
@@ -158,10 +159,10 @@ def _drive(setulb, fun_batch, starts, bounds, n, pgtol, factr, m, maxfun, maxite
         if waiting:
             X = np.array([runs[k].x for k in waiting])
             f, G = fun_batch(X)
-            for k, fk, gk in zip(waiting, np.asarray(f, dtype=float), np.asarray(G, dtype=float)):
+            for k, fk, gk in zip(waiting, np.asarray(f, dtype=float), np.asarray(G, dtype=float).reshape(len(waiting), n)):
                 r = runs[k]
-                r.f = np.array(float(fk), dtype=np.float64)
-                r.g = np.array(gk, dtype=np.float64).reshape(n)
+                r.f[...] = fk  # (in place: the run keeps its two arrays)
+                r.g[:] = gk
                 r.nfev += 1
         active = waiting
     out = []

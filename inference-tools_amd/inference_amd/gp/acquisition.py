@@ -25,26 +25,35 @@ class AcquisitionFunction:
     def starting_positions(self, bounds):
         """One L-BFGS start per training point inside the bounds, chosen as the best of 20
         jittered probes (acquisition.py:13-37).  The random numbers are drawn in the reference's
-        order; all probes are then ranked from a single batched device evaluation."""
+        order; all probes are then ranked from a single batched device evaluation.
+
+        The reference draws `random(size=L)` 20 times per training point inside the bounds and once per point outside,
+        point by point; here ONE draw of the same total length is cut up in the same order (the legacy generator fills an
+        array sequentially: the numbers, and with them the probes, are the same) - the Python loop over 4096 x 20 probes
+        was a third of the wall time of `GpOptimiser.propose_evaluation` at N = 4096 (round 6)."""
         lwr, upr = [array([k[i] for k in bounds], dtype=float) for i in [0, 1]]
         widths = upr - lwr
         lwr += widths * 0.01
         upr -= widths * 0.01
         L = len(widths)
-        starts, groups = [], []
-        for x0 in self.gp.x:
-            if ((x0 >= lwr) & (x0 <= upr)).all():
-                samples = [x0 + 0.02 * widths * (2 * random(size=L) - 1) for _ in range(20)]
-                samples = [minimum(upr, maximum(lwr, s)) for s in samples]
-                groups.append((len(starts), samples))
-                starts.append(None)
-            else:
-                starts.append(lwr + (upr - lwr) * random(size=L))
-        if groups:
-            flat = array([s for _, grp in groups for s in grp])
-            vals = self.opt_func_batch(flat).reshape(len(groups), 20)
-            for (slot, samples), v in zip(groups, vals):
-                starts[slot] = samples[int(np.argsort(v, kind="stable")[0])]
+        X = np.asarray(self.gp.x, dtype=float).reshape(len(self.gp.x), L)
+        inside = ((X >= lwr) & (X <= upr)).all(axis=1)
+        counts = np.where(inside, 20 * L, L)
+        offs = np.concatenate(([0], np.cumsum(counts)))
+        r = random(size=int(offs[-1]))
+        starts = [None] * len(X)
+        idx_in = np.flatnonzero(inside)
+        for i in np.flatnonzero(~inside):
+            starts[i] = lwr + (upr - lwr) * r[offs[i]:offs[i + 1]]
+        if len(idx_in):
+            take = offs[idx_in][:, None] + np.arange(20 * L)[None, :]
+            rr = r[take].reshape(len(idx_in), 20, L)
+            samples = X[idx_in][:, None, :] + 0.02 * widths * (2 * rr - 1)
+            samples = minimum(upr, maximum(lwr, samples))
+            vals = self.opt_func_batch(samples.reshape(-1, L)).reshape(len(idx_in), 20)
+            best = np.argsort(vals, axis=1, kind="stable")[:, 0]
+            for g, i in enumerate(idx_in):
+                starts[i] = samples[g, best[g]]
         return starts
 
     def update_gp(self, gp):
