@@ -106,7 +106,7 @@ int gpmi_lml_batch(gpmi_ctx* ctx, int kernel, int64_t T, const double* thetas_ho
                    const double* extra_diag_host, const double* mus_host,
                    const double* mu_const_host, double* lml_host, int* info_host);
 /* Asynchronous form of gpmi_lml_batch for the lockstep sizes (n <= 4096, diagonal data errors): submit enqueues the T
- * (<= 128) evaluations of slot 0 or 1 and returns at once, wait blocks until they are through and delivers lml[T] /
+ * (<= 256; GPMI_ASYNC_SLOT_MAX) evaluations of slot 0 or 1 and returns at once, wait blocks until they are through and delivers lml[T] /
  * info[T] in the order submitted.  The two slots are the two halves of the lockstep workspace and run side by side; a
  * value is bit-identical to what gpmi_lml_batch returns for the same hyper-parameters.  What it is for: a tempering
  * driver (mcmc/parallel.py:190-231 in the reference: one process per chain, results over pipes) splits its ladders

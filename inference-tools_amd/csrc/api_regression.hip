@@ -175,7 +175,14 @@ int gpmi_lml_batch_submit(gpmi_ctx* c, int kernel, int64_t T, const double* thet
                           const double* mus, const double* mu_const, int slot) {
   if (!c) return GPMI_ERR_ARG;
   ARGCHK(c, slot == 0 || slot == 1, "slot must be 0 or 1");
-  ARGCHK(c, T >= 1 && T <= 128, "T out of range (1 .. 128 per slot)");
+  // evaluations per slot: GPMI_ASYNC_SLOT_MAX (default 256 - 128 until round 6; the workspace budget GPMI_BATCH_GIB /
+  // GPMI_BATCH_MAX decides how many of them a slot really gets: api.hip, ensure_batch_ws)
+  static const int slot_max = [] {
+    const char* e = std::getenv("GPMI_ASYNC_SLOT_MAX");
+    const int v = e ? std::atoi(e) : 256;
+    return v >= 1 && v <= 2048 ? v : 256;
+  }();
+  ARGCHK(c, T >= 1 && T <= slot_max, "T out of range (1 .. GPMI_ASYNC_SLOT_MAX per slot, default 256)");
   ARGCHK(c, thetas, "thetas is NULL");
   ARGCHK(c, mus || mu_const, "one of mus / mu_const is required");
   ARGCHK(c, c->np <= 4096 && !c->ycov, "asynchronous batches: lockstep sizes only (n <= 4096, diagonal data errors)");
@@ -186,7 +193,7 @@ int gpmi_lml_batch_submit(gpmi_ctx* c, int kernel, int64_t T, const double* thet
   // is pending, all that a slot may ever be asked for (128 evaluations) from the first submission on, as far as the
   // memory cap of ensure_batch_ws allows: a later, larger group of chains then fits whatever the first one was
   if (c->bpend[1 - slot] == 0) {
-    if (int rc = ensure_batch_ws(c, 256)) return rc;  // (a no-op once it is that large)
+    if (int rc = ensure_batch_ws(c, 2 * slot_max)) return rc;  // (a no-op once it is that large)
     ARGCHK(c, c->bcap >= 2 * T, "not enough device memory for two batches of this size");
   } else {
     ARGCHK(c, c->bcap >= 2 * T,

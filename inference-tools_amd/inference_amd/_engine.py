@@ -4,6 +4,7 @@ the device operations of the GP hot path with ndarray arguments / results.
 Used by `inference_amd.gp.regression.GpRegressor` and the covariance classes.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -128,14 +129,17 @@ class GpEngine(_DeviceCommMixin):
                     dptr(out), info.ctypes.data_as(C.POINTER(C.c_int)))
         return out, info
 
-    ASYNC_MAX = 128  # evaluations per slot of the asynchronous form (gpmi.h)
+    # evaluations per slot of the asynchronous form (gpmi.h); the library reads the same three environment variables
+    ASYNC_MAX = int(os.environ.get("GPMI_ASYNC_SLOT_MAX", "256"))
+    _BATCH_GIB = int(os.environ.get("GPMI_BATCH_GIB", "24"))
+    _BATCH_MAX = int(os.environ.get("GPMI_BATCH_MAX", "512"))
 
     def async_slot_capacity(self):
         """Evaluations one asynchronous slot can hold: half of the lockstep workspace (api.hip: ensure_batch_ws keeps it
-        below 256 matrices and 6 GiB)."""
+        below 512 matrices and 24 GiB; GPMI_BATCH_MAX / GPMI_BATCH_GIB)."""
         cap = self.capacity()
         per = cap * (cap + 32) * 8
-        return max(0, min(self.ASYNC_MAX, min(256, (6 << 30) // per) // 2))
+        return max(0, min(self.ASYNC_MAX, min(self._BATCH_MAX, (self._BATCH_GIB << 30) // per) // 2))
 
     def lml_batch_submit(self, slot, kernel, thetas_cov, extra_diag=None, mus=None, mu_const=None):
         """gpmi_lml_batch_submit: enqueue the evaluations of `slot` (0 / 1) and return; `lml_batch_wait(slot)` delivers."""

@@ -327,7 +327,7 @@ def advance_ladders(ladders, n: int, swap_interval=10, batch_posterior=None):
     gmax = 0
     if (len(ladders) > 1 and getattr(bp, "__name__", "") == "marginal_likelihood_batch"
             and hasattr(model, "marginal_likelihood_batch_submit") and model.async_batches()):
-        gmax = min(getattr(model.engine, "ASYNC_MAX", 128), model.engine.async_slot_capacity())
+        gmax = min(getattr(model.engine, "ASYNC_MAX", 256), model.engine.async_slot_capacity())
     if gmax >= max(len(lad.chains) for lad in ladders) and os.environ.get("GPMI_PT_ASYNC", "1") != "0":
         if hasattr(model, "batch_independent_values"):
             model.batch_independent_values(True)  # (a round of one chain must take the same path as a round of many)
