@@ -1,4 +1,6 @@
-"""Fit and LML at mid sizes with and without the CU-masked pair (GPMI_PAIR_MIN_TILES: handles of at least that many tile
+"""(Record of the experiment in profiles/HISTORY.md R6.18: the GPMI_PAIR_MIN_TILES / GPMI_PAIR_POOL_SMALL switches and the pool it
+exercised were a temporary patch of api.hip and are not in the library.)
+Fit and LML at mid sizes with and without the CU-masked pair (GPMI_PAIR_MIN_TILES: handles of at least that many tile
 rows get one - 40 by default, i.e. N >= 5120): what the flag-ordered tail would buy below that."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

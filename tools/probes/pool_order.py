@@ -1,4 +1,6 @@
-"""Does a fit at N = 8192 depend on which pooled pair its handle got / on how many other handles (with pairs) are alive?
+"""(Record of the experiment in profiles/HISTORY.md R6.18: the GPMI_PAIR_MIN_TILES / GPMI_PAIR_POOL_SMALL switches and the pool it
+exercised were a temporary patch of api.hip and are not in the library.)
+Does a fit at N = 8192 depend on which pooled pair its handle got / on how many other handles (with pairs) are alive?
 usage: python tools/probes/pool_order.py <alive small handles before the big one> [closed small handles before]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

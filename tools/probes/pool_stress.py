@@ -1,4 +1,6 @@
-"""Stress of the process-wide pool of CU-masked stream pairs: many handles opened and closed one after another (the pool's one
+"""(Record of the experiment in profiles/HISTORY.md R6.18: the GPMI_PAIR_MIN_TILES / GPMI_PAIR_POOL_SMALL switches and the pool it
+exercised were a temporary patch of api.hip and are not in the library.)
+Stress of the process-wide pool of CU-masked stream pairs: many handles opened and closed one after another (the pool's one
 pair is reused), several alive at once (the pool grows), values checked against the first; then a clean exit (gpmi_shutdown
 from the binding's atexit hook).  usage: python tools/probes/pool_stress.py [cycles]"""
 import os, sys, time
