@@ -298,7 +298,7 @@ void build_mix_square(gpmi_ctx* c, hipStream_t s, const MixEval& mx, double* dst
 // info[slot].  `mu_dev` may be null (then mu_const is used).  `mix` != nullptr: mixture covariance.
 int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const double* mu_dev,
                                double mu_const, int slot, bool allow_lookahead,
-                               const MixEval* mix, bool prebuild_inv2, double* backward_out) {
+                               const MixEval* mix, bool prebuild_inv2, double* backward_out, double* early_identity) {
   hipStream_t s = L.stream;
   L.inv2_valid = false;
   potrf_pair_quiesce(L);  // (before this call's own work reaches the pair: the build below uses the update stream)
@@ -339,6 +339,9 @@ int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const dou
   L.early.np = c->np;
   L.early.fill[0] = L.vec;
   L.early.fill[1] = backward_out;
+  L.early.ident = early_identity;  // (the caller computes the inverse factor next: its right-hand side, 70 us at N = 8192)
+  L.early.ident_ld = c->ld;
+  L.identity_ready = false;
   if (!early_fill) L.early.pending = false;
   potrf_lower(c, L, L.A, c->np, c->ld, L.invD, L.info + slot, allow_lookahead);
   if (!early_fill) L.early.pending = true;
@@ -398,7 +401,8 @@ int ensure_trsm_panel(gpmi_ctx* c, int64_t rows) {
 int enqueue_inverse_factor(gpmi_ctx* c, Lane& L, Lane& F) {
   if (int rc = ensure_inv2(c, F, L.stream)) return rc;
   if (int rc = ensure_trsm_panel(c, c->np)) return rc;
-  launch_set_identity(L.stream, L.B2, c->ld, c->np);
+  if (!L.identity_ready) launch_set_identity(L.stream, L.B2, c->ld, c->np);  // (else: written beside the factorisation, Lane::EarlyWork)
+  L.identity_ready = false;
   trsm_rows_forward(c, L.stream, F.A, c->np, c->ld, F.inv2, L.B2, c->np, true, nullptr, c->trsm_panel);
   return GPMI_OK;
 }

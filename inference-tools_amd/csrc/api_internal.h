@@ -163,7 +163,8 @@ int make_params(gpmi_ctx* c, int kernel, const double* theta, int n_theta, doubl
 int set_device(gpmi_ctx* c);
 void build_mix_square(gpmi_ctx* c, hipStream_t s, const MixEval& mx, double* dst, bool lower_only);
 int enqueue_factor_and_forward(gpmi_ctx* c, Lane& L, const KParams& p, const double* mu_dev, double mu_const, int slot, bool allow_lookahead = true,
-                               const MixEval* mix = nullptr, bool prebuild_inv2 = false, double* backward_out = nullptr);
+                               const MixEval* mix = nullptr, bool prebuild_inv2 = false, double* backward_out = nullptr,
+                               double* early_identity = nullptr);
 int ensure_second_matrix(gpmi_ctx* c, Lane& L);
 int ensure_inv2(gpmi_ctx* c, Lane& F, hipStream_t s);
 int ensure_trsm_panel(gpmi_ctx* c, int64_t rows);

@@ -299,7 +299,7 @@ int gpmi_lml_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
   double* alpha_dev = L.vec + c->np;
   double* gout = L.red + 16;  // n_theta + 1 values (n_theta <= GPMI_MAX_D + 2)
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
-  if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
+  if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0, true, nullptr, false, nullptr, L.B2)) return rc;
   trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, alpha_dev, L.info);
   // K^-1 = L^-T L^-1 (regression.py:556-557), lower tiles, overwriting L
   if (int rc = enqueue_inverse_factor(c, L, L)) return rc;
@@ -781,7 +781,7 @@ int gpmi_loo_terms(gpmi_ctx* c, int kernel, const double* theta, int n_theta, do
   double* alpha_dev = L.vec + c->np;
   double* diag_dev = L.vec + 2 * c->np;
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
-  if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
+  if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0, true, nullptr, false, nullptr, L.B2)) return rc;
   trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, alpha_dev, L.info);
   if (int rc = enqueue_inverse_factor(c, L, L)) return rc;
   launch_rows_sumsq(s, L.B2, c->ld, c->np, c->np, 0.0, diag_dev);
@@ -826,7 +826,7 @@ int gpmi_loo_grad(gpmi_ctx* c, int kernel, const double* theta, int n_theta, dou
   double* partial = L.gws + 4 * c->np;
   double* gout = L.red + 16;
   HIPCHK(c, hipMemcpyAsync(mu_dev, mu, sizeof(double) * c->n, hipMemcpyHostToDevice, s));
-  if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0)) return rc;
+  if (int rc = enqueue_factor_and_forward(c, L, p, mu_dev, 0.0, 0, true, nullptr, false, nullptr, L.B2)) return rc;
   trsv_backward(c, s, L.A, c->np, c->ld, L.invD, L.vec, alpha_dev, L.info);
   // K^-1 (full, both triangles) in A
   if (int rc = enqueue_inverse_factor(c, L, L)) return rc;

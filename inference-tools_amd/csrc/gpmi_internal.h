@@ -56,7 +56,10 @@ struct Lane {
     double* r = nullptr;
     int64_t n = 0, np = 0;
     double* fill[2] = {nullptr, nullptr};
+    double* ident = nullptr;  // np x np matrix (leading dimension ident_ld) to be set to the identity: the right-hand side
+    int64_t ident_ld = 0;     // of the inverse factor the gradient paths compute next (enqueue_inverse_factor)
   } early;
+  bool identity_ready = false;  // EarlyWork has written the identity into B2 for the inverse factor that follows
   bool pair_checked = false;       // potrf_pair_quiesce has run for the factorisation being enqueued (potrf.hip)
   hipEvent_t ev_la = nullptr, ev_panel = nullptr, ev_join = nullptr, ev_main = nullptr, ev_slice = nullptr;
   double* A = nullptr;      // np x ld scratch (K then L)

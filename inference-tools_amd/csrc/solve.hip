@@ -520,6 +520,10 @@ void lane_run_early(Lane& lane, hipStream_t s) {
   launch_residual(s, e.y, e.mu, e.mu_const, e.r, e.n, e.np);
   for (double* f : e.fill)
     if (f) hipLaunchKernelGGL(flow_fill_kernel, dim3((unsigned)((e.np + 255) / 256), 1, 1), dim3(256), 0, s, f, e.np, (int64_t)0);
+  if (e.ident) {
+    launch_set_identity(s, e.ident, e.ident_ld, e.np);
+    lane.identity_ready = true;
+  }
 }
 
 void trsv_forward(gpmi_ctx* c, hipStream_t s, const double* L, int64_t np, int64_t ld,
